@@ -1,0 +1,61 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+class Golden:
+    """Lazy view over one tests/golden/*.npz: ``g.case('c0')`` -> dict of torch tensors."""
+
+    def __init__(self, name):
+        self._z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+    def cases(self, prefix="c"):
+        return sorted({k.split(".")[0] for k in self._z.files if k.startswith(prefix)})
+
+    def case(self, case):
+        pre = case + "."
+        out = {}
+        for k in self._z.files:
+            if k.startswith(pre):
+                a = self._z[k]
+                out[k[len(pre):]] = a if a.dtype.kind in "US" else torch.from_numpy(np.array(a))
+        return out
+
+
+@pytest.fixture(scope="session")
+def golden():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = Golden(name)
+        return cache[name]
+    return get
+
+
+def sub(d, prefix):
+    """{'p.a': x, 'p.b': y} -> {'a': x, 'b': y}"""
+    return {k[len(prefix):]: v for k, v in d.items() if k.startswith(prefix)}
+
+
+def rel_err(a, b):
+    """max|a-b| / max(|b|) -- the relative error used for every fp32 parity bar in this repo."""
+    a = torch.as_tensor(a, dtype=torch.float64).cpu()
+    b = torch.as_tensor(b, dtype=torch.float64).cpu()
+    denom = b.abs().max().clamp_min(1e-30)
+    return float((a - b).abs().max() / denom)
+
+
+requires_gpu = pytest.mark.gpu

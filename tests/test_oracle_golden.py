@@ -1,0 +1,173 @@
+"""Pin the CPU oracle (oracle/lbbnn_oracle.py) to the golden vectors generated from the
+reference's own classes (tests/golden/make_golden.py).  Bar: 1e-6 relative (fp32, same ops,
+only transcendental/summation-order ulps may differ)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err, sub
+from oracle import lbbnn_oracle as orc
+
+TOL = 2e-6
+
+
+# --------------------------------------------------------------------------- LRT
+@pytest.mark.parametrize("case", ["c0", "c1", "c2", "c3"])
+def test_lrt_layer(golden, case):
+    c = golden("lrt.npz").case(case)
+    p = sub(c, "p.")
+    out, kl, _ = orc.lrt_forward(c["x"], p, c["eps"], stochastic=True, compute_kl=True)
+    assert rel_err(out, c["out_train"]) < TOL
+    assert rel_err(kl, c["kl"]) < TOL
+    out, kl, _ = orc.lrt_forward(c["x"], p, c["eps_eval"], stochastic=True, compute_kl=False)
+    assert rel_err(out, c["out_eval_sample"]) < TOL
+    assert float(kl) == 0.0 == float(c["kl_eval"])
+    out, kl, _ = orc.lrt_forward(c["x"], p, None, stochastic=False, compute_kl=True)
+    assert rel_err(out, c["out_mean"]) < TOL
+    assert rel_err(kl, c["kl_logprobs"]) < TOL
+
+
+def test_lrt_smallnet(golden):
+    c = golden("lrt.npz").case("smallnet")
+    layers = [sub(c, "l%d." % i) for i in range(3)]
+    eps = [c["eps%d" % i] for i in range(3)]
+    out, kl = orc.lrt_network_forward(c["x"], layers, eps)
+    assert rel_err(out, c["out"]) < TOL
+    assert rel_err(kl, c["kl"]) < TOL
+
+
+def test_lrt_anchor_value(golden):
+    # seed 0, BayesianLinear(784,400), kl = 1165260.625
+    assert abs(float(golden("lrt.npz").case("anchor")["kl"]) - 1165260.625) < 1.0
+
+
+# --------------------------------------------------------------------------- flows
+@pytest.mark.parametrize("case", ["planar0", "planar1", "planar2", "planar3"])
+def test_planar_1d(golden, case):
+    c = golden("flows.npz").case(case)
+    I, T = [int(v) for v in c["shape"]]
+    flow = orc.flow_from_state("", "Planar", {"." + k: v for k, v in sub(c, "p.").items()}, T)
+    z, ld = flow.run(c["z"])
+    assert rel_err(z, c["z_out"]) < TOL
+    assert abs(float(ld) - float(c["logdet"])) < 1e-7
+    # row-wise restatement == 1-D reference, row by row
+    zz = torch.stack([c["z"], 2 * c["z"], -c["z"]])
+    zr, ldr = flow.run(zz)
+    for r in range(3):
+        z1, l1 = flow.run(zz[r])
+        assert rel_err(zr[r], z1) < TOL
+        assert abs(float(ldr[r]) - float(l1)) < 1e-7
+
+
+@pytest.mark.parametrize("kind,case", [("RNVP", "rnvp0"), ("RNVP", "rnvp1"), ("MNF", "mnf0"), ("MNF", "mnf1")])
+def test_dense_flows(golden, kind, case):
+    c = golden("flows.npz").case(case)
+    R, I, T = [int(v) for v in c["shape"]]
+    flow = orc.flow_from_state("", kind, {"." + k: v for k, v in sub(c, "p.").items()}, T)
+    masks = [c["mask%d" % t] for t in range(T)]
+    z, ld = flow.run(c["z"], masks)
+    assert rel_err(z, c["z_out"]) < TOL
+    assert rel_err(ld, c["logdet"]) < 1e-5
+
+
+# --------------------------------------------------------------------------- MNF layer
+def _mnf_case(c):
+    B, I, O, T = [int(v) for v in c["shape"]]
+    kind = str(c["kind"])
+    p = sub(c, "p.")
+    zf = orc.flow_from_state("z_flow", kind, p, T)
+    rf = orc.flow_from_state("r_flow", kind, p, T)
+    noise = {k: c[k] for k in ("eps_z", "eps_out", "eps_z2", "eps_act")}
+    if kind != "Planar":
+        noise["zmask"] = [c["zmask%d" % t] for t in range(T)]
+        noise["zmask2"] = [c["zmask2_%d" % t] for t in range(T)]
+        noise["rmask"] = [c["rmask%d" % t] for t in range(T)]
+    return p, zf, rf, noise, kind, T
+
+
+@pytest.mark.parametrize("case", ["c%d" % i for i in range(8)])
+def test_mnf_layer(golden, case):
+    c = golden("mnf.npz").case(case)
+    p, zf, rf, noise, kind, T = _mnf_case(c)
+    out, kl, inter = orc.mnf_forward(c["x"], p, zf, rf, noise)
+    assert rel_err(out, c["out_train"]) < TOL
+    assert rel_err(kl, c["kl"]) < TOL
+    # eval / posterior-mean path still draws z (quirk 5)
+    n2 = {"eps_z": c["eps_z_eval"]}
+    if kind != "Planar":
+        n2["zmask"] = [c["zmask_eval%d" % t] for t in range(T)]
+    out, kl, _ = orc.mnf_forward(c["x"], p, zf, rf, n2, stochastic=False, compute_kl=False)
+    assert rel_err(out, c["out_eval_mean"]) < TOL
+    assert float(kl) == 0.0
+
+
+def test_mnf_last_row_only(golden):
+    """Quirk 1: only the LAST row of the B-row z draw reaches the output."""
+    c = golden("mnf.npz").case("c1")
+    p, zf, rf, noise, _, _ = _mnf_case(c)
+    out, kl, _ = orc.mnf_forward(c["x"], p, zf, rf, noise)
+    n2 = dict(noise)
+    e = noise["eps_z"].clone()
+    e[:-1] = 123.0
+    n2["eps_z"] = e
+    out2, kl2, _ = orc.mnf_forward(c["x"], p, zf, rf, n2)
+    assert torch.equal(out, out2) and torch.equal(kl, kl2)
+
+
+def test_mnf_smallnet(golden):
+    c = golden("mnf.npz").case("smallnet")
+    layers, zfs, rfs, noise = [], [], [], []
+    for i in range(3):
+        p = sub(c, "l%d.p." % i)
+        layers.append(p)
+        zfs.append(orc.flow_from_state("z_flow", "Planar", p, 2))
+        rfs.append(orc.flow_from_state("r_flow", "Planar", p, 2))
+        noise.append({k: c["l%d.%s" % (i, k)] for k in ("eps_z", "eps_out", "eps_z2", "eps_act")})
+    out, kl = orc.mnf_network_forward(c["x"], layers, zfs, rfs, noise)
+    assert rel_err(out, c["out"]) < TOL
+    assert rel_err(kl, c["kl"]) < TOL
+
+
+# --------------------------------------------------------------------------- base LBBNN
+@pytest.mark.parametrize("case", ["c0", "c1", "c2"])
+def test_base_layer(golden, case):
+    c = golden("base.npz").case(case)
+    p = sub(c, "p.")
+    noise = {k: c[k] for k in ("eps_w", "eps_b", "tau_w", "tau_b")}
+    out, lp, lq = orc.base_forward(c["x"], p, c["cgamma"], noise, mode="sample")
+    assert rel_err(out, c["out_train"]) < TOL
+    assert rel_err(lp, c["log_prior"]) < 1e-5
+    assert rel_err(lq, c["log_q"]) < 1e-5
+    hard = torch.round(c["cgamma"])
+    noise = {k: c["x_" + k] for k in ("eps_w", "eps_b", "tau_w", "tau_b")}
+    ex = dict(weight_prior=True, bias_prior=True, gamma_prior=True, gamma=True)
+    out, lp, lq = orc.base_forward(c["x"], p, hard, noise, mode="sample", exact=ex)
+    assert rel_err(out, c["x_out_train"]) < TOL
+    assert rel_err(lp, c["x_log_prior"]) < 1e-5
+    assert rel_err(lq, c["x_log_q"]) < 1e-5
+    out, _, _ = orc.base_forward(c["x"], p, hard, {}, mode="medimean", compute_lp=False)
+    assert rel_err(out, c["out_medimean"]) < TOL
+    out, _, _ = orc.base_forward(c["x"], p, hard, {}, mode="mean", compute_lp=False, alpha_attr=c["alpha_attr"])
+    assert rel_err(out, c["out_mean"]) < TOL
+
+
+# --------------------------------------------------------------------------- variational dropout
+@pytest.mark.parametrize("case", ["c0", "c1", "c2"])
+def test_vd_layer(golden, case):
+    c = golden("vd.npz").case(case)
+    out = orc.vd_forward(c["x"], c["theta"], c["alpha"], c["zeta"])
+    assert rel_err(out, c["out"]) < TOL
+    nll = torch.nn.functional.nll_loss(torch.log_softmax(out, 1), c["target"], reduction="sum")
+    loss = orc.vd_kl([c["alpha"]]) / float(c["num_batches"]) + nll
+    assert rel_err(loss, c["loss"]) < 1e-5
+
+
+# --------------------------------------------------------------------------- fp64 truth sanity
+def test_fp64_truth_close(golden):
+    """The oracle is dtype-preserving: the fp64 run bounds the fp32 reference's own error."""
+    c = golden("lrt.npz").case("c2")
+    p64 = {k: v.double() for k, v in sub(c, "p.").items()}
+    out, kl, _ = orc.lrt_forward(c["x"].double(), p64, c["eps"].double())
+    assert out.dtype == torch.float64
+    assert rel_err(out, c["out_train"]) < 1e-5
+    assert rel_err(kl, c["kl"]) < 1e-5
