@@ -1,0 +1,102 @@
+"""Interim backward pass: differentiable PyTorch-ROCm restatement of the layer arithmetic.
+
+The FORWARD of every layer runs in the hand-written HIP kernels.  Until the HIP backward
+kernels land, ``loss.backward()`` is served by recomputing the layer with
+the torch ops below *on the GPU tensors* under autograd, using exactly the noise the forward
+kernels drew (re-created with ``lbbnn_philox_normal``).  This module is only ever entered from
+``autograd.Function.backward``; nothing in the forward path calls it, and it never touches CPU.
+"""
+import math
+
+import torch
+
+
+def _sigma(rho):
+    return torch.log1p(torch.exp(rho))
+
+
+def _alpha(lam):
+    return 1 / (1 + torch.exp(-lam))
+
+
+def _kl_bias(bias_mu, bias_rho, pr):
+    sb = _sigma(bias_rho)
+    return (torch.log(pr.bias_sigma_prior / sb) - 0.5
+            + (sb ** 2 + (bias_mu - pr.bias_mu_prior) ** 2) / (2 * pr.bias_sigma_prior ** 2)).sum()
+
+
+def _kl_weight(mu_eff, sigma, alpha, pr):
+    return (alpha * (torch.log(pr.sigma_prior / sigma) - 0.5 + torch.log(alpha / pr.alpha_prior)
+                     + (sigma ** 2 + (mu_eff - pr.mu_prior) ** 2) / (2 * pr.sigma_prior ** 2))
+            + (1 - alpha) * torch.log((1 - alpha) / (1 - pr.alpha_prior))).sum()
+
+
+def _planar(z, tr):
+    logdet = z.new_zeros(())
+    for (u, w, b) in tr:
+        inner = torch.dot(w, z) + b[0]
+        th = torch.tanh(inner)
+        z = z + u * th
+        logdet = logdet + torch.log(torch.abs(1 + (1 - th ** 2) * torch.dot(u, w)))
+    return z, logdet
+
+
+def lrt_torch(x, P, noise, *, stochastic, want_kl, priors, relu):
+    """LBBNN-GP-MF-LRT.py:166-197 as differentiable torch ops. P: dict of tensors."""
+    alpha = _alpha(P["lambdal"])
+    e_w = P["weight_mu"] * alpha
+    out = x @ e_w.T + P["bias_mu"]
+    sigma = None
+    if stochastic:
+        sigma = _sigma(P["weight_rho"])
+        var_b = (x ** 2) @ (sigma ** 2 * alpha ** 2).T + _sigma(P["bias_rho"]) ** 2
+        out = out + torch.sqrt(var_b) * noise["eps_out"]
+    if relu:
+        out = torch.relu(out)
+    kl = None
+    if want_kl:
+        sigma = _sigma(P["weight_rho"]) if sigma is None else sigma
+        kl = _kl_bias(P["bias_mu"], P["bias_rho"], priors) + _kl_weight(P["weight_mu"], sigma, alpha, priors)
+    return out, kl
+
+
+def mnf_planar_torch(x, P, zf, rf, noise, *, stochastic, want_kl, priors, relu):
+    """LBBNN-GP-MF-MNF.py:190-239 with planar flows, only the kept z row.
+
+    zf / rf: lists of (u, w, bias) tensors.  noise: eps_z (I,), eps_out (B,O), eps_z2 (I,), eps_act (O,).
+    """
+    alpha = _alpha(P["lambdal"])
+    q0_std = P["q0_log_var"].exp().sqrt()
+    z_k, _ = _planar(P["q0_mean"] + q0_std * noise["eps_z"], zf)
+    e_w = P["weight_mu"] * alpha
+    out = (x * z_k) @ e_w.T + P["bias_mu"]
+    sigma = None
+    if stochastic:
+        sigma = _sigma(P["weight_rho"])
+        var_b = (x ** 2) @ (sigma ** 2 * alpha ** 2).T + _sigma(P["bias_rho"]) ** 2
+        out = out + torch.sqrt(var_b) * noise["eps_out"]
+    if relu:
+        out = torch.relu(out)
+    kl = None
+    if want_kl:
+        sigma = _sigma(P["weight_rho"]) if sigma is None else sigma
+        z0 = P["q0_mean"] + q0_std * noise["eps_z2"]
+        z2, log_det_q = _planar(z0, zf)
+        log_q0 = (-0.5 * math.log(math.pi) - 0.5 * P["q0_log_var"]
+                  - 0.5 * ((z0 - P["q0_mean"]) ** 2 / P["q0_log_var"].exp())).sum()
+        log_q = -log_det_q + log_q0
+        W_mean = z2 * P["weight_mu"] * alpha
+        W_var = sigma ** 2 * alpha ** 2
+        act_mu = P["r0_c"] @ W_mean.T
+        act_var = P["r0_c"] ** 2 @ W_var.T
+        act = torch.tanh(act_mu + act_var.sqrt() * noise["eps_act"])
+        m = act.mean()
+        mean_r = P["r0_b1"] * m
+        log_var_r = P["r0_b2"] * m
+        z_b, log_det_r = _planar(z2, rf)
+        log_rb = (-0.5 * math.log(math.pi) - 0.5 * log_var_r
+                  - 0.5 * ((z_b[-1] - mean_r) ** 2 / log_var_r.exp())).sum()
+        log_r = log_det_r + log_rb
+        kl = (_kl_bias(P["bias_mu"], P["bias_rho"], priors)
+              + _kl_weight(P["weight_mu"] * z2, sigma, alpha, priors) + log_q - log_r)
+    return out, kl

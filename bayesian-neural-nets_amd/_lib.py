@@ -1,0 +1,74 @@
+"""ctypes binding of the C ABI in include/lbbnn.h.
+
+There is deliberately NO fallback: if ``csrc/liblbbnn_hip.so`` is missing, or a tensor is not on
+a HIP device, the call raises.  (The CPU oracle under ``oracle/`` is test infrastructure and is
+never imported from here.)
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liblbbnn_hip.so")
+
+c_p = ctypes.c_void_p
+c_i = ctypes.c_int
+c_u32 = ctypes.c_uint32
+c_i64 = ctypes.c_int64
+c_u64 = ctypes.c_uint64
+
+
+class Priors(ctypes.Structure):
+    """lbbnn_priors_t (include/lbbnn.h)."""
+    _fields_ = [("mu_prior", ctypes.c_float), ("sigma_prior", ctypes.c_float),
+                ("alpha_prior", ctypes.c_float), ("bias_mu_prior", ctypes.c_float),
+                ("bias_sigma_prior", ctypes.c_float)]
+
+    def __init__(self, mu_prior=0.0, sigma_prior=1.0, alpha_prior=0.05, bias_mu_prior=0.0,
+                 bias_sigma_prior=1.0):
+        super().__init__(mu_prior, sigma_prior, alpha_prior, bias_mu_prior, bias_sigma_prior)
+
+
+# name -> (restype, argtypes); must list every symbol include/lbbnn.h declares
+SIGNATURES = {
+    "lbbnn_abi_version": (c_i, []),
+    "lbbnn_error_string": (ctypes.c_char_p, [c_i]),
+    "lbbnn_operand_ld": (c_i, [c_i]),
+    "lbbnn_weight_pass": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.POINTER(Priors),
+                                c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "lbbnn_lrt_gemm": (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_u32, c_i64,
+                             c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "lbbnn_mnf_flow_planar": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p,
+                                    c_p, c_u32, c_p, c_p, c_p, c_i, c_i, c_p]),
+    "lbbnn_kl_finalize": (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p,
+                                ctypes.POINTER(Priors), c_p, c_u32, c_p, c_p, c_i, c_p]),
+    "lbbnn_rng_advance": (c_i, [c_p, c_u64, c_p]),
+    "lbbnn_philox_normal": (c_i, [c_p, c_u32, c_i64, c_i64, c_i64, c_p, c_p]),
+    "lbbnn_log_softmax_rows": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library; raise loudly if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "bnn_amd: HIP extension not built: %s is missing. Build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` or "
+                "`make -C bayesian-neural-nets_amd/csrc` (hipcc, --offload-arch=gfx950). "
+                "There is no CPU fallback." % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)      # AttributeError => header/library out of sync: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().lbbnn_error_string(rc)
+        raise RuntimeError("bnn_amd: %s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))

@@ -1,0 +1,82 @@
+// Device-side helpers shared by the gfx950 kernels: wave64/block reductions, Philox4x32-10,
+// Box-Muller, and the accurate elementwise forms the KL terms need.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lbbnn {
+
+constexpr int kWave = 64;   // CDNA wavefront
+
+// ------------------------------------------------------------------------------------------ reductions
+// Fixed-order butterfly over the 64 lanes of a wave: every lane ends with the full sum, and the
+// order of additions is independent of scheduling, so results are bitwise reproducible.
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
+// Block-wide sum for blockDim.x = NW*64 threads; `scratch` holds NW values of T in LDS.
+// All threads get the result. Contains two barriers.
+template <typename T, int NW>
+__device__ __forceinline__ T block_sum(T v, T* scratch) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();                 // protect scratch from a previous use
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    T s = scratch[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) s += scratch[i];
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------ elementwise
+// softplus exactly as the reference spells it: log1p(exp(rho)) (LBBNN-GP-MF-LRT.py:81-82).
+__device__ __forceinline__ float softplus_ref(float rho) { return log1pf(expf(rho)); }
+// alpha = 1/(1+exp(-lambda)) (LBBNN-GP-MF-LRT.py:167)
+__device__ __forceinline__ float sigmoid_ref(float l) { return 1.0f / (1.0f + expf(-l)); }
+
+// ------------------------------------------------------------------------------------------ Philox4x32-10
+struct Philox4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                 uint32_t k0, uint32_t k1) {
+    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+        const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    return Philox4{c0, c1, c2, c3};
+}
+
+// Four N(0,1) draws for counter (ctr0, ctr1) of stream `stream`; rng = {seed, offset}.
+// Counter layout: (ctr0_lo, ctr0_hi ^ ctr1<<?, ...) kept simple and collision-free:
+//   c0 = ctr0 low 32, c1 = ctr0 high 32, c2 = ctr1, c3 = stream ^ (offset_hi mixed into key)
+// key = seed_lo ^ offset_lo*golden, seed_hi ^ offset_hi.  Distinct (seed, offset, stream, ctr) never collide
+// within one (seed, offset) because the counter words are distinct; offset enters through the key.
+__device__ __forceinline__ void philox_normal4(uint64_t seed, uint64_t offset, uint32_t stream,
+                                               uint64_t ctr0, uint32_t ctr1, float out[4]) {
+    const uint32_t k0 = (uint32_t)seed ^ ((uint32_t)offset * 0x9E3779B9u);
+    const uint32_t k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(offset >> 32) ^ ((uint32_t)offset >> 7);
+    const Philox4 r = philox4x32_10((uint32_t)ctr0, (uint32_t)(ctr0 >> 32), ctr1, stream, k0, k1);
+    // Box-Muller on two pairs; u in (0,1]: (x + 1) * 2^-32 avoids log(0).
+    const float u0 = ((float)r.x + 1.0f) * 2.3283064365386963e-10f;
+    const float u1 = (float)r.y * 2.3283064365386963e-10f;
+    const float u2 = ((float)r.z + 1.0f) * 2.3283064365386963e-10f;
+    const float u3 = (float)r.w * 2.3283064365386963e-10f;
+    const float ra = sqrtf(-2.0f * __logf(fminf(u0, 1.0f)));
+    const float rb = sqrtf(-2.0f * __logf(fminf(u2, 1.0f)));
+    float sa, ca, sb, cb;
+    __sincosf(6.283185307179586f * u1, &sa, &ca);
+    __sincosf(6.283185307179586f * u3, &sb, &cb);
+    out[0] = ra * ca; out[1] = ra * sa; out[2] = rb * cb; out[3] = rb * sb;
+}
+
+}  // namespace lbbnn

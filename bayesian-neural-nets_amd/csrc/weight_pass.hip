@@ -1,0 +1,159 @@
+// K1 -- fused pass over the (O,I) variational parameters of one Bayesian layer (gfx950).
+//
+// One HBM read of mu/rho/lambdal (12 B per weight) produces everything the rest of the layer
+// needs from them: the two GEMM operands (e_w with the MNF multiplier z folded in, var_w), the
+// per-row KL sums, and the auxiliary-posterior row reductions act_mu / act_var.  The reference
+// spends ~25 separate full-matrix aten passes on the same values.
+//
+// Roofline: HBM.  Algorithmic bytes per weight: 12 read + 8 written (fp32 operands).
+// Mapping: one 256-thread workgroup per output row o; thread t owns float4 column groups
+// t, t+256, ... so a wave reads 1 KiB contiguous per instruction.  Row sums use a fixed-order
+// wave butterfly + LDS, so kl_rows / act_* are bitwise reproducible.
+#include "lbbnn_device.h"
+#include "../../include/lbbnn.h"
+
+namespace {
+
+using namespace lbbnn;
+
+struct WeightPassArgs {
+    const float* mu; const float* rho; const float* lambdal;
+    const float* z_fwd; const float* z_kl; const float* r0_c; const float* bias_rho;
+    float* e_w; float* var_w;
+    float* kl_rows; float* act_mu; float* act_var; float* bias_var;
+    int O, I, ld;
+    float mu_prior, sigma_prior, alpha_prior;
+};
+
+struct Elem { float ew, vw, kl, amu, avar; };
+
+// All per-weight arithmetic, spelled in the reference's operation order
+// (LBBNN-GP-MF-LRT.py:167-171,189-192; LBBNN-GP-MF-MNF.py:195-196,211-212,230-233).
+__device__ __forceinline__ Elem weight_elem(float mu, float rho, float lam, float zf, float zk, float rc,
+                                            bool want_kl, bool want_act, const WeightPassArgs& a) {
+    Elem e;
+    const float alpha = sigmoid_ref(lam);
+    const float sigma = softplus_ref(rho);
+    const float ea = mu * alpha;
+    e.ew = ea * zf;
+    e.vw = (sigma * sigma) * (alpha * alpha);
+    e.kl = 0.f; e.amu = 0.f; e.avar = 0.f;
+    if (want_kl) {
+        const float d = mu * zk - a.mu_prior;
+        const float sp = a.sigma_prior;
+        e.kl = alpha * (logf(sp / sigma) - 0.5f + logf(alpha / a.alpha_prior)
+                        + (sigma * sigma + d * d) / (2.f * sp * sp))
+             + (1.f - alpha) * logf((1.f - alpha) / (1.f - a.alpha_prior));
+    }
+    if (want_act) {
+        e.amu = rc * ((zk * mu) * alpha);
+        e.avar = (rc * rc) * e.vw;
+    }
+    return e;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void weight_pass_kernel(const WeightPassArgs a) {
+    __shared__ float red[3][4];
+    const int o = blockIdx.x;
+    const int tid = threadIdx.x;
+    const size_t rowoff = (size_t)o * a.I;
+    const bool want_kl = a.kl_rows != nullptr;
+    const bool want_act = a.act_mu != nullptr;
+    float kl = 0.f, amu = 0.f, avar = 0.f;
+
+    if (VEC) {
+        const int n4 = a.ld >> 2, i4 = a.I >> 2;
+        for (int j = tid; j < n4; j += 256) {
+            float4 ew = make_float4(0.f, 0.f, 0.f, 0.f), vw = ew;
+            if (j < i4) {
+                const float4 mu = reinterpret_cast<const float4*>(a.mu + rowoff)[j];
+                const float4 rho = reinterpret_cast<const float4*>(a.rho + rowoff)[j];
+                const float4 lam = reinterpret_cast<const float4*>(a.lambdal + rowoff)[j];
+                const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
+                const float4 zf = a.z_fwd ? reinterpret_cast<const float4*>(a.z_fwd)[j] : one;
+                const float4 zk = a.z_kl ? reinterpret_cast<const float4*>(a.z_kl)[j] : one;
+                const float4 rc = a.r0_c ? reinterpret_cast<const float4*>(a.r0_c)[j] : one;
+                const Elem e0 = weight_elem(mu.x, rho.x, lam.x, zf.x, zk.x, rc.x, want_kl, want_act, a);
+                const Elem e1 = weight_elem(mu.y, rho.y, lam.y, zf.y, zk.y, rc.y, want_kl, want_act, a);
+                const Elem e2 = weight_elem(mu.z, rho.z, lam.z, zf.z, zk.z, rc.z, want_kl, want_act, a);
+                const Elem e3 = weight_elem(mu.w, rho.w, lam.w, zf.w, zk.w, rc.w, want_kl, want_act, a);
+                ew = make_float4(e0.ew, e1.ew, e2.ew, e3.ew);
+                vw = make_float4(e0.vw, e1.vw, e2.vw, e3.vw);
+                kl += (e0.kl + e1.kl) + (e2.kl + e3.kl);
+                amu += (e0.amu + e1.amu) + (e2.amu + e3.amu);
+                avar += (e0.avar + e1.avar) + (e2.avar + e3.avar);
+            }
+            if (a.e_w) reinterpret_cast<float4*>(a.e_w + (size_t)o * a.ld)[j] = ew;
+            if (a.var_w) reinterpret_cast<float4*>(a.var_w + (size_t)o * a.ld)[j] = vw;
+        }
+    } else {
+        for (int i = tid; i < a.ld; i += 256) {
+            float ew = 0.f, vw = 0.f;
+            if (i < a.I) {
+                const Elem e = weight_elem(a.mu[rowoff + i], a.rho[rowoff + i], a.lambdal[rowoff + i],
+                                           a.z_fwd ? a.z_fwd[i] : 1.f, a.z_kl ? a.z_kl[i] : 1.f,
+                                           a.r0_c ? a.r0_c[i] : 1.f, want_kl, want_act, a);
+                ew = e.ew; vw = e.vw; kl += e.kl; amu += e.amu; avar += e.avar;
+            }
+            if (a.e_w) a.e_w[(size_t)o * a.ld + i] = ew;
+            if (a.var_w) a.var_w[(size_t)o * a.ld + i] = vw;
+        }
+    }
+
+    if (want_kl || want_act) {
+        kl = wave_sum(kl); amu = wave_sum(amu); avar = wave_sum(avar);
+        const int lane = tid & 63, w = tid >> 6;
+        if (lane == 0) { red[0][w] = kl; red[1][w] = amu; red[2][w] = avar; }
+        __syncthreads();
+        if (tid == 0) {
+            if (want_kl) a.kl_rows[o] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+            if (want_act) {
+                a.act_mu[o] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+                a.act_var[o] = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+            }
+        }
+    }
+    if (tid == 0 && a.bias_var && a.bias_rho) {
+        const float sb = softplus_ref(a.bias_rho[o]);
+        a.bias_var[o] = sb * sb;                      // bias.sigma**2, LBBNN-GP-MF-LRT.py:173
+    }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" int lbbnn_operand_ld(int I) { return I <= 0 ? 0 : ((I + 31) / 32) * 32; }
+
+extern "C" int lbbnn_weight_pass(const float* mu, const float* rho, const float* lambdal,
+                                 const float* z_fwd, const float* z_kl, const float* r0_c,
+                                 const float* bias_rho, const lbbnn_priors_t* priors,
+                                 void* e_w, void* var_w, int ld,
+                                 float* kl_rows, float* act_mu, float* act_var, float* bias_var,
+                                 int O, int I, int flags, void* stream) {
+    if (!mu || !rho || !lambdal || !priors) return LBBNN_E_NULL;
+    if (O <= 0 || I <= 0) return LBBNN_E_SHAPE;
+    if (flags & ~LBBNN_F_SPLIT16) return LBBNN_E_FLAGS;
+    if (flags & LBBNN_F_SPLIT16) return LBBNN_E_FLAGS;   // split-precision operands: not in this build
+    if ((e_w || var_w) && (ld < I || (ld & 31))) return LBBNN_E_ALIGN;
+    if ((act_mu == nullptr) != (act_var == nullptr)) return LBBNN_E_NULL;
+    if (act_mu && (!z_kl || !r0_c)) return LBBNN_E_NULL;
+    if (bias_var && !bias_rho) return LBBNN_E_NULL;
+    if ((e_w && !aligned16(e_w)) || (var_w && !aligned16(var_w))) return LBBNN_E_ALIGN;
+
+    WeightPassArgs a;
+    a.mu = mu; a.rho = rho; a.lambdal = lambdal; a.z_fwd = z_fwd; a.z_kl = z_kl; a.r0_c = r0_c;
+    a.bias_rho = bias_rho;
+    a.e_w = static_cast<float*>(e_w); a.var_w = static_cast<float*>(var_w);
+    a.kl_rows = kl_rows; a.act_mu = act_mu; a.act_var = act_var; a.bias_var = bias_var;
+    a.O = O; a.I = I; a.ld = (e_w || var_w) ? ld : lbbnn_operand_ld(I);
+    a.mu_prior = priors->mu_prior; a.sigma_prior = priors->sigma_prior; a.alpha_prior = priors->alpha_prior;
+
+    const bool vec = (I % 4 == 0) && aligned16(mu) && aligned16(rho) && aligned16(lambdal) &&
+                     (!z_fwd || aligned16(z_fwd)) && (!z_kl || aligned16(z_kl)) && (!r0_c || aligned16(r0_c));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (vec) hipLaunchKernelGGL(weight_pass_kernel<true>, dim3(O), dim3(256), 0, s, a);
+    else     hipLaunchKernelGGL(weight_pass_kernel<false>, dim3(O), dim3(256), 0, s, a);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,93 @@
+"""Normalizing-flow parameter containers with the reference's module/parameter names
+(flows2.py:14-241), so ``state_dict`` keys and optimizer parameter groups carry over:
+``z_flow.transforms.N.{u,w,bias}`` (planar), ``….network.{0,2,4,6}.*, t.*, s.*`` (RNVP),
+``….{f,g,k}.*`` (MNF).
+
+The transforms hold parameters only; the arithmetic runs in the HIP kernels
+(``lbbnn_mnf_flow_planar`` for planar flows).  Initialisation reproduces the reference's
+formulas and draw order, so a seeded construction yields the reference's values.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def parameter_init(low, high, size):
+    # (low - high) * U[0,1) + high, as flows2.py:10-12
+    return (low - high) * torch.rand(size) + high
+
+
+class PlanarTransform(nn.Module):
+    """Parameters of one planar transform (flows2.py:72-95): u, w (dim,), bias (1,)."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.u = nn.Parameter(parameter_init(-0.01, 0.01, dim))
+        self.w = nn.Parameter(parameter_init(-0.01, 0.01, dim))
+        self.bias = nn.Parameter(parameter_init(-0.01, 0.01, 1))
+
+
+class _MLP(nn.Sequential):
+    def __init__(self, *layer_sizes, leaky_a=0.1):
+        layers = []
+        for s1, s2 in zip(layer_sizes, layer_sizes[1:]):
+            layers.append(nn.Linear(s1, s2))
+            layers.append(nn.LeakyReLU(leaky_a))
+        super().__init__(*layers[:-1])
+
+
+class RNVP(nn.Module):
+    """Parameters of one RNVP coupling transform (flows2.py:188-219)."""
+
+    def __init__(self, dim, h_sizes=(75, 75, 75, 75)):
+        super().__init__()
+        self.network = _MLP(*([dim] + list(h_sizes)))
+        self.t = nn.Linear(h_sizes[-1], dim)
+        self.s = nn.Linear(h_sizes[-1], dim)
+
+
+class MNF(nn.Module):
+    """Parameters of one MNF-type transform (flows2.py:225-241)."""
+
+    def __init__(self, dim, hidden=100):
+        super().__init__()
+        self.f = nn.Linear(dim, hidden)
+        self.g = nn.Linear(hidden, dim)
+        self.k = nn.Linear(hidden, dim)
+
+
+_KINDS = {"Planar": PlanarTransform, "RNVP": RNVP, "MNF": MNF}
+
+
+class PropagateFlow(nn.Module):
+    """flows2.PropagateFlow(transform, dim, num_transforms): same ctor, ``forward(z) -> (z, logdet)``."""
+
+    def __init__(self, transform, dim, num_transforms):
+        super().__init__()
+        if transform not in _KINDS:
+            raise NotImplementedError(
+                "flow type %r: only %s have HIP kernels in this build (Radial/Householder/Sylvester/mixed "
+                "are 'next' rows of SURVEY.md 8f)" % (transform, sorted(_KINDS)))
+        self.kind = transform
+        self.dim = dim
+        self.transforms = nn.ModuleList([_KINDS[transform](dim) for _ in range(num_transforms)])
+
+    def planar_params(self):
+        return [(t.u, t.w, t.bias) for t in self.transforms]
+
+    def forward(self, z):
+        """Stand-alone flow on a 1-D z (what ``r_flow(z2)`` does at LBBNN-GP-MF-MNF.py:222)."""
+        if self.kind != "Planar":
+            raise NotImplementedError("stand-alone %s flow forward" % self.kind)
+        if z.dim() != 1:
+            z = z.reshape(-1, self.dim)[-1]
+        # the fused kernel computes z_flow(q0_mean + exp(lv)^.5 * eps): lv -> -inf, eps = 0 gives flow(z)
+        lv = torch.full_like(z, -1e30)
+        eps = torch.zeros_like(z)
+        out = torch.empty_like(z)
+        scal = torch.empty(8, dtype=torch.float32, device=z.device)
+        with torch.no_grad():
+            ops.mnf_flow_planar(z.detach().contiguous(), lv, self.planar_params(), [], eps_fwd=eps,
+                                z_fwd=out, scal=scal, want_kl=False)
+        return out, scal[4]

@@ -1,0 +1,341 @@
+"""Drop-in ``torch.nn.Module``s for the reference's Bayesian linear layers, forward in HIP.
+
+``LRTBayesianLinear``  <-> BayesianLinear of LBBNN-GP-MF-LRT.py:129-197
+``MNFBayesianLinear``  <-> BayesianLinear of LBBNN-GP-MF-MNF.py:133-239
+``LRTBayesianNetwork`` / ``MNFBayesianNetwork`` <-> BayesianNetwork (…LRT.py:199-214, …MNF.py:244-260)
+
+Same constructor positional arguments, same ``forward(input, sample=False,
+calculate_log_probs=False)``, same ``.kl`` attribute, same parameter names (so ``state_dict``s,
+optimizer parameter groups by attribute and the eval code's ``layer.gamma.rsample()`` /
+``layer.alpha_q`` accesses carry over).  Seeded construction consumes the torch generator in the
+reference's order, so ``torch.manual_seed(s); BayesianLinear(...)`` gives the reference's values.
+
+Additions (keyword-only, defaults = reference behaviour): ``priors=``, ``z_flow_type= /
+r_flow_type=`` (module globals in the reference, LBBNN-GP-MF-MNF.py:46-47), and ``layer.noise``
+-- a dict of explicit draws (``eps_out, eps_z, eps_z2, eps_act``) for parity tests; when
+``None`` the kernels draw N(0,1) in-kernel (Philox) from the device RNG state.
+
+There is no CPU path: parameters may be *constructed* on CPU (as the reference does) but
+``forward`` needs them on a HIP device.
+"""
+import itertools
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _grad, ops
+from ._lib import Priors
+from .distributions import Bernoulli, Gaussian
+from .flows import PropagateFlow
+
+_layer_ids = itertools.count()
+
+
+class _BayesLinearFn(torch.autograd.Function):
+    """Forward: HIP kernels.  Backward: torch-op recompute on the GPU (see _grad.py)."""
+
+    @staticmethod
+    def forward(ctx, layer, x, cfg, *params):
+        out, kl, saved = layer._forward_hip(x, cfg)
+        ctx.layer, ctx.cfg, ctx.saved = layer, cfg, saved
+        ctx.save_for_backward(x, *params)
+        if kl is None:
+            kl = out.new_zeros(())
+        return out, kl
+
+    @staticmethod
+    def backward(ctx, g_out, g_kl):
+        layer, cfg = ctx.layer, ctx.cfg
+        x, *params = ctx.saved_tensors
+        noise = layer._noise_for_backward(ctx.saved, x.shape[0])
+        with torch.enable_grad():
+            xs = x.detach().requires_grad_(ctx.needs_input_grad[1])
+            ps = [p.detach().requires_grad_(True) for p in params]
+            out_t, kl_t = layer._forward_torch(xs, ps, cfg, noise)
+            outs, gouts = [out_t], [g_out]
+            if kl_t is not None:
+                outs.append(kl_t)
+                gouts.append(g_kl)
+            wrt = ([xs] if xs.requires_grad else []) + ps
+            grads = list(torch.autograd.grad(outs, wrt, gouts, allow_unused=True))
+        gx = grads.pop(0) if xs.requires_grad else None
+        return (None, gx, None, *grads)
+
+
+class _BayesLinearBase(nn.Module):
+    _mnf = False
+
+    def _common_init(self, in_features, out_features, mu_range, priors):
+        self.in_features = in_features
+        self.out_features = out_features
+        self.priors = priors if priors is not None else Priors()
+        # creation order == reference (LBBNN-GP-MF-LRT.py:137-155): mu, rho, lambdal, alpha_q, bias_mu, bias_rho
+        self.weight_mu = nn.Parameter(torch.Tensor(out_features, in_features).uniform_(-mu_range, mu_range))
+        self.weight_rho = nn.Parameter(torch.Tensor(out_features, in_features).uniform_(-5, -4))
+        self.weight = Gaussian(self.weight_mu, self.weight_rho)
+        self.lambdal = nn.Parameter(torch.Tensor(out_features, in_features).uniform_(0, 1))
+        self._alpha_q_init = torch.Tensor(out_features, in_features).uniform_(0.999, 0.9999)   # placeholder draw, :147
+        self.gamma = Bernoulli(self._alpha_q_init)
+        self.gamma.bind(self._alpha_now)
+        self.bias_mu = nn.Parameter(torch.Tensor(out_features).uniform_(-0.2, 0.2))
+        self.bias_rho = nn.Parameter(torch.Tensor(out_features).uniform_(-5, -4))
+        self.bias = Gaussian(self.bias_mu, self.bias_rho)
+        self.kl = 0
+        self.noise: Optional[Dict[str, torch.Tensor]] = None
+        self.row_offset = 0            # global row index of this rank's first batch row (data parallel)
+        self._layer_id = next(_layer_ids) % 64
+        self._ws = None
+
+    # reference keeps the prior tensors as attributes; expose them lazily with the same names
+    @property
+    def mu_prior(self):
+        return torch.full_like(self.weight_mu, self.priors.mu_prior).detach()
+
+    @property
+    def sigma_prior(self):
+        return torch.full_like(self.weight_mu, self.priors.sigma_prior).detach()
+
+    @property
+    def alpha_prior(self):
+        return torch.full_like(self.weight_mu, self.priors.alpha_prior).detach()
+
+    def _workspace(self):
+        dev = self.weight_mu.device
+        if self._ws is None or self._ws.device != dev:
+            self._ws = ops.LayerWorkspace(self.out_features, self.in_features, dev, self._mnf)
+        return self._ws
+
+    def _alpha_now(self):
+        return 1 / (1 + torch.exp(-self.lambdal))
+
+    @property
+    def alpha_q(self):
+        """sigmoid(lambdal) (…LRT.py:167).  The reference refreshes this attribute (and
+        ``gamma.alpha``) inside forward; its eval code only reads them (…LRT.py:242-246), so they are
+        computed on access with torch ops, off the hot path."""
+        return self._alpha_now()
+
+    def _param_list(self):
+        raise NotImplementedError
+
+    def forward(self, input, sample=False, calculate_log_probs=False, *, _relu=False):
+        if not input.is_cuda:
+            raise RuntimeError("bnn_amd: forward needs a HIP device tensor (input is on %s); there is no CPU path"
+                               % input.device)
+        cfg = (bool(self.training or sample), bool(self.training or calculate_log_probs), bool(_relu))
+        x = input if input.dtype == torch.float32 else input.float()
+        params = self._param_list()
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
+            out, kl = _BayesLinearFn.apply(self, x, cfg, *params)
+        else:
+            out, kl, _ = self._forward_hip(x, cfg)
+        self.kl = kl if cfg[1] else 0
+        return out
+
+
+class LRTBayesianLinear(_BayesLinearBase):
+    """BayesianLinear(in_features, out_features) of LBBNN-GP-MF-LRT.py:129-197."""
+
+    def __init__(self, in_features, out_features, *, priors: Optional[Priors] = None):
+        super().__init__()
+        self._common_init(in_features, out_features, 0.2, priors)
+
+    def _param_list(self):
+        return [self.weight_mu, self.weight_rho, self.lambdal, self.bias_mu, self.bias_rho]
+
+    _names = ("weight_mu", "weight_rho", "lambdal", "bias_mu", "bias_rho")
+
+    def _forward_hip(self, x, cfg):
+        stochastic, want_kl, relu = cfg
+        ws = self._workspace()
+        noise = self.noise or {}
+        eps = noise.get("eps_out")
+        rng = None
+        saved = {"noise": self.noise}
+        if stochastic and eps is None:
+            st = ops.RngState.get(x.device)
+            rng = st.t
+            saved["rng"] = rng.clone()
+        ops.weight_pass(self.weight_mu, self.weight_rho, self.lambdal, bias_rho=self.bias_rho,
+                        priors=self.priors, e_w=ws.e_w, var_w=ws.var_w if stochastic else None,
+                        kl_rows=ws.kl_rows if want_kl else None, bias_var=ws.bias_var)
+        out = ops.lrt_gemm(x, ws.e_w, ws.var_w, I=self.in_features, O=self.out_features,
+                           bias_mean=self.bias_mu, bias_var=ws.bias_var, eps=eps, rng=rng,
+                           rng_stream=ops.STREAM_EPS_OUT * 64 + self._layer_id, row_offset=self.row_offset,
+                           relu=relu, mean_only=not stochastic)
+        kl = None
+        if want_kl:
+            kl = torch.empty((), dtype=torch.float32, device=x.device)
+            ops.kl_finalize(ws.kl_rows, self.bias_mu, self.bias_rho, priors=self.priors, kl_out=kl)
+        if rng is not None:
+            st.advance(1)
+        return out, kl, saved
+
+    def _noise_for_backward(self, saved, B):
+        if saved.get("noise") and "eps_out" in saved["noise"]:
+            return saved["noise"]
+        if "rng" not in saved:
+            return {}
+        return {"eps_out": ops.philox_normal(saved["rng"], ops.STREAM_EPS_OUT * 64 + self._layer_id,
+                                             B, self.out_features, self.row_offset)}
+
+    def _forward_torch(self, x, ps, cfg, noise):
+        P = dict(zip(self._names, ps))
+        return _grad.lrt_torch(x, P, noise, stochastic=cfg[0], want_kl=cfg[1], priors=self.priors, relu=cfg[2])
+
+
+class MNFBayesianLinear(_BayesLinearBase):
+    """BayesianLinear(in_features, out_features, num_transforms) of LBBNN-GP-MF-MNF.py:133-239."""
+    _mnf = True
+
+    def __init__(self, in_features, out_features, num_transforms, *, z_flow_type="RNVP", r_flow_type="RNVP",
+                 priors: Optional[Priors] = None):
+        super().__init__()
+        self._common_init(in_features, out_features, 0.01, priors)         # weight_mu ~ U(+-0.01), :140
+        self.q0_mean = nn.Parameter(0.1 * torch.randn(in_features))         # :166
+        self.q0_log_var = nn.Parameter(-9 + 0.1 * torch.randn(in_features))  # :167
+        self.r0_c = nn.Parameter(0.1 * torch.randn(in_features))            # :170-172
+        self.r0_b1 = nn.Parameter(0.1 * torch.randn(in_features))
+        self.r0_b2 = nn.Parameter(0.1 * torch.randn(in_features))
+        self.z_flow = PropagateFlow(z_flow_type, in_features, num_transforms)   # :175-176
+        self.r_flow = PropagateFlow(r_flow_type, in_features, num_transforms)
+        self.z = 0
+
+    _names = ("weight_mu", "weight_rho", "lambdal", "bias_mu", "bias_rho", "q0_mean", "q0_log_var",
+              "r0_c", "r0_b1", "r0_b2")
+
+    def _param_list(self):
+        ps = [getattr(self, n) for n in self._names]
+        ps += list(self.z_flow.parameters()) + list(self.r_flow.parameters())
+        return ps
+
+    def _check_flows(self):
+        if self.z_flow.kind != "Planar" or self.r_flow.kind != "Planar":
+            raise NotImplementedError("bnn_amd: MNF layer forward has HIP kernels for planar flows only in this "
+                                      "build (got z=%s, r=%s)" % (self.z_flow.kind, self.r_flow.kind))
+
+    def sample_z(self, batch_size=1):
+        """LBBNN-GP-MF-MNF.py:182-187: returns (z_flow(z0)[-1], logdet) -- only the kept row is computed."""
+        self._check_flows()
+        ws = self._workspace()
+        st = ops.RngState.get(self.q0_mean.device)
+        with torch.no_grad():
+            ops.mnf_flow_planar(self.q0_mean, self.q0_log_var, self.z_flow.planar_params(), [], rng=st.t,
+                                layer_id=self._layer_id, z_fwd=ws.z_fwd, scal=ws.scal, want_kl=False)
+            st.advance(1)
+        return ws.z_fwd.clone(), ws.scal[4].clone()
+
+    def _forward_hip(self, x, cfg):
+        stochastic, want_kl, relu = cfg
+        self._check_flows()
+        ws = self._workspace()
+        noise = self.noise or {}
+        need = ["eps_z"] + (["eps_out"] if stochastic else []) + (["eps_z2", "eps_act"] if want_kl else [])
+        have = [k for k in need if k in noise]
+        if have and len(have) != len(need):
+            raise RuntimeError("bnn_amd: layer.noise must give all of %s or none (got %s)" % (need, have))
+        rng, st = None, None
+        saved = {"noise": self.noise if have else None}
+        if not have:
+            st = ops.RngState.get(x.device)
+            rng = st.t
+            saved["rng"] = rng.clone()
+        eps_z = noise.get("eps_z")
+        if eps_z is not None and eps_z.dim() == 2:
+            eps_z = eps_z[-1]                      # zs[-1]: only the last of the B rows is used (:187)
+        eps_z2 = noise.get("eps_z2")
+        if eps_z2 is not None:
+            eps_z2 = eps_z2.reshape(-1)
+        ops.mnf_flow_planar(self.q0_mean, self.q0_log_var, self.z_flow.planar_params(),
+                            self.r_flow.planar_params(),
+                            eps_fwd=None if eps_z is None else eps_z.contiguous(),
+                            eps_kl=None if eps_z2 is None else eps_z2.contiguous(),
+                            rng=rng, layer_id=self._layer_id, z_fwd=ws.z_fwd, z_kl=ws.z_kl, scal=ws.scal,
+                            want_kl=want_kl)
+        ops.weight_pass(self.weight_mu, self.weight_rho, self.lambdal, z_fwd=ws.z_fwd,
+                        z_kl=ws.z_kl if want_kl else None, r0_c=self.r0_c if want_kl else None,
+                        bias_rho=self.bias_rho, priors=self.priors, e_w=ws.e_w,
+                        var_w=ws.var_w if stochastic else None,
+                        kl_rows=ws.kl_rows if want_kl else None,
+                        act_mu=ws.act_mu if want_kl else None, act_var=ws.act_var if want_kl else None,
+                        bias_var=ws.bias_var)
+        out = ops.lrt_gemm(x, ws.e_w, ws.var_w, I=self.in_features, O=self.out_features,
+                           bias_mean=self.bias_mu, bias_var=ws.bias_var, eps=noise.get("eps_out"), rng=rng,
+                           rng_stream=ops.STREAM_EPS_OUT * 64 + self._layer_id, row_offset=self.row_offset,
+                           relu=relu, mean_only=not stochastic)
+        kl = None
+        if want_kl:
+            kl = torch.empty((), dtype=torch.float32, device=x.device)
+            ops.kl_finalize(ws.kl_rows, self.bias_mu, self.bias_rho, priors=self.priors,
+                            act_mu=ws.act_mu, act_var=ws.act_var, eps_act=noise.get("eps_act"),
+                            r0_b1=self.r0_b1, r0_b2=self.r0_b2, scal=ws.scal, rng=rng,
+                            layer_id=self._layer_id, kl_out=kl)
+        if st is not None:
+            st.advance(1)
+        return out, kl, saved
+
+    def _noise_for_backward(self, saved, B):
+        if saved.get("noise"):
+            n = dict(saved["noise"])
+            if n["eps_z"].dim() == 2:
+                n["eps_z"] = n["eps_z"][-1]
+            if "eps_z2" in n:
+                n["eps_z2"] = n["eps_z2"].reshape(-1)
+            return n
+        r, L, I, O = saved["rng"], self._layer_id, self.in_features, self.out_features
+        return {"eps_out": ops.philox_normal(r, ops.STREAM_EPS_OUT * 64 + L, B, O, self.row_offset),
+                "eps_z": ops.philox_normal(r, ops.STREAM_EPS_Z * 64 + L, 0, I),
+                "eps_z2": ops.philox_normal(r, ops.STREAM_EPS_Z2 * 64 + L, 0, I),
+                "eps_act": ops.philox_normal(r, ops.STREAM_EPS_ACT * 64 + L, 0, O)}
+
+    def _forward_torch(self, x, ps, cfg, noise):
+        n = len(self._names)
+        P = dict(zip(self._names, ps[:n]))
+        rest = ps[n:]
+        T = len(self.z_flow.transforms)
+        zf = [tuple(rest[3 * t:3 * t + 3]) for t in range(T)]
+        rf = [tuple(rest[3 * T + 3 * t:3 * T + 3 * t + 3]) for t in range(len(self.r_flow.transforms))]
+        return _grad.mnf_planar_torch(x, P, zf, rf, noise, stochastic=cfg[0], want_kl=cfg[1],
+                                      priors=self.priors, relu=cfg[2])
+
+
+class _NetworkBase(nn.Module):
+    def forward(self, x, sample=False):
+        x = x.view(-1, self.dims[0])                                  # …LRT.py:207
+        layers = [self.l1, self.l2, self.l3]
+        for i, l in enumerate(layers):
+            x = l.forward(x, sample, _relu=(i < 2))                   # F.relu fused into the GEMM epilogue
+        return F.log_softmax(x, dim=1)                                # …LRT.py:210
+
+    def kl(self):
+        return self.l1.kl + self.l2.kl + self.l3.kl                   # …LRT.py:213-214
+
+    def set_row_offset(self, off: int):
+        for l in (self.l1, self.l2, self.l3):
+            l.row_offset = int(off)
+
+
+class LRTBayesianNetwork(_NetworkBase):
+    """BayesianNetwork() of LBBNN-GP-MF-LRT.py:199-214 (reference dims 784-400-600-10; ``dims=`` added)."""
+
+    def __init__(self, dims=(28 * 28, 400, 600, 10), *, priors=None):
+        super().__init__()
+        self.dims = tuple(dims)
+        self.l1 = LRTBayesianLinear(dims[0], dims[1], priors=priors)
+        self.l2 = LRTBayesianLinear(dims[1], dims[2], priors=priors)
+        self.l3 = LRTBayesianLinear(dims[2], dims[3], priors=priors)
+
+
+class MNFBayesianNetwork(_NetworkBase):
+    """BayesianNetwork() of LBBNN-GP-MF-MNF.py:244-260 (num_transforms=2 there)."""
+
+    def __init__(self, dims=(28 * 28, 400, 600, 10), num_transforms=2, *, z_flow_type="RNVP",
+                 r_flow_type="RNVP", priors=None):
+        super().__init__()
+        self.dims = tuple(dims)
+        kw = dict(z_flow_type=z_flow_type, r_flow_type=r_flow_type, priors=priors)
+        self.l1 = MNFBayesianLinear(dims[0], dims[1], num_transforms, **kw)
+        self.l2 = MNFBayesianLinear(dims[1], dims[2], num_transforms, **kw)
+        self.l3 = MNFBayesianLinear(dims[2], dims[3], num_transforms, **kw)

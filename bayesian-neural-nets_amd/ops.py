@@ -1,0 +1,202 @@
+"""Tensor-level wrappers over the C ABI (include/lbbnn.h).
+
+Every function takes torch tensors that must already live on a HIP device (contiguous fp32),
+enqueues on torch's current stream and returns without synchronising.  Nothing here computes
+on the host; a CPU tensor or a missing library raises.
+"""
+import ctypes
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import Priors
+
+F_RELU = 0x1
+F_MEAN_ONLY = 0x2
+F_SPLIT16 = 0x4
+
+STREAM_EPS_OUT = 0
+STREAM_EPS_Z = 1
+STREAM_EPS_Z2 = 2
+STREAM_EPS_ACT = 3
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor], name: str = "tensor") -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("bnn_amd: %s is on %s; the HIP path needs a GPU tensor (no CPU fallback)" % (name, t.device))
+    if t.dtype != torch.float32 and t.dtype != torch.int64:
+        raise RuntimeError("bnn_amd: %s has dtype %s, expected float32" % (name, t.dtype))
+    if not t.is_contiguous():
+        raise RuntimeError("bnn_amd: %s must be contiguous" % name)
+    return t.data_ptr()
+
+
+def operand_ld(I: int) -> int:
+    return ((I + 31) // 32) * 32
+
+
+# ----------------------------------------------------------------------------------------- RNG state
+class RngState:
+    """Per-device {seed, offset} pair in device memory, read by the kernels (graph-replay safe).
+
+    The seed follows ``torch.initial_seed()`` (so ``torch.manual_seed(i)`` in a training script
+    reseeds the in-kernel noise too); the offset is advanced on the device after every layer call.
+    """
+    _states = {}
+
+    def __init__(self, device: torch.device):
+        self.device = device
+        self.seed = None
+        self.t = torch.zeros(2, dtype=torch.int64, device=device)
+        self.reseed(torch.initial_seed())
+
+    def reseed(self, seed: int, offset: int = 0):
+        self.seed = int(seed)
+        s = self.seed & 0xFFFFFFFFFFFFFFFF
+        if s >= 1 << 63:
+            s -= 1 << 64
+        self.t.copy_(torch.tensor([s, int(offset)], dtype=torch.int64))
+
+    @classmethod
+    def get(cls, device: torch.device) -> "RngState":
+        key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+        st = cls._states.get(key)
+        if st is None:
+            st = cls(device)
+            cls._states[key] = st
+        elif st.seed != torch.initial_seed() and not torch.cuda.is_current_stream_capturing():
+            st.reseed(torch.initial_seed())
+        return st
+
+    def advance(self, delta: int = 1):
+        _lib.check(_lib.lib().lbbnn_rng_advance(self.t.data_ptr(), delta, _stream()), "lbbnn_rng_advance")
+
+
+def manual_seed(seed: int, offset: int = 0):
+    """Reseed the in-kernel noise of every device that has a state (also done implicitly when
+    ``torch.manual_seed`` changes ``torch.initial_seed()``)."""
+    torch.manual_seed(seed)
+    for st in RngState._states.values():
+        st.reseed(seed, offset)
+
+
+def philox_normal(rng: torch.Tensor, stream_id: int, rows: int, cols: int, row_base: int = 0) -> torch.Tensor:
+    """The exact N(0,1) values the kernels draw (2-D if rows > 0, else 1-D of length cols)."""
+    out = torch.empty((rows, cols) if rows > 0 else (cols,), dtype=torch.float32, device=rng.device)
+    _lib.check(_lib.lib().lbbnn_philox_normal(rng.data_ptr(), stream_id, row_base, rows, cols, out.data_ptr(),
+                                              _stream()), "lbbnn_philox_normal")
+    return out
+
+
+# ----------------------------------------------------------------------------------------- K1
+def weight_pass(mu, rho, lambdal, *, z_fwd=None, z_kl=None, r0_c=None, bias_rho=None,
+                priors: Priors, e_w=None, var_w=None, kl_rows=None, act_mu=None, act_var=None,
+                bias_var=None):
+    """lbbnn_weight_pass.  Output tensors are caller-allocated (see LayerWorkspace)."""
+    O, I = mu.shape
+    ld = operand_ld(I)
+    rc = _lib.lib().lbbnn_weight_pass(
+        _ptr(mu, "weight_mu"), _ptr(rho, "weight_rho"), _ptr(lambdal, "lambdal"),
+        _ptr(z_fwd), _ptr(z_kl), _ptr(r0_c), _ptr(bias_rho), ctypes.byref(priors),
+        _ptr(e_w), _ptr(var_w), ld, _ptr(kl_rows), _ptr(act_mu), _ptr(act_var), _ptr(bias_var),
+        O, I, 0, _stream())
+    _lib.check(rc, "lbbnn_weight_pass")
+
+
+# ----------------------------------------------------------------------------------------- K2
+def lrt_gemm(x, e_w, var_w, *, I: int, O: int, bias_mean=None, bias_var=None, var_scale=None,
+             eps=None, rng: Optional[torch.Tensor] = None, rng_stream: int = 0, row_offset: int = 0,
+             relu: bool = False, mean_only: bool = False, out: Optional[torch.Tensor] = None):
+    """lbbnn_lrt_gemm: out = x.e_w^T + b [+ sqrt(x^2.var_w^T + bv) * eps] [ReLU]."""
+    if x.dim() != 2 or x.shape[1] != I:
+        raise RuntimeError("bnn_amd: input must be (B,%d), got %s" % (I, tuple(x.shape)))
+    B = x.shape[0]
+    if out is None:
+        out = torch.empty((B, O), dtype=torch.float32, device=x.device)
+    if eps is not None and tuple(eps.shape) != (B, O):
+        raise RuntimeError("bnn_amd: eps must be (%d,%d), got %s" % (B, O, tuple(eps.shape)))
+    flags = (F_RELU if relu else 0) | (F_MEAN_ONLY if mean_only else 0)
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    rc = _lib.lib().lbbnn_lrt_gemm(
+        x.data_ptr() if x.is_cuda else _ptr(x, "input"), x.stride(0), _ptr(e_w), _ptr(var_w), operand_ld(I),
+        _ptr(bias_mean), _ptr(bias_var), _ptr(var_scale), _ptr(eps, "eps"),
+        rng.data_ptr() if rng is not None else None, rng_stream, row_offset,
+        out.data_ptr(), out.stride(0), B, I, O, flags, _stream())
+    _lib.check(rc, "lbbnn_lrt_gemm")
+    return out
+
+
+# ----------------------------------------------------------------------------------------- K3
+def _ptr_array(ts: Sequence[torch.Tensor]):
+    arr = (ctypes.c_void_p * max(len(ts), 1))()
+    for i, t in enumerate(ts):
+        arr[i] = _ptr(t, "flow parameter")
+    return arr
+
+
+def mnf_flow_planar(q0_mean, q0_log_var, z_params, r_params, *, eps_fwd=None, eps_kl=None,
+                    rng: Optional[torch.Tensor] = None, layer_id: int = 0, z_fwd, z_kl=None, scal=None,
+                    want_kl: bool = True):
+    """lbbnn_mnf_flow_planar.  z_params / r_params: lists of (u, w, bias) per transform."""
+    I = q0_mean.shape[0]
+    zu, zw, zb = (_ptr_array([p[k] for p in z_params]) for k in range(3))
+    ru, rw, rb = (_ptr_array([p[k] for p in r_params]) for k in range(3))
+    rc = _lib.lib().lbbnn_mnf_flow_planar(
+        _ptr(q0_mean, "q0_mean"), _ptr(q0_log_var, "q0_log_var"),
+        zu, zw, zb, len(z_params), ru, rw, rb, len(r_params),
+        _ptr(eps_fwd), _ptr(eps_kl), rng.data_ptr() if rng is not None else None, layer_id,
+        _ptr(z_fwd), _ptr(z_kl), _ptr(scal), I, 1 if want_kl else 0, _stream())
+    _lib.check(rc, "lbbnn_mnf_flow_planar")
+
+
+# ----------------------------------------------------------------------------------------- K5
+def kl_finalize(kl_rows, bias_mu, bias_rho, *, priors: Priors, act_mu=None, act_var=None, eps_act=None,
+                r0_b1=None, r0_b2=None, scal=None, rng: Optional[torch.Tensor] = None, layer_id: int = 0,
+                kl_out=None, kl_layer=None, accumulate: bool = False):
+    O = bias_mu.shape[0]
+    I = r0_b1.shape[0] if r0_b1 is not None else 0
+    rc = _lib.lib().lbbnn_kl_finalize(
+        _ptr(kl_rows), _ptr(bias_mu, "bias_mu"), _ptr(bias_rho, "bias_rho"), O,
+        _ptr(act_mu), _ptr(act_var), _ptr(eps_act), _ptr(r0_b1), _ptr(r0_b2), I,
+        _ptr(scal), ctypes.byref(priors), rng.data_ptr() if rng is not None else None, layer_id,
+        _ptr(kl_out), _ptr(kl_layer), 1 if accumulate else 0, _stream())
+    _lib.check(rc, "lbbnn_kl_finalize")
+
+
+def log_softmax_rows(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    B, O = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    rc = _lib.lib().lbbnn_log_softmax_rows(_ptr(x, "input"), x.stride(0), out.data_ptr(), out.stride(0), B, O, _stream())
+    _lib.check(rc, "lbbnn_log_softmax_rows")
+    return out
+
+
+# ----------------------------------------------------------------------------------------- workspaces
+class LayerWorkspace:
+    """Caller-owned device buffers of one layer, allocated once and reused every forward
+    (the C ABI never allocates; fixed addresses also make the launch sequence graph-capturable)."""
+
+    def __init__(self, O: int, I: int, device: torch.device, mnf: bool):
+        ld = operand_ld(I)
+        f = dict(dtype=torch.float32, device=device)
+        self.device = device
+        self.e_w = torch.empty((O, ld), **f)
+        self.var_w = torch.empty((O, ld), **f)
+        self.kl_rows = torch.empty(O, **f)
+        self.bias_var = torch.empty(O, **f)
+        self.kl = torch.zeros((), **f)
+        if mnf:
+            self.act_mu = torch.empty(O, **f)
+            self.act_var = torch.empty(O, **f)
+            self.z_fwd = torch.empty(I, **f)
+            self.z_kl = torch.empty(I, **f)
+            self.scal = torch.empty(8, **f)

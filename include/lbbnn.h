@@ -1,0 +1,172 @@
+/*
+ * lbbnn.h -- C ABI of the MI355X (gfx950) Bayesian linear-layer hot path.
+ *
+ * Drop-in boundary for LarsELund/Bayesian-Neural-Nets' BayesianLinear.forward family.
+ * The reference has no native layer: its "FFI" is the set of PyTorch aten calls the layer
+ * issues.  Each entry point below replaces one group of those calls and
+ * cites the reference lines it stands for (paths relative to the reference checkout).
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE pointer to contiguous row-major fp32 unless stated otherwise.
+ *    The caller (PyTorch) owns all buffers, including workspaces; nothing here allocates.
+ *  - `stream` is a hipStream_t passed as void*.  Calls only enqueue work and return; they
+ *    never synchronise, keep no global state, and are safe under HIP-graph capture.
+ *  - Return value: 0 on success; a negative LBBNN_E_* for argument errors (nothing was
+ *    launched); a positive hipError_t if the launch failed.  No C++ exception crosses.
+ *  - Noise: every stochastic entry takes either an explicit draw (`eps`, parity mode) or,
+ *    when that pointer is NULL, generates N(0,1) in-kernel with Philox4x32-10 keyed by the
+ *    two 64-bit words at `rng` = {seed, offset} (device memory, so a captured graph sees
+ *    fresh noise on every replay after lbbnn_rng_advance).
+ */
+#ifndef LBBNN_H_
+#define LBBNN_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LBBNN_ABI_VERSION 1
+
+#define LBBNN_OK 0
+#define LBBNN_E_NULL (-1)      /* a required pointer is NULL                    */
+#define LBBNN_E_SHAPE (-2)     /* a dimension is <= 0 or exceeds a kernel limit */
+#define LBBNN_E_ALIGN (-3)     /* a pointer / leading dimension is misaligned   */
+#define LBBNN_E_FLAGS (-4)     /* unknown or inconsistent flag bits             */
+#define LBBNN_E_NOISE (-5)     /* neither an explicit draw nor an rng state     */
+
+#define LBBNN_MAX_FLOW_T 16    /* max transforms per planar flow ('mixed' uses 10)  */
+#define LBBNN_MAX_FLOW_DIM 16384
+
+/* GEMM flags */
+#define LBBNN_F_RELU 0x1       /* fuse F.relu on the output (LBBNN-GP-MF-LRT.py:208-209)      */
+#define LBBNN_F_MEAN_ONLY 0x2  /* posterior-mean branch: out = x.e_w^T + b (…LRT.py:178-180)  */
+#define LBBNN_F_SPLIT16 0x4    /* split-precision MFMA path (bf16x3 mean, fp16 variance)      */
+
+/* Philox stream ids (third counter word) -- one per kind of draw, per layer (stream = kind*64+layer) */
+#define LBBNN_STREAM_EPS_OUT 0
+#define LBBNN_STREAM_EPS_Z 1
+#define LBBNN_STREAM_EPS_Z2 2
+#define LBBNN_STREAM_EPS_ACT 3
+
+/* Prior constants of one layer.  The reference keeps them as constant tensors:
+ * LBBNN-GP-MF-LRT.py:142-143,151,159-160; LBBNN-GP-MF-MNF.py:145-146,154,162-163. */
+typedef struct lbbnn_priors {
+    float mu_prior;          /* 0    */
+    float sigma_prior;       /* 1    */
+    float alpha_prior;       /* 0.05 */
+    float bias_mu_prior;     /* 0    */
+    float bias_sigma_prior;  /* 1    */
+} lbbnn_priors_t;
+
+int lbbnn_abi_version(void);
+const char* lbbnn_error_string(int code);
+
+/* Round a K extent up to the operand leading dimension the GEMM expects (multiple of 32). */
+int lbbnn_operand_ld(int I);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1  lbbnn_weight_pass -- one fused, coalesced pass over the (O,I) variational parameters.
+ *
+ * Replaces, per layer and per forward:
+ *   alpha = 1/(1+exp(-lambdal))                       LBBNN-GP-MF-LRT.py:167, …MNF.py:191
+ *   sigma = log1p(exp(rho))  (recomputed 3-4x there)  …LRT.py:81-82
+ *   e_w = mu*alpha ; var_w = sigma^2*alpha^2           …LRT.py:170-171, …MNF.py:195-196
+ *   kl_weight integrand + row sums                     …LRT.py:189-192, …MNF.py:230-233
+ *   act_mu = r0_c @ (z2*mu*alpha)^T, act_var = r0_c^2 @ var_w^T     …MNF.py:211-212,216-217
+ *   bias sigma^2                                       …LRT.py:173
+ *
+ * Inputs : mu, rho, lambdal (O,I).  z_fwd (I) or NULL: per-input multiplier z_k folded into
+ *          the mean operand (…MNF.py:197).  z_kl (I) or NULL: z2 of the KL branch (…MNF.py:210).
+ *          r0_c (I) or NULL.  bias_rho (O) or NULL.
+ * Outputs: e_w, var_w: GEMM operands [O][ld] (ld = lbbnn_operand_ld(I), zero-filled tail),
+ *          either may be NULL.  kl_rows (O): per-row sum of the KL integrand (NULL = skip).
+ *          act_mu, act_var (O) (NULL = skip; need z_kl and r0_c).  bias_var (O) = softplus(bias_rho)^2.
+ *          With LBBNN_F_SPLIT16, e_w is written as two bf16 planes (hi, lo) and var_w as scaled fp16;
+ *          see DESIGN.md "operand formats".
+ */
+int lbbnn_weight_pass(const float* mu, const float* rho, const float* lambdal,
+                      const float* z_fwd, const float* z_kl, const float* r0_c,
+                      const float* bias_rho, const lbbnn_priors_t* priors,
+                      void* e_w, void* var_w, int ld,
+                      float* kl_rows, float* act_mu, float* act_var, float* bias_var,
+                      int O, int I, int flags, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K2  lbbnn_lrt_gemm -- the two activation-moment GEMMs + local-reparameterisation epilogue.
+ *
+ *   mean = x . e_w^T + bias_mean          torch.mm  …LRT.py:172, …MNF.py:197
+ *   var  = x^2 . var_w^T (* var_scale) + bias_var      …LRT.py:173, …MNF.py:198  (x^2 formed in registers)
+ *   out  = mean + sqrt(var) * eps         randn + sample  …LRT.py:174-175, …MNF.py:199-200
+ *   optional ReLU                         …LRT.py:208-209
+ * LBBNN_F_MEAN_ONLY: out = mean (…LRT.py:178-180; F.linear of LBBNN-GP-MF.py:255).
+ *
+ * x (B,I) with row stride ldx floats; e_w/var_w operands from lbbnn_weight_pass (leading dim ld);
+ * bias_mean/bias_var/var_scale (O) or NULL (0 / 0 / 1); eps (B,O) or NULL => Philox from `rng`
+ * with counter = (row_offset + b, o/4), stream id `rng_stream`; out (B,O) row stride ldo.
+ */
+int lbbnn_lrt_gemm(const float* x, int ldx, const void* e_w, const void* var_w, int ld,
+                   const float* bias_mean, const float* bias_var, const float* var_scale,
+                   const float* eps, const uint64_t* rng, uint32_t rng_stream, int64_t row_offset,
+                   float* out, int ldo, int B, int I, int O, int flags, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K3  lbbnn_mnf_flow_planar -- z sampling + planar flows of one MNF layer, one launch.
+ *
+ * Replaces sample_z (LBBNN-GP-MF-MNF.py:182-187) called twice per training forward, the planar
+ * transforms (flows2.py:86-95, PropagateFlow.forward :41-46), log_q0 (…MNF.py:213-214) and
+ * r_flow(z2) (…MNF.py:222).  Only the row the reference keeps (zs[-1], quirk 1 of SURVEY.md 3.2)
+ * is computed.
+ *
+ *   z_fwd = z_flow(q0_mean + exp(q0_log_var)^.5 * eps_fwd)            (forward multiplier z_k)
+ *   z0    = q0_mean + exp(q0_log_var)^.5 * eps_kl ; z_kl = z_flow(z0) (KL branch z2)
+ *   scal[0] = log_det_q   scal[1] = log_q0 (uses -0.5*log(pi), quirk 3)
+ *   scal[2] = log_det_r   scal[3] = r_flow(z_kl)[-1]  (last ELEMENT, quirk 2)
+ *   scal[4] = log-det of the forward draw's z_flow (what sample_z(B) returns next to z_k)
+ *
+ * zu/zw/zb (ru/rw/rb): host arrays of T device pointers to the u (I), w (I), bias (1) of each
+ * transform.  eps_fwd / eps_kl: (I) draws or NULL => Philox (streams EPS_Z / EPS_Z2, counter = i/4).
+ * want_kl == 0 computes z_fwd (and scal[4] if scal != NULL) only.  z_fwd / z_kl (I) outputs; scal: 8 floats.
+ */
+int lbbnn_mnf_flow_planar(const float* q0_mean, const float* q0_log_var,
+                          const float* const* zu, const float* const* zw, const float* const* zb, int Tz,
+                          const float* const* ru, const float* const* rw, const float* const* rb, int Tr,
+                          const float* eps_fwd, const float* eps_kl,
+                          const uint64_t* rng, uint32_t layer_id,
+                          float* z_fwd, float* z_kl, float* scal,
+                          int I, int want_kl, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K5  lbbnn_kl_finalize -- the O(O+I) tail of the KL and the final scalar.
+ *
+ *   kl_bias                                                    …LRT.py:185-186, …MNF.py:227-228
+ *   act = tanh(act_mu + sqrt(act_var)*eps_act); mean_r, log_var_r; log_rb   …MNF.py:218-224
+ *   kl = kl_bias + sum(kl_rows) + (-log_det_q + log_q0) - (log_det_r + log_rb)   …MNF.py:215,225,235
+ * LRT (scal == NULL): kl = kl_bias + sum(kl_rows)               …LRT.py:194
+ *
+ * kl_accum: if nonzero, *kl_out += kl (BayesianNetwork.kl(), …LRT.py:213-214), else *kl_out = kl.
+ */
+int lbbnn_kl_finalize(const float* kl_rows, const float* bias_mu, const float* bias_rho, int O,
+                      const float* act_mu, const float* act_var, const float* eps_act,
+                      const float* r0_b1, const float* r0_b2, int I,
+                      const float* scal, const lbbnn_priors_t* priors,
+                      const uint64_t* rng, uint32_t layer_id,
+                      float* kl_out, float* kl_layer, int kl_accum, void* stream);
+
+/* rng[1] += delta (device side, so graph replays draw fresh noise). */
+int lbbnn_rng_advance(uint64_t* rng, uint64_t delta, void* stream);
+
+/* Reproduce the in-kernel N(0,1) draws (tests, and the backward pass that must re-create eps):
+ * rows > 0: out[r][c] = normal(counter (row_base + r, c/4))[c%4]  -- lbbnn_lrt_gemm's epilogue indexing;
+ * rows == 0: out[i]   = normal(counter (i/4, 0))[i%4], i < cols   -- the 1-D draws of K3 / K5. */
+int lbbnn_philox_normal(const uint64_t* rng, uint32_t rng_stream, int64_t row_base, int64_t rows,
+                        int64_t cols, float* out, void* stream);
+
+/* log_softmax over the last dim of a (B,O<=64) matrix, in place allowed (…LRT.py:210). */
+int lbbnn_log_softmax_rows(const float* in, int ldi, float* out, int ldo, int B, int O, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LBBNN_H_ */
