@@ -13,6 +13,14 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # keep csrc/liblbbnn_hip.so in step with its sources (make is a no-op when up to date)
+    import shutil
+    import subprocess
+    csrc = os.path.join(ROOT, "bayesian-neural-nets_amd", "csrc")
+    if shutil.which("make") and os.path.exists("/opt/rocm/bin/hipcc"):
+        r = subprocess.run(["make", "-C", csrc, "-j4"], capture_output=True, text=True)
+        if r.returncode != 0 and not os.path.exists(os.path.join(csrc, "liblbbnn_hip.so")):
+            raise RuntimeError("building the HIP extension failed:\n" + r.stdout + r.stderr)
 
 
 class Golden:
