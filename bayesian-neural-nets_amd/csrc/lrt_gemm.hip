@@ -20,6 +20,7 @@
 //    wave issues 80 MFMAs (2560 cycles) against 12 ds_read_b128; global->LDS staging of the next
 //    chunk is issued before the MFMAs and written after them (one barrier per chunk).
 //  * Roofline for this path: fp32 matrix peak 157.3 TFLOP/s (MI355X_MICROARCH.md).
+#include <cstdlib>
 #include "lbbnn_device.h"
 #include "../../include/lbbnn.h"
 
@@ -39,10 +40,85 @@ struct GemmArgs {
     long long row_offset;
     int ldx, ld, ldo, B, I, O;
     uint32_t rng_stream;
-    int relu;
+    int relu, log_softmax;
 };
 
+struct EpiCtx { bool ovec; uint64_t seed, offs; };
+
+template <bool MEAN_ONLY>
+__device__ __forceinline__ EpiCtx make_epi_ctx(const GemmArgs& a) {
+    EpiCtx c;
+    c.ovec = ((a.O & 3) == 0) && ((a.ldo & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0) &&
+             (!a.eps || (reinterpret_cast<uintptr_t>(a.eps) & 15u) == 0);
+    c.seed = 0; c.offs = 0;
+    if (!MEAN_ONLY && !a.eps) { c.seed = a.rng[0]; c.offs = a.rng[1]; }
+    return c;
+}
+
+// Per-output-feature constants of out[.][o..o+3], loaded once per o-tile (float4 when aligned).
+struct OConst { float bm[4], bv[4], vs[4]; };
+
+__device__ __forceinline__ void load4_or_fill(const float* p, int o, int O, float fill, float out[4]) {
+    if (!p) { out[0] = out[1] = out[2] = out[3] = fill; return; }
+    if (o + 3 < O && ((reinterpret_cast<uintptr_t>(p + o) & 15u) == 0)) {
+        const float4 t = *reinterpret_cast<const float4*>(p + o);
+        out[0] = t.x; out[1] = t.y; out[2] = t.z; out[3] = t.w;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[r] = (o + r < O) ? p[o + r] : fill;
+    }
+}
+
+__device__ __forceinline__ OConst load_oconst(const GemmArgs& a, int o) {
+    OConst c;
+    load4_or_fill(a.bias_mean, o, a.O, 0.f, c.bm);
+    load4_or_fill(a.bias_var, o, a.O, 0.f, c.bv);
+    load4_or_fill(a.var_scale, o, a.O, 1.f, c.vs);
+    return c;
+}
+
+// Local-reparameterisation epilogue for out[b][o..o+3] (LBBNN-GP-MF-LRT.py:172-175): bias, variance
+// scale/bias, eps (explicit or Philox with counter (row_offset + b, o/4)), sqrt, optional ReLU.
+template <bool MEAN_ONLY>
+__device__ __forceinline__ void epilogue4(const GemmArgs& a, const EpiCtx& c, const OConst& oc, int b, int o,
+                                          const floatx4& am, const floatx4& av, float res[4]) {
+    float e[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!MEAN_ONLY) {
+        if (a.eps) {
+            const float* ep = a.eps + (size_t)b * a.O + o;
+            if (c.ovec) { const float4 t = *reinterpret_cast<const float4*>(ep); e[0] = t.x; e[1] = t.y; e[2] = t.z; e[3] = t.w; }
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (o + r < a.O) e[r] = ep[r];
+            }
+        } else {
+            philox_normal4(c.seed, c.offs, a.rng_stream, (uint64_t)(a.row_offset + b), (uint32_t)(o >> 2), e);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float mean = am[r] + oc.bm[r];
+        if (!MEAN_ONLY) mean += sqrtf(av[r] * oc.vs[r] + oc.bv[r]) * e[r];
+        res[r] = a.relu ? fmaxf(mean, 0.f) : mean;
+    }
+}
+
+__device__ __forceinline__ void store4(const GemmArgs& a, const EpiCtx& c, int b, int o, const float res[4]) {
+    float* op = a.out + (size_t)b * a.ldo + o;
+    if (c.ovec) *reinterpret_cast<float4*>(op) = make_float4(res[0], res[1], res[2], res[3]);
+    else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (o + r < a.O) op[r] = res[r];
+    }
+}
+
 // TO x TB 16x16 tiles per wave (o x b), WB waves along b; all waves share the o extent.
+//
+// Staging is deliberately branch-free in the steady state: each thread owns NIT fixed (row, 4-float
+// column) slots of the chunk image; its global pointers are computed ONCE (rows past B / O are clamped
+// to the last valid row -- their accumulators are never stored) and advance by 16 floats per chunk.
+// Only a K tail (I % 16 != 0) takes the guarded path, and only for the x rows (the weight operands
+// are zero-padded to ld by the weight pass).
 template <int TO, int TB, int WB, bool MEAN_ONLY, bool XVEC>
 __global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_f32_kernel(const GemmArgs a) {
     constexpr int NT = WB * 64;
@@ -52,55 +128,223 @@ __global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_f32_kernel(const GemmArgs
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // [buf][ X: BM rows | Wm: BN rows | Wv: BN rows ] x LDS_LD
     constexpr int ROWS = BM + NW * BN;
-    float* const buf0 = smem;
-    float* const buf1 = smem + ROWS * LDS_LD;
+    constexpr int BUF = ROWS * LDS_LD;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int lr = lane & 15, q = lane >> 4;
     const int o0 = blockIdx.x * BN;
     const int b0 = blockIdx.y * BM;
 
-    // ---- staging plan: the block moves ROWS*4 float4 per chunk; slot s -> (row s>>2, col4 s&3)
     constexpr int SLOTS = ROWS * 4;
     constexpr int NIT = (SLOTS + NT - 1) / NT;
+    const float* gp[NIT];     // this thread's source pointer per slot (chunk 0)
+    int loff[NIT];            // LDS float offset of the slot inside a buffer
+    int kcol[NIT];            // first k of the slot inside a chunk, or -1 for weight slots
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        int sl = tid + it * NT;
+        if (sl >= SLOTS) sl -= SLOTS;              // surplus threads duplicate an early slot (same data, same address)
+        const int row = sl >> 2, c4 = (sl & 3) << 2;
+        loff[it] = row * LDS_LD + c4;
+        if (row < BM) {
+            const int bb = min(b0 + row, a.B - 1);
+            gp[it] = a.x + (size_t)bb * a.ldx + c4;
+            kcol[it] = c4;
+        } else {
+            const int wr = row - BM;
+            const bool isv = (!MEAN_ONLY) && wr >= BN;
+            const int oo = min(o0 + (isv ? wr - BN : wr), a.O - 1);
+            gp[it] = (isv ? a.var_w : a.e_w) + (size_t)oo * a.ld + c4;
+            kcol[it] = -1;
+        }
+    }
     float4 stage[NIT];
-
-    auto load_chunk = [&](int k0) {
+    // steady state: chunk c lies entirely inside I -> unconditional loads
+    auto load_full = [&](int c) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int s = tid + it * NT;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (s < SLOTS) {
-                const int row = s >> 2, k = k0 + ((s & 3) << 2);
-                if (row < BM) {
-                    const int b = b0 + row;
-                    if (b < a.B) {
-                        const float* p = a.x + (size_t)b * a.ldx + k;
-                        if (XVEC) {
-                            if (k < a.I) v = *reinterpret_cast<const float4*>(p);
-                        } else {
-                            if (k + 0 < a.I) v.x = p[0];
-                            if (k + 1 < a.I) v.y = p[1];
-                            if (k + 2 < a.I) v.z = p[2];
-                            if (k + 3 < a.I) v.w = p[3];
-                        }
-                    }
-                } else {
-                    const int wr = row - BM;
-                    const bool isv = (!MEAN_ONLY) && wr >= BN;
-                    const int o = o0 + (isv ? wr - BN : wr);
-                    // operands are zero-padded to ld (multiple of 32 >= I): no k guard needed
-                    if (o < a.O) v = *reinterpret_cast<const float4*>((isv ? a.var_w : a.e_w) + (size_t)o * a.ld + k);
-                }
+            const float* p = gp[it] + c * BK;
+            if (XVEC) stage[it] = *reinterpret_cast<const float4*>(p);
+            else if (kcol[it] < 0) stage[it] = *reinterpret_cast<const float4*>(p);
+            else stage[it] = make_float4(p[0], p[1], p[2], p[3]);
+        }
+    };
+    // the (single) K-tail chunk: x elements at k >= I read as zero; weight operands are zero-padded
+    auto load_tail = [&](int c) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const float* p = gp[it] + c * BK;
+            if (kcol[it] < 0) {
+                stage[it] = *reinterpret_cast<const float4*>(p);
+            } else {
+                const int k = c * BK + kcol[it];
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k + 0 < a.I) v.x = p[0];
+                if (k + 1 < a.I) v.y = p[1];
+                if (k + 2 < a.I) v.z = p[2];
+                if (k + 3 < a.I) v.w = p[3];
+                stage[it] = v;
             }
-            stage[it] = v;
         }
     };
     auto store_chunk = [&](float* buf) {
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int s = tid + it * NT;
-            if (s < SLOTS) *reinterpret_cast<float4*>(buf + (s >> 2) * LDS_LD + ((s & 3) << 2)) = stage[it];
+        for (int it = 0; it < NIT; ++it) *reinterpret_cast<float4*>(buf + loff[it]) = stage[it];
+    };
+
+    floatx4 accm[TO][TB], accv[TO][TB];
+#pragma unroll
+    for (int i = 0; i < TO; ++i)
+#pragma unroll
+        for (int j = 0; j < TB; ++j) { accm[i][j] = floatx4{0.f, 0.f, 0.f, 0.f}; accv[i][j] = floatx4{0.f, 0.f, 0.f, 0.f}; }
+
+    const int nfull = a.I / BK;                       // chunks entirely inside I
+    const int nchunks = (a.I + BK - 1) / BK;          // nfull (+1 guarded tail chunk)
+    if (nfull > 0) load_full(0); else load_tail(0);
+    store_chunk(smem);
+    __syncthreads();
+
+    // fragment read offsets (floats) inside a buffer
+    const int xoff = (wv * TB * 16 + lr) * LDS_LD + 4 * q;
+    const int woff = (BM + lr) * LDS_LD + 4 * q;
+
+    // One chunk of MFMA work from the LDS image `cur`.  All 2*TO + TB fragment reads are issued back
+    // to back (one LDS latency per chunk, counted lgkmcnt waits); the MFMAs then run k-outermost so
+    // consecutive MFMAs never share an accumulator.
+    auto compute = [&](const float* cur) {
+        float xf[TB][4], xs[TB][4], wm[TO][4], wq[TO][4];
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            const float4 t = *reinterpret_cast<const float4*>(cur + xoff + j * 16 * LDS_LD);
+            xf[j][0] = t.x; xf[j][1] = t.y; xf[j][2] = t.z; xf[j][3] = t.w;
+        }
+#pragma unroll
+        for (int i = 0; i < TO; ++i) {
+            const float4 t = *reinterpret_cast<const float4*>(cur + woff + i * 16 * LDS_LD);
+            wm[i][0] = t.x; wm[i][1] = t.y; wm[i][2] = t.z; wm[i][3] = t.w;
+            if (!MEAN_ONLY) {
+                const float4 u = *reinterpret_cast<const float4*>(cur + woff + (BN + i * 16) * LDS_LD);
+                wq[i][0] = u.x; wq[i][1] = u.y; wq[i][2] = u.z; wq[i][3] = u.w;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TB; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xs[j][k] = xf[j][k] * xf[j][k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int i = 0; i < TO; ++i) {
+#pragma unroll
+                for (int j = 0; j < TB; ++j) {
+                    accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wm[i][k], xf[j][k], accm[i][j], 0, 0, 0);
+                    if (!MEAN_ONLY)
+                        accv[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[i][k], xs[j][k], accv[i][j], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    // steady state: both this chunk and the next are full -> no predicates anywhere in the loop
+    int c = 0;
+    for (; c + 1 < nfull; ++c) {
+        load_full(c + 1);                                  // global loads in flight under the MFMAs
+        __builtin_amdgcn_sched_barrier(0);                 // keep them ABOVE the MFMAs (hipcc sinks them otherwise)
+        compute(smem + (c & 1) * BUF);
+        __builtin_amdgcn_sched_barrier(0);
+        store_chunk(smem + ((c & 1) ^ 1) * BUF);
+        __syncthreads();
+    }
+    // last full chunk (prefetching the guarded K-tail chunk if there is one), then the tail chunk
+    for (; c < nchunks; ++c) {
+        const bool more = (c + 1) < nchunks;
+        if (more) load_tail(c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(smem + (c & 1) * BUF);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) store_chunk(smem + ((c & 1) ^ 1) * BUF);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds out[b][o .. o+3] for each (i, j) tile
+    const EpiCtx ec = make_epi_ctx<MEAN_ONLY>(a);
+#pragma unroll
+    for (int i = 0; i < TO; ++i) {
+        const int o = o0 + i * 16 + 4 * q;
+        if (o >= a.O) continue;
+        const OConst oc = load_oconst(a, o);
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            const int b = b0 + (wv * TB + j) * 16 + lr;
+            if (b >= a.B) continue;
+            float res[4];
+            epilogue4<MEAN_ONLY>(a, ec, oc, b, o, accm[i][j], accv[i][j], res);
+            store4(a, ec, b, o, res);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant of the kernel above (the fast path: x 16-B aligned, I % 16 == 0).
+//
+// Measured on MI355X (tools/mfma_peak.hip): with this loop skeleton the register-staged
+// `ds_write_b128` pass alone costs 12 % of MFMA throughput (146 -> 129 TFLOP/s) -- a store moves its
+// address and data VGPRs to the LDS at ~13 cycles per wave-instruction and serialises every wave's
+// write -> lgkmcnt(0) -> barrier -> read chain.  `global_load_lds_dwordx4` writes the chunk image
+// straight into LDS: no staging VGPRs, no ds_write, and the loads are counted by vmcnt.
+//
+// LDS-DMA writes wave-uniform base + lane*16 B, so the image is lane-linear: rows of 64 B (16 floats,
+// NO padding), one wave-instruction = 16 rows.  Unswizzled, a ds_read_b128 fragment read (lane ->
+// row lr, 16-B slot q) would be 4-way bank conflicted; the fix goes on the per-lane SOURCE address
+// (cdna guide rule 21): LDS slot q' of row r holds global slot q' ^ F[(r>>2)&3], F = {0,2,3,1}, and
+// readers apply the same involution.  With that map each of ds_read_b128's four 16-lane groups
+// touches 16 distinct 16-B slots of the 256-B bank row: conflict-free.
+constexpr int DROW = 16;                     // floats per LDS row in the DMA image
+
+__device__ __forceinline__ int swz(int rowgrp) { return (0x78 >> (2 * (rowgrp & 3))) & 3; }   // F = {0,2,3,1}
+
+template <int TO, int TB, int WB, bool MEAN_ONLY>
+__global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_f32_dma_kernel(const GemmArgs a) {
+    constexpr int BN = TO * 16, BM = TB * WB * 16;
+    constexpr int NW = MEAN_ONLY ? 1 : 2;
+    constexpr int ROWS = BM + NW * BN;
+    constexpr int NG = ROWS / 16;                        // 16-row DMA groups per chunk image
+    constexpr int NPW = (NG + WB - 1) / WB;              // DMA instructions per wave per chunk
+    constexpr int BUF = ROWS * DROW;                     // floats per buffer
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, q = lane >> 4;
+    const int o0 = blockIdx.x * BN;
+    const int b0 = blockIdx.y * BM;
+
+    // ---- per-lane DMA sources: group g = wv + WB*u covers image rows [16g, 16g+16); this lane feeds
+    // row 16g + (lane>>2), LDS slot lane&3, i.e. global slot (lane&3) ^ F[(lane>>4)&3].
+    const int srow = lane >> 2;
+    const int scol = ((lane & 3) ^ swz(lane >> 4)) << 2;
+    const float* gp[NPW];
+#pragma unroll
+    for (int u = 0; u < NPW; ++u) {
+        const int g = wv + WB * u;
+        const int row = 16 * g + srow;
+        if (row < BM) {
+            gp[u] = a.x + (size_t)min(b0 + row, a.B - 1) * a.ldx + scol;
+        } else {
+            const int wr = row - BM;
+            const bool isv = (!MEAN_ONLY) && wr >= BN;
+            const int oo = min(o0 + (isv ? wr - BN : wr), a.O - 1);
+            gp[u] = (isv ? a.var_w : a.e_w) + (size_t)oo * a.ld + scol;
+        }
+    }
+    auto dma_chunk = [&](int c, float* buf) {
+#pragma unroll
+        for (int u = 0; u < NPW; ++u) {
+            const int g = wv + WB * u;                   // wave-uniform
+            if (g < NG)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(gp[u] + c * BK),
+                    (__attribute__((address_space(3))) void*)(buf + g * 16 * DROW), 16, 0, 0);
         }
     };
 
@@ -110,97 +354,203 @@ __global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_f32_kernel(const GemmArgs
 #pragma unroll
         for (int j = 0; j < TB; ++j) { accm[i][j] = floatx4{0.f, 0.f, 0.f, 0.f}; accv[i][j] = floatx4{0.f, 0.f, 0.f, 0.f}; }
 
-    const int nchunks = (a.I + BK - 1) / BK;
-    load_chunk(0);
-    store_chunk(buf0);
-    __syncthreads();
+    // fragment read offsets: row (R + lr), slot q ^ F[(lr>>2)&3]   (R is a multiple of 16)
+    const int fcol = (q ^ swz(lr >> 2)) << 2;
+    const int xoff = (wv * TB * 16 + lr) * DROW + fcol;
+    const int woff = (BM + lr) * DROW + fcol;
 
-    for (int c = 0; c < nchunks; ++c) {
-        float* const cur = (c & 1) ? buf1 : buf0;
-        float* const nxt = (c & 1) ? buf0 : buf1;
-        const bool more = (c + 1) < nchunks;
-        if (more) load_chunk((c + 1) * BK);          // global loads in flight under the MFMAs
-
-        float4 xf[TB], xs[TB];
+    float xf[TB][4], xs[TB][4], wm[TO][4], wq[TO][4];
+    auto read_frags = [&](const float* cur) {
 #pragma unroll
         for (int j = 0; j < TB; ++j) {
-            xf[j] = *reinterpret_cast<const float4*>(cur + ((wv * TB + j) * 16 + lr) * LDS_LD + 4 * q);
-            xs[j] = make_float4(xf[j].x * xf[j].x, xf[j].y * xf[j].y, xf[j].z * xf[j].z, xf[j].w * xf[j].w);
+            const float4 t = *reinterpret_cast<const float4*>(cur + xoff + j * 16 * DROW);
+            xf[j][0] = t.x; xf[j][1] = t.y; xf[j][2] = t.z; xf[j][3] = t.w;
         }
 #pragma unroll
         for (int i = 0; i < TO; ++i) {
-            const float4 wm = *reinterpret_cast<const float4*>(cur + (BM + i * 16 + lr) * LDS_LD + 4 * q);
-            float4 wvv = wm;
-            if (!MEAN_ONLY) wvv = *reinterpret_cast<const float4*>(cur + (BM + BN + i * 16 + lr) * LDS_LD + 4 * q);
-#pragma unroll
-            for (int j = 0; j < TB; ++j) {
-                accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wm.x, xf[j].x, accm[i][j], 0, 0, 0);
-                accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wm.y, xf[j].y, accm[i][j], 0, 0, 0);
-                accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wm.z, xf[j].z, accm[i][j], 0, 0, 0);
-                accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wm.w, xf[j].w, accm[i][j], 0, 0, 0);
-                if (!MEAN_ONLY) {
-                    accv[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wvv.x, xs[j].x, accv[i][j], 0, 0, 0);
-                    accv[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wvv.y, xs[j].y, accv[i][j], 0, 0, 0);
-                    accv[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wvv.z, xs[j].z, accv[i][j], 0, 0, 0);
-                    accv[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wvv.w, xs[j].w, accv[i][j], 0, 0, 0);
-                }
-            }
-        }
-        if (more) store_chunk(nxt);
-        __syncthreads();
-    }
-
-    // ---- epilogue: lane holds out[b][o .. o+3] for each (i, j) tile
-    const bool ovec = ((a.O & 3) == 0) && ((a.ldo & 3) == 0) &&
-                      ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0) &&
-                      (!a.eps || (reinterpret_cast<uintptr_t>(a.eps) & 15u) == 0);
-    uint64_t seed = 0, offs = 0;
-    if (!MEAN_ONLY && !a.eps) { seed = a.rng[0]; offs = a.rng[1]; }
-
-#pragma unroll
-    for (int j = 0; j < TB; ++j) {
-        const int b = b0 + (wv * TB + j) * 16 + lr;
-        if (b >= a.B) continue;
-#pragma unroll
-        for (int i = 0; i < TO; ++i) {
-            const int o = o0 + i * 16 + 4 * q;
-            if (o >= a.O) continue;
-            float m[4] = {accm[i][j][0], accm[i][j][1], accm[i][j][2], accm[i][j][3]};
-            float v[4] = {accv[i][j][0], accv[i][j][1], accv[i][j][2], accv[i][j][3]};
-            float e[4] = {0.f, 0.f, 0.f, 0.f};
+            const float4 t = *reinterpret_cast<const float4*>(cur + woff + i * 16 * DROW);
+            wm[i][0] = t.x; wm[i][1] = t.y; wm[i][2] = t.z; wm[i][3] = t.w;
             if (!MEAN_ONLY) {
-                if (a.eps) {
-                    const float* ep = a.eps + (size_t)b * a.O + o;
-                    if (ovec) { const float4 t = *reinterpret_cast<const float4*>(ep); e[0] = t.x; e[1] = t.y; e[2] = t.z; e[3] = t.w; }
-                    else {
+                const float4 u = *reinterpret_cast<const float4*>(cur + woff + (BN + i * 16) * DROW);
+                wq[i][0] = u.x; wq[i][1] = u.y; wq[i][2] = u.z; wq[i][3] = u.w;
+            }
+        }
+    };
+    auto mfmas = [&]() {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) if (o + r < a.O) e[r] = ep[r];
-                    }
-                } else {
-                    philox_normal4(seed, offs, a.rng_stream, (uint64_t)(a.row_offset + b), (uint32_t)(o >> 2), e);
+        for (int j = 0; j < TB; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xs[j][k] = xf[j][k] * xf[j][k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int i = 0; i < TO; ++i) {
+#pragma unroll
+                for (int j = 0; j < TB; ++j) {
+                    accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wm[i][k], xf[j][k], accm[i][j], 0, 0, 0);
+                    if (!MEAN_ONLY)
+                        accv[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[i][k], xs[j][k], accv[i][j], 0, 0, 0);
                 }
             }
+        }
+    };
+
+    const int nchunks = a.I / BK;                        // host guarantees I % 16 == 0
+    dma_chunk(0, smem);
+    __syncthreads();                                     // vmcnt(0) + barrier: chunk 0 visible to all waves
+    for (int c = 0; c < nchunks; ++c) {
+        // Order matters: hipcc drains every in-flight LDS-DMA (vmcnt(0)) before a ds_read it cannot
+        // disambiguate from the DMA destination, so the fragment reads of `cur` are ISSUED first, then
+        // the DMA of the next chunk (which lands under the 80 MFMAs), then the MFMAs.
+        read_frags(smem + (c & 1) * BUF);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < nchunks) dma_chunk(c + 1, smem + ((c & 1) ^ 1) * BUF);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas();
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();      // my DMAs landed (vmcnt(0)) + every wave done reading `cur` and done landing `nxt`
+    }
+
+    // ---- epilogue (identical to the register-staged kernel)
+    const EpiCtx ec = make_epi_ctx<MEAN_ONLY>(a);
+#pragma unroll
+    for (int i = 0; i < TO; ++i) {
+        const int o = o0 + i * 16 + 4 * q;
+        if (o >= a.O) continue;
+        const OConst oc = load_oconst(a, o);
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            const int b = b0 + (wv * TB + j) * 16 + lr;
+            if (b >= a.B) continue;
             float res[4];
+            epilogue4<MEAN_ONLY>(a, ec, oc, b, o, accm[i][j], accv[i][j], res);
+            store4(a, ec, b, o, res);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Skinny-output variant (O <= 16: the 10-class head).  One 16(o) x 16(b) accumulator pair per wave;
+// the 16 waves of a 1024-thread workgroup split K 16 ways (chunk c -> wave c mod 16), every wave
+// issues ALL its global loads (x fragment straight to registers: the tile is read once, LDS staging
+// would only add a round trip) before its first MFMA, then the 16 partial accumulators are summed
+// through LDS in a fixed order (deterministic) and wave 0 runs the epilogue -- optionally fused with
+// log_softmax over the row (LBBNN-GP-MF-LRT.py:210), whose <=16 logits sit on 4 lanes x 4 registers.
+// HBM-bound: x is (B, I) fp32 read once.
+constexpr int SK_WAVES = 16;
+constexpr int SK_NCH = 5;      // chunks per wave per batch: covers I <= 16*16*5 = 1280 in one batch
+
+template <bool MEAN_ONLY, bool XVEC>
+__global__ __launch_bounds__(SK_WAVES * 64) void lrt_gemm_skinny_kernel(const GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[SK_WAVES][2][64][4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int lr = lane & 15, q = lane >> 4;
+    const int b0 = blockIdx.x * 16;
+    const int b = b0 + lr;
+    const bool brow = b < a.B, orow = lr < a.O;
+    floatx4 accm = {0.f, 0.f, 0.f, 0.f}, accv = {0.f, 0.f, 0.f, 0.f};
+    const int nchunks = (a.I + BK - 1) / BK;
+    for (int cb = wv; cb < nchunks; cb += SK_WAVES * SK_NCH) {
+        float4 xf[SK_NCH], wm[SK_NCH], wvv[SK_NCH];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int oo = (o + r < a.O) ? o + r : a.O - 1;
-                float mean = m[r] + (a.bias_mean ? a.bias_mean[oo] : 0.f);
-                if (!MEAN_ONLY) {
-                    float var = v[r];
-                    if (a.var_scale) var *= a.var_scale[oo];
-                    if (a.bias_var) var += a.bias_var[oo];
-                    mean += sqrtf(var) * e[r];
+        for (int u = 0; u < SK_NCH; ++u) {
+            const int c = cb + u * SK_WAVES;
+            const int k = c * BK + 4 * q;
+            float4 vx = make_float4(0.f, 0.f, 0.f, 0.f), vm = vx, vv = vx;
+            if (c < nchunks) {
+                if (brow) {
+                    const float* p = a.x + (size_t)b * a.ldx + k;
+                    if (XVEC) { if (k < a.I) vx = *reinterpret_cast<const float4*>(p); }
+                    else {
+                        if (k + 0 < a.I) vx.x = p[0];
+                        if (k + 1 < a.I) vx.y = p[1];
+                        if (k + 2 < a.I) vx.z = p[2];
+                        if (k + 3 < a.I) vx.w = p[3];
+                    }
                 }
-                res[r] = a.relu ? fmaxf(mean, 0.f) : mean;
+                if (orow) {
+                    vm = *reinterpret_cast<const float4*>(a.e_w + (size_t)lr * a.ld + k);
+                    if (!MEAN_ONLY) vv = *reinterpret_cast<const float4*>(a.var_w + (size_t)lr * a.ld + k);
+                }
             }
-            float* op = a.out + (size_t)b * a.ldo + o;
-            if (ovec) *reinterpret_cast<float4*>(op) = make_float4(res[0], res[1], res[2], res[3]);
-            else {
+            xf[u] = vx; wm[u] = vm; wvv[u] = vv;
+        }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (o + r < a.O) op[r] = res[r];
+        for (int u = 0; u < SK_NCH; ++u) {
+            accm = __builtin_amdgcn_mfma_f32_16x16x4f32(wm[u].x, xf[u].x, accm, 0, 0, 0);
+            accm = __builtin_amdgcn_mfma_f32_16x16x4f32(wm[u].y, xf[u].y, accm, 0, 0, 0);
+            accm = __builtin_amdgcn_mfma_f32_16x16x4f32(wm[u].z, xf[u].z, accm, 0, 0, 0);
+            accm = __builtin_amdgcn_mfma_f32_16x16x4f32(wm[u].w, xf[u].w, accm, 0, 0, 0);
+            if (!MEAN_ONLY) {
+                accv = __builtin_amdgcn_mfma_f32_16x16x4f32(wvv[u].x, xf[u].x * xf[u].x, accv, 0, 0, 0);
+                accv = __builtin_amdgcn_mfma_f32_16x16x4f32(wvv[u].y, xf[u].y * xf[u].y, accv, 0, 0, 0);
+                accv = __builtin_amdgcn_mfma_f32_16x16x4f32(wvv[u].z, xf[u].z * xf[u].z, accv, 0, 0, 0);
+                accv = __builtin_amdgcn_mfma_f32_16x16x4f32(wvv[u].w, xf[u].w * xf[u].w, accv, 0, 0, 0);
             }
         }
     }
+    *reinterpret_cast<floatx4*>(&red[wv][0][lane][0]) = accm;
+    if (!MEAN_ONLY) *reinterpret_cast<floatx4*>(&red[wv][1][lane][0]) = accv;
+    __syncthreads();
+    if (wv != 0) return;
+    floatx4 sm = *reinterpret_cast<const floatx4*>(&red[0][0][lane][0]);
+    floatx4 sv = {0.f, 0.f, 0.f, 0.f};
+    if (!MEAN_ONLY) sv = *reinterpret_cast<const floatx4*>(&red[0][1][lane][0]);
+#pragma unroll 3
+    for (int w = 1; w < SK_WAVES; ++w) {
+        sm += *reinterpret_cast<const floatx4*>(&red[w][0][lane][0]);
+        if (!MEAN_ONLY) sv += *reinterpret_cast<const floatx4*>(&red[w][1][lane][0]);
+    }
+    const EpiCtx ec = make_epi_ctx<MEAN_ONLY>(a);
+    const int o = 4 * q;
+    float res[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool live = brow && o < a.O;
+    if (live) { const OConst oc = load_oconst(a, o); epilogue4<MEAN_ONLY>(a, ec, oc, b, o, sm, sv, res); }
+    if (a.log_softmax) {
+        // the row's logits live on lanes lr, lr+16, lr+32, lr+48 (q = 0..3), 4 registers each
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (live && o + r < a.O) mx = fmaxf(mx, res[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float se = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (live && o + r < a.O) se += expf(res[r] - mx);
+        se += __shfl_xor(se, 16, 64);
+        se += __shfl_xor(se, 32, 64);
+        const float lse = mx + logf(se);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) res[r] -= lse;
+    }
+    if (live) store4(a, ec, b, o, res);
+}
+
+// Workgroup residency matters more than anything else here: the kernel is MFMA-issue bound, so a CU
+// that receives 3 workgroups takes 3x as long as one that receives 1, and the hardware dispatcher
+// packs as many as fit (LDS 46 KB and 164 VGPRs admit 3).  We therefore cap residency through the
+// dynamic-LDS request so that `nblocks` spread evenly: r = ceil(nblocks / 256 CUs) per CU (<= 3).
+constexpr size_t kLdsPerCU = 160 * 1024;
+constexpr int kNumCU = 256;
+
+inline size_t lds_request(size_t needed, long nblocks) {
+    long r = (nblocks + kNumCU - 1) / kNumCU;
+    if (const char* e = getenv("LBBNN_GEMM_RESIDENCY")) r = atol(e);      // tuning knob (bench sweeps only)
+    if (r < 1) r = 1;
+    if (r >= 3) return needed;                       // as many as fit
+    const size_t cap = kLdsPerCU / (size_t)(r + 1) + 256;   // r fit, r+1 do not
+    return needed > cap ? needed : cap;
+}
+
+template <typename K>
+inline int launch_one(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s, const GemmArgs& a) {
+    if (lds > 64 * 1024) {
+        // above 64 KB the dynamic-LDS limit of the function has to be raised (host-side attribute, not a stream op)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kernel, grid, block, lds, s, a);
+    return (int)hipGetLastError();
 }
 
 template <int TO, int TB, int WB>
@@ -208,16 +558,22 @@ int launch_cfg(const GemmArgs& a, bool mean_only, bool xvec, hipStream_t s) {
     constexpr int BN = TO * 16, BM = TB * WB * 16;
     dim3 grid((a.O + BN - 1) / BN, (a.B + BM - 1) / BM);
     dim3 block(WB * 64);
-    const size_t lds_full = 2u * (BM + 2 * BN) * LDS_LD * sizeof(float);
-    const size_t lds_mean = 2u * (BM + BN) * LDS_LD * sizeof(float);
-    if (mean_only) {
-        if (xvec) hipLaunchKernelGGL((lrt_gemm_f32_kernel<TO, TB, WB, true, true>), grid, block, lds_mean, s, a);
-        else      hipLaunchKernelGGL((lrt_gemm_f32_kernel<TO, TB, WB, true, false>), grid, block, lds_mean, s, a);
-    } else {
-        if (xvec) hipLaunchKernelGGL((lrt_gemm_f32_kernel<TO, TB, WB, false, true>), grid, block, lds_full, s, a);
-        else      hipLaunchKernelGGL((lrt_gemm_f32_kernel<TO, TB, WB, false, false>), grid, block, lds_full, s, a);
+    const long nblocks = (long)grid.x * grid.y;
+    static const bool no_dma = getenv("LBBNN_GEMM_NO_DMA") != nullptr;     // A/B knob for bench sweeps
+    if (xvec && (a.I % BK) == 0 && !no_dma) {
+        const size_t l_full = lds_request(2u * (BM + 2 * BN) * DROW * sizeof(float), nblocks);
+        const size_t l_mean = lds_request(2u * (BM + BN) * DROW * sizeof(float), nblocks);
+        if (mean_only) return launch_one(lrt_gemm_f32_dma_kernel<TO, TB, WB, true>, grid, block, l_mean, s, a);
+        return launch_one(lrt_gemm_f32_dma_kernel<TO, TB, WB, false>, grid, block, l_full, s, a);
     }
-    return (int)hipGetLastError();
+    const size_t lds_full = lds_request(2u * (BM + 2 * BN) * LDS_LD * sizeof(float), nblocks);
+    const size_t lds_mean = lds_request(2u * (BM + BN) * LDS_LD * sizeof(float), nblocks);
+    if (mean_only) {
+        if (xvec) return launch_one(lrt_gemm_f32_kernel<TO, TB, WB, true, true>, grid, block, lds_mean, s, a);
+        return launch_one(lrt_gemm_f32_kernel<TO, TB, WB, true, false>, grid, block, lds_mean, s, a);
+    }
+    if (xvec) return launch_one(lrt_gemm_f32_kernel<TO, TB, WB, false, true>, grid, block, lds_full, s, a);
+    return launch_one(lrt_gemm_f32_kernel<TO, TB, WB, false, false>, grid, block, lds_full, s, a);
 }
 
 }  // namespace
@@ -228,7 +584,8 @@ extern "C" int lbbnn_lrt_gemm(const float* x, int ldx, const void* e_w, const vo
                               float* out, int ldo, int B, int I, int O, int flags, void* stream) {
     if (!x || !e_w || !out) return LBBNN_E_NULL;
     if (B <= 0 || I <= 0 || O <= 0 || ldx < I || ldo < O) return LBBNN_E_SHAPE;
-    if (flags & ~(LBBNN_F_RELU | LBBNN_F_MEAN_ONLY | LBBNN_F_SPLIT16)) return LBBNN_E_FLAGS;
+    if (flags & ~(LBBNN_F_RELU | LBBNN_F_MEAN_ONLY | LBBNN_F_SPLIT16 | LBBNN_F_LOG_SOFTMAX)) return LBBNN_E_FLAGS;
+    if ((flags & LBBNN_F_LOG_SOFTMAX) && (O > 16 || (flags & LBBNN_F_RELU))) return LBBNN_E_FLAGS;
     if (flags & LBBNN_F_SPLIT16) return LBBNN_E_FLAGS;    // split-precision path: not in this build
     const bool mean_only = (flags & LBBNN_F_MEAN_ONLY) != 0;
     if (!mean_only && !var_w) return LBBNN_E_NULL;
@@ -242,13 +599,24 @@ extern "C" int lbbnn_lrt_gemm(const float* x, int ldx, const void* e_w, const vo
     a.eps = eps; a.rng = rng; a.out = out; a.row_offset = row_offset;
     a.ldx = ldx; a.ld = ld; a.ldo = ldo; a.B = B; a.I = I; a.O = O;
     a.rng_stream = rng_stream; a.relu = (flags & LBBNN_F_RELU) ? 1 : 0;
+    a.log_softmax = (flags & LBBNN_F_LOG_SOFTMAX) ? 1 : 0;
 
     const bool xvec = ((I & 3) == 0) && ((ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0);
     hipStream_t s = static_cast<hipStream_t>(stream);
     // Tile choice: 80(o) x 128(b) fills the chip for the headline shapes (B=4096, O=1200 -> 15x32 = 480
     // workgroups, 2 resident per CU); small problems take a 80x32 tile for more workgroups; a skinny
-    // output (O <= 16, the 10-class head) takes 16(o) x 64(b).
-    if (O <= 16) return launch_cfg<1, 1, 4>(a, mean_only, xvec, s);
+    // output (O <= 16, the 10-class head) takes the split-K kernel above.
+    if (O <= 16) {
+        dim3 grid((B + 15) / 16), block(SK_WAVES * 64);
+        if (mean_only) {
+            if (xvec) hipLaunchKernelGGL((lrt_gemm_skinny_kernel<true, true>), grid, block, 0, s, a);
+            else      hipLaunchKernelGGL((lrt_gemm_skinny_kernel<true, false>), grid, block, 0, s, a);
+        } else {
+            if (xvec) hipLaunchKernelGGL((lrt_gemm_skinny_kernel<false, true>), grid, block, 0, s, a);
+            else      hipLaunchKernelGGL((lrt_gemm_skinny_kernel<false, false>), grid, block, 0, s, a);
+        }
+        return (int)hipGetLastError();
+    }
     const long blocks_big = (long)((O + 79) / 80) * ((B + 127) / 128);
     if (blocks_big >= 256) return launch_cfg<5, 2, 4>(a, mean_only, xvec, s);
     return launch_cfg<5, 1, 2>(a, mean_only, xvec, s);

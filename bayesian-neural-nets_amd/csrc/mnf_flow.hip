@@ -93,6 +93,119 @@ __global__ __launch_bounds__(256) void mnf_flow_planar_kernel(const FlowArgs a) 
     }
 }
 
+
+// ---- fast path: I <= 256*KMAX and T <= 4.  Everything one thread needs (its KMAX elements of z, of
+// q0_mean / q0_log_var / eps and of every transform's u, w) is loaded into registers BEFORE the first
+// reduction, so the whole kernel pays one HBM/L2 latency instead of one per transform; z never leaves
+// registers and the only LDS traffic is the two-value block reductions.
+constexpr int FT = 4;     // max transforms per flow on the fast path
+
+template <typename T2>
+__device__ __forceinline__ void block_sum2(double& a, double& b, T2* scratch) {
+    a = wave_sum(a); b = wave_sum(b);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) { scratch[w] = a; scratch[4 + w] = b; }
+    __syncthreads();
+    a = (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+    b = (scratch[4] + scratch[5]) + (scratch[6] + scratch[7]);
+}
+
+template <int KMAX>
+__device__ __forceinline__ float planar_apply_reg(const float (&u)[FT][KMAX], const float (&w)[FT][KMAX],
+                                                  const float (&bias)[FT], int T, float (&z)[KMAX], double* scratch) {
+    float logdet = 0.f;
+#pragma unroll
+    for (int t = 0; t < FT; ++t) {
+        if (t < T) {
+            double s_wz = 0.0, s_uw = 0.0;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) { s_wz += (double)(w[t][k] * z[k]); s_uw += (double)(u[t][k] * w[t][k]); }
+            block_sum2(s_wz, s_uw, scratch);
+            const float th = tanhf((float)s_wz + bias[t]);
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) z[k] += u[t][k] * th;
+            logdet += logf(fabsf(1.f + (1.f - th * th) * (float)s_uw));
+        }
+    }
+    return logdet;
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(256) void mnf_flow_planar_fast_kernel(const FlowArgs a) {
+    __shared__ double scratch[8];
+    const bool klblk = blockIdx.x == 1;
+    const float* eps = klblk ? a.eps_kl : a.eps_fwd;
+    const int tid = threadIdx.x;
+    float zu[FT][KMAX], zw[FT][KMAX], ru[FT][KMAX], rw[FT][KMAX], zb[FT], rb[FT];
+    float qm[KMAX], lv[KMAX], e[KMAX];
+    // ---- issue every load first (indices past I read as 0 and contribute nothing)
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int i = tid + 256 * k;
+        const bool in = i < a.I;
+        qm[k] = in ? a.q0_mean[i] : 0.f;
+        lv[k] = in ? a.q0_log_var[i] : 0.f;
+        e[k] = (in && eps) ? eps[i] : 0.f;
+#pragma unroll
+        for (int t = 0; t < FT; ++t) {
+            zu[t][k] = (in && t < a.zf.T) ? a.zf.u[t][i] : 0.f;
+            zw[t][k] = (in && t < a.zf.T) ? a.zf.w[t][i] : 0.f;
+            ru[t][k] = (in && klblk && t < a.rf.T) ? a.rf.u[t][i] : 0.f;
+            rw[t][k] = (in && klblk && t < a.rf.T) ? a.rf.w[t][i] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < FT; ++t) {
+        zb[t] = t < a.zf.T ? a.zf.b[t][0] : 0.f;
+        rb[t] = (klblk && t < a.rf.T) ? a.rf.b[t][0] : 0.f;
+    }
+    if (!eps) {
+        const uint64_t seed = a.rng[0], offs = a.rng[1];
+        const uint32_t stream = (klblk ? LBBNN_STREAM_EPS_Z2 : LBBNN_STREAM_EPS_Z) * 64u + a.layer;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int i = tid + 256 * k;
+            float n[4];
+            philox_normal4(seed, offs, stream, (uint64_t)(i >> 2), 0u, n);
+            e[k] = n[i & 3];
+        }
+    }
+    float z[KMAX];
+    double lq0 = 0.0;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int i = tid + 256 * k;
+        const float ev = expf(lv[k]);
+        const float z0 = qm[k] + sqrtf(ev) * e[k];                    // LBBNN-GP-MF-MNF.py:183-185
+        z[k] = (i < a.I) ? z0 : 0.f;
+        if (klblk && i < a.I) {
+            const float d = z0 - qm[k];
+            lq0 += (double)(-0.5f * 1.1447298858494002f - 0.5f * lv[k] - 0.5f * ((d * d) / ev));   // :213-214
+        }
+    }
+    const float ldq = planar_apply_reg<KMAX>(zu, zw, zb, a.zf.T, z, scratch);
+    float* zo = klblk ? a.z_kl : a.z_fwd;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) { const int i = tid + 256 * k; if (i < a.I) zo[i] = z[k]; }
+    if (!klblk) {
+        if (tid == 0 && a.scal) a.scal[4] = ldq;
+        return;
+    }
+    double dummy = 0.0;
+    block_sum2(lq0, dummy, scratch);
+    const float ldr = planar_apply_reg<KMAX>(ru, rw, rb, a.rf.T, z, scratch);
+    // z_b[-1]: the thread that owns element I-1 publishes it                        :224
+    const int last = a.I - 1;
+    if (tid == (last & 255)) {
+        float zl = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) if (k == (last >> 8)) zl = z[k];
+        a.scal[3] = zl;
+    }
+    if (tid == 0) { a.scal[0] = ldq; a.scal[1] = (float)lq0; a.scal[2] = ldr; }
+}
+
 // -------------------------------------------------------------------------------------------- K5
 struct FinalizeArgs {
     const float* kl_rows; const float* bias_mu; const float* bias_rho;
@@ -211,8 +324,12 @@ extern "C" int lbbnn_mnf_flow_planar(const float* q0_mean, const float* q0_log_v
     a.z_fwd = z_fwd; a.z_kl = z_kl; a.scal = scal; a.I = I; a.want_kl = want_kl; a.layer = layer_id & 63u;
     if (!fill_set(a.zf, zu, zw, zb, Tz)) return LBBNN_E_NULL;
     if (!fill_set(a.rf, ru, rw, rb, want_kl ? Tr : 0)) return LBBNN_E_NULL;
-    hipLaunchKernelGGL(mnf_flow_planar_kernel, dim3(want_kl ? 2 : 1), dim3(256), (size_t)I * sizeof(float),
-                       static_cast<hipStream_t>(stream), a);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid(want_kl ? 2 : 1), block(256);
+    const bool small_t = Tz <= FT && (!want_kl || Tr <= FT);
+    if (small_t && I <= 256 * 2)      hipLaunchKernelGGL(mnf_flow_planar_fast_kernel<2>, grid, block, 0, s, a);
+    else if (small_t && I <= 256 * 5) hipLaunchKernelGGL(mnf_flow_planar_fast_kernel<5>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(mnf_flow_planar_kernel, grid, block, (size_t)I * sizeof(float), s, a);
     return (int)hipGetLastError();
 }
 

@@ -38,7 +38,7 @@ class _BayesLinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, layer, x, cfg, *params):
-        out, kl, saved = layer._forward_hip(x, cfg)
+        out, kl, saved = layer._forward_hip(x, cfg, save_rng=True)
         ctx.layer, ctx.cfg, ctx.saved = layer, cfg, saved
         ctx.save_for_backward(x, *params)
         if kl is None:
@@ -120,6 +120,22 @@ class _BayesLinearBase(nn.Module):
     def _param_list(self):
         raise NotImplementedError
 
+    def _forward_hip(self, x, cfg, advance=True, save_rng=False):
+        """One layer, sequentially on the current stream: prep kernels, GEMM, RNG advance.
+        ``save_rng`` snapshots the device RNG state so backward can re-create the in-kernel draws."""
+        rng, st = None, None
+        saved = {"noise": self.noise}
+        if self._uses_rng(cfg):
+            st = ops.RngState.get(x.device)
+            rng = st.t
+            saved["rng"] = rng.clone() if save_rng else None
+        kl = torch.empty((), dtype=torch.float32, device=x.device) if cfg[1] else None
+        self._prep(cfg, rng, kl_layer=kl)
+        out = self._gemm(x, cfg, rng)
+        if st is not None and advance:
+            st.advance(1)
+        return out, kl, saved
+
     def forward(self, input, sample=False, calculate_log_probs=False, *, _relu=False):
         if not input.is_cuda:
             raise RuntimeError("bnn_amd: forward needs a HIP device tensor (input is on %s); there is no CPU path"
@@ -147,36 +163,37 @@ class LRTBayesianLinear(_BayesLinearBase):
 
     _names = ("weight_mu", "weight_rho", "lambdal", "bias_mu", "bias_rho")
 
-    def _forward_hip(self, x, cfg):
-        stochastic, want_kl, relu = cfg
+    def _uses_rng(self, cfg):
+        return cfg[0] and not (self.noise and "eps_out" in self.noise)
+
+    def _prep(self, cfg, rng, kl_layer=None, kl_total=None, accumulate=False, finalize=True):
+        """x-independent kernels: K1 weight pass (+ K5 KL finalize unless deferred to ``_finalize``)."""
+        stochastic, want_kl, _ = cfg
         ws = self._workspace()
-        noise = self.noise or {}
-        eps = noise.get("eps_out")
-        rng = None
-        saved = {"noise": self.noise}
-        if stochastic and eps is None:
-            st = ops.RngState.get(x.device)
-            rng = st.t
-            saved["rng"] = rng.clone()
         ops.weight_pass(self.weight_mu, self.weight_rho, self.lambdal, bias_rho=self.bias_rho,
                         priors=self.priors, e_w=ws.e_w, var_w=ws.var_w if stochastic else None,
                         kl_rows=ws.kl_rows if want_kl else None, bias_var=ws.bias_var)
-        out = ops.lrt_gemm(x, ws.e_w, ws.var_w, I=self.in_features, O=self.out_features,
-                           bias_mean=self.bias_mu, bias_var=ws.bias_var, eps=eps, rng=rng,
-                           rng_stream=ops.STREAM_EPS_OUT * 64 + self._layer_id, row_offset=self.row_offset,
-                           relu=relu, mean_only=not stochastic)
-        kl = None
-        if want_kl:
-            kl = torch.empty((), dtype=torch.float32, device=x.device)
-            ops.kl_finalize(ws.kl_rows, self.bias_mu, self.bias_rho, priors=self.priors, kl_out=kl)
-        if rng is not None:
-            st.advance(1)
-        return out, kl, saved
+        if want_kl and finalize:
+            self._finalize(rng, kl_layer, kl_total, accumulate)
+
+    def _finalize(self, rng, kl_layer=None, kl_total=None, accumulate=False):
+        ws = self._workspace()
+        ops.kl_finalize(ws.kl_rows, self.bias_mu, self.bias_rho, priors=self.priors, kl_layer=kl_layer,
+                        kl_out=kl_total, accumulate=accumulate)
+
+    def _gemm(self, x, cfg, rng, log_softmax=False):
+        stochastic, _, relu = cfg
+        ws = self._workspace()
+        eps = (self.noise or {}).get("eps_out")
+        return ops.lrt_gemm(x, ws.e_w, ws.var_w, I=self.in_features, O=self.out_features,
+                            bias_mean=self.bias_mu, bias_var=ws.bias_var, eps=eps, rng=rng,
+                            rng_stream=ops.STREAM_EPS_OUT * 64 + self._layer_id, row_offset=self.row_offset,
+                            relu=relu, mean_only=not stochastic, log_softmax=log_softmax)
 
     def _noise_for_backward(self, saved, B):
         if saved.get("noise") and "eps_out" in saved["noise"]:
             return saved["noise"]
-        if "rng" not in saved:
+        if saved.get("rng") is None:
             return {}
         return {"eps_out": ops.philox_normal(saved["rng"], ops.STREAM_EPS_OUT * 64 + self._layer_id,
                                              B, self.out_features, self.row_offset)}
@@ -227,21 +244,24 @@ class MNFBayesianLinear(_BayesLinearBase):
             st.advance(1)
         return ws.z_fwd.clone(), ws.scal[4].clone()
 
-    def _forward_hip(self, x, cfg):
-        stochastic, want_kl, relu = cfg
-        self._check_flows()
-        ws = self._workspace()
+    def _needed_noise(self, cfg):
+        return ["eps_z"] + (["eps_out"] if cfg[0] else []) + (["eps_z2", "eps_act"] if cfg[1] else [])
+
+    def _uses_rng(self, cfg):
         noise = self.noise or {}
-        need = ["eps_z"] + (["eps_out"] if stochastic else []) + (["eps_z2", "eps_act"] if want_kl else [])
+        need = self._needed_noise(cfg)
         have = [k for k in need if k in noise]
         if have and len(have) != len(need):
             raise RuntimeError("bnn_amd: layer.noise must give all of %s or none (got %s)" % (need, have))
-        rng, st = None, None
-        saved = {"noise": self.noise if have else None}
-        if not have:
-            st = ops.RngState.get(x.device)
-            rng = st.t
-            saved["rng"] = rng.clone()
+        return not have
+
+    def _prep(self, cfg, rng, kl_layer=None, kl_total=None, accumulate=False, finalize=True):
+        """x-independent kernels: K3 flows, K1 weight pass, K5 KL finalize (``finalize=False`` defers K5
+        to ``_finalize`` so a network can keep it off the critical path)."""
+        stochastic, want_kl, _ = cfg
+        self._check_flows()
+        ws = self._workspace()
+        noise = self.noise or {}
         eps_z = noise.get("eps_z")
         if eps_z is not None and eps_z.dim() == 2:
             eps_z = eps_z[-1]                      # zs[-1]: only the last of the B rows is used (:187)
@@ -261,20 +281,24 @@ class MNFBayesianLinear(_BayesLinearBase):
                         kl_rows=ws.kl_rows if want_kl else None,
                         act_mu=ws.act_mu if want_kl else None, act_var=ws.act_var if want_kl else None,
                         bias_var=ws.bias_var)
-        out = ops.lrt_gemm(x, ws.e_w, ws.var_w, I=self.in_features, O=self.out_features,
-                           bias_mean=self.bias_mu, bias_var=ws.bias_var, eps=noise.get("eps_out"), rng=rng,
-                           rng_stream=ops.STREAM_EPS_OUT * 64 + self._layer_id, row_offset=self.row_offset,
-                           relu=relu, mean_only=not stochastic)
-        kl = None
-        if want_kl:
-            kl = torch.empty((), dtype=torch.float32, device=x.device)
-            ops.kl_finalize(ws.kl_rows, self.bias_mu, self.bias_rho, priors=self.priors,
-                            act_mu=ws.act_mu, act_var=ws.act_var, eps_act=noise.get("eps_act"),
-                            r0_b1=self.r0_b1, r0_b2=self.r0_b2, scal=ws.scal, rng=rng,
-                            layer_id=self._layer_id, kl_out=kl)
-        if st is not None:
-            st.advance(1)
-        return out, kl, saved
+        if want_kl and finalize:
+            self._finalize(rng, kl_layer, kl_total, accumulate)
+
+    def _finalize(self, rng, kl_layer=None, kl_total=None, accumulate=False):
+        ws = self._workspace()
+        ops.kl_finalize(ws.kl_rows, self.bias_mu, self.bias_rho, priors=self.priors,
+                        act_mu=ws.act_mu, act_var=ws.act_var, eps_act=(self.noise or {}).get("eps_act"),
+                        r0_b1=self.r0_b1, r0_b2=self.r0_b2, scal=ws.scal, rng=rng,
+                        layer_id=self._layer_id, kl_layer=kl_layer, kl_out=kl_total, accumulate=accumulate)
+
+    def _gemm(self, x, cfg, rng, log_softmax=False):
+        stochastic, _, relu = cfg
+        ws = self._workspace()
+        return ops.lrt_gemm(x, ws.e_w, ws.var_w, I=self.in_features, O=self.out_features,
+                            bias_mean=self.bias_mu, bias_var=ws.bias_var, eps=(self.noise or {}).get("eps_out"),
+                            rng=rng, rng_stream=ops.STREAM_EPS_OUT * 64 + self._layer_id,
+                            row_offset=self.row_offset, relu=relu, mean_only=not stochastic,
+                            log_softmax=log_softmax)
 
     def _noise_for_backward(self, saved, B):
         if saved.get("noise"):
@@ -302,18 +326,78 @@ class MNFBayesianLinear(_BayesLinearBase):
 
 
 class _NetworkBase(nn.Module):
+    """3-layer MLP of Bayesian layers: ReLU, ReLU, log_softmax (LBBNN-GP-MF-LRT.py:206-214).
+
+    Without autograd the forward is scheduled across two HIP streams: everything that does not
+    depend on the activations (flows, weight passes, KL finalisation of ALL layers) runs on a side
+    stream, so the critical path is only  [prep of layer 1] -> GEMM1 -> GEMM2 -> GEMM3  with ReLU /
+    log_softmax fused into the GEMM epilogues; the three layers share one RNG offset (their Philox
+    streams differ by layer id) and the offset is advanced once per forward.  The multi-stream
+    sequence contains no host synchronisation and is HIP-graph capturable.
+    """
+    _kl_total = None
+
+    def _layers(self):
+        return [self.l1, self.l2, self.l3]
+
     def forward(self, x, sample=False):
         x = x.view(-1, self.dims[0])                                  # …LRT.py:207
-        layers = [self.l1, self.l2, self.l3]
-        for i, l in enumerate(layers):
-            x = l.forward(x, sample, _relu=(i < 2))                   # F.relu fused into the GEMM epilogue
-        return F.log_softmax(x, dim=1)                                # …LRT.py:210
+        layers = self._layers()
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if needs_grad or not x.is_cuda:
+            self._kl_total = None
+            for i, l in enumerate(layers):
+                x = l.forward(x, sample, _relu=(i < 2))               # F.relu fused into the GEMM epilogue
+            return F.log_softmax(x, dim=1)                            # …LRT.py:210
+        return self._forward_streams(x.float(), sample)
+
+    def _forward_streams(self, x, sample):
+        layers = self._layers()
+        dev = x.device
+        cfgs = [(bool(l.training or sample), bool(l.training), i < 2) for i, l in enumerate(layers)]
+        st = None
+        if any(l._uses_rng(c) for l, c in zip(layers, cfgs)):
+            st = ops.RngState.get(dev)
+        rng = st.t if st is not None else None
+        main = torch.cuda.current_stream(dev)
+        if getattr(self, "_side", None) is None or self._side.device != dev:
+            self._side = torch.cuda.Stream(device=dev)
+            self._events = [torch.cuda.Event() for _ in layers]
+        side = self._side
+        want_kl = any(c[1] for c in cfgs)
+        kls = [torch.empty((), dtype=torch.float32, device=dev) if c[1] else None for c in cfgs]
+        total = torch.empty((), dtype=torch.float32, device=dev) if want_kl else None
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            for l, c, ev in zip(layers, cfgs, self._events):
+                l._prep(c, rng, finalize=False)                 # K5 deferred: keeps it off the critical path
+                ev.record(side)
+            first = True
+            for l, c, k in zip(layers, cfgs, kls):
+                if not c[1]:
+                    continue
+                l._finalize(rng, kl_layer=k, kl_total=total, accumulate=not first)
+                first = False
+        for i, (l, c, ev) in enumerate(zip(layers, cfgs, self._events)):
+            main.wait_event(ev)
+            x = l._gemm(x, c, rng, log_softmax=(i == len(layers) - 1 and l.out_features <= 16))
+        if layers[-1].out_features > 16:
+            x = F.log_softmax(x, dim=1)
+        main.wait_stream(side)
+        if st is not None:
+            st.advance(1)
+        for l, c, k in zip(layers, cfgs, kls):
+            l.kl = k if c[1] else 0
+        self._kl_total = total
+        return x
 
     def kl(self):
+        if self._kl_total is not None:
+            return self._kl_total                                     # summed on the device by K5
         return self.l1.kl + self.l2.kl + self.l3.kl                   # …LRT.py:213-214
 
     def set_row_offset(self, off: int):
-        for l in (self.l1, self.l2, self.l3):
+        for l in self._layers():
             l.row_offset = int(off)
 
 

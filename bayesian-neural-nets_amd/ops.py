@@ -15,6 +15,7 @@ from ._lib import Priors
 F_RELU = 0x1
 F_MEAN_ONLY = 0x2
 F_SPLIT16 = 0x4
+F_LOG_SOFTMAX = 0x8
 
 STREAM_EPS_OUT = 0
 STREAM_EPS_Z = 1
@@ -35,6 +36,15 @@ def _ptr(t: Optional[torch.Tensor], name: str = "tensor") -> Optional[int]:
         raise RuntimeError("bnn_amd: %s has dtype %s, expected float32" % (name, t.dtype))
     if not t.is_contiguous():
         raise RuntimeError("bnn_amd: %s must be contiguous" % name)
+    return t.data_ptr()
+
+
+def _ptr_rows(t: torch.Tensor, name: str) -> int:
+    """Pointer of a 2-D fp32 GPU tensor whose rows are dense (stride(1) == 1); row stride is free."""
+    if not t.is_cuda:
+        raise RuntimeError("bnn_amd: %s is on %s; the HIP path needs a GPU tensor (no CPU fallback)" % (name, t.device))
+    if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
+        raise RuntimeError("bnn_amd: %s must be a 2-D float32 tensor with dense rows" % name)
     return t.data_ptr()
 
 
@@ -111,9 +121,15 @@ def weight_pass(mu, rho, lambdal, *, z_fwd=None, z_kl=None, r0_c=None, bias_rho=
 
 
 # ----------------------------------------------------------------------------------------- K2
+# When set to a list, every lrt_gemm launch is bracketed by HIP events recorded on the launch
+# stream and (B, I, O, start, end) is appended -- bench.py's per-kernel roofline timing.
+GEMM_EVENTS = None
+
+
 def lrt_gemm(x, e_w, var_w, *, I: int, O: int, bias_mean=None, bias_var=None, var_scale=None,
              eps=None, rng: Optional[torch.Tensor] = None, rng_stream: int = 0, row_offset: int = 0,
-             relu: bool = False, mean_only: bool = False, out: Optional[torch.Tensor] = None):
+             relu: bool = False, mean_only: bool = False, log_softmax: bool = False,
+             out: Optional[torch.Tensor] = None):
     """lbbnn_lrt_gemm: out = x.e_w^T + b [+ sqrt(x^2.var_w^T + bv) * eps] [ReLU]."""
     if x.dim() != 2 or x.shape[1] != I:
         raise RuntimeError("bnn_amd: input must be (B,%d), got %s" % (I, tuple(x.shape)))
@@ -122,15 +138,22 @@ def lrt_gemm(x, e_w, var_w, *, I: int, O: int, bias_mean=None, bias_var=None, va
         out = torch.empty((B, O), dtype=torch.float32, device=x.device)
     if eps is not None and tuple(eps.shape) != (B, O):
         raise RuntimeError("bnn_amd: eps must be (%d,%d), got %s" % (B, O, tuple(eps.shape)))
-    flags = (F_RELU if relu else 0) | (F_MEAN_ONLY if mean_only else 0)
-    if x.stride(1) != 1:
+    flags = (F_RELU if relu else 0) | (F_MEAN_ONLY if mean_only else 0) | (F_LOG_SOFTMAX if log_softmax else 0)
+    if x.stride(1) != 1 or (x.stride(0) < I):
         x = x.contiguous()
+    ev = None
+    if GEMM_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     rc = _lib.lib().lbbnn_lrt_gemm(
-        x.data_ptr() if x.is_cuda else _ptr(x, "input"), x.stride(0), _ptr(e_w), _ptr(var_w), operand_ld(I),
+        _ptr_rows(x, "input"), x.stride(0), _ptr(e_w), _ptr(var_w), operand_ld(I),
         _ptr(bias_mean), _ptr(bias_var), _ptr(var_scale), _ptr(eps, "eps"),
         rng.data_ptr() if rng is not None else None, rng_stream, row_offset,
         out.data_ptr(), out.stride(0), B, I, O, flags, _stream())
     _lib.check(rc, "lbbnn_lrt_gemm")
+    if ev is not None:
+        ev[1].record()
+        GEMM_EVENTS.append((B, I, O, ev[0], ev[1]))
     return out
 
 

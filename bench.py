@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""ELBO-forward throughput of the MNF Bayesian MLP on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one training-mode forward of the 784-1200-1200-10 MNF network (2 planar flows per
+layer) over one synthetic MNIST-shaped batch of 4096 rows PER GPU: the three layers' sampled
+activations, log_softmax, and net.kl() -- what the reference's train() runs before .backward()
+(LBBNN-GP-MF-MNF.py:268-270).  Inputs are resident in HBM before the timed region; noise is drawn
+in-kernel (Philox).  Data parallel: every rank holds the (replicated) parameters and its own
+4096 rows (weak scaling); the forward has no collective.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with two extra objects:
+  roofline      dominant kernel (the 80x128-tile dual-moment GEMM) timed with HIP events inside
+                the timed region vs the fp32 MFMA peak;
+  cpu_baseline  the CPU oracle (port of the reference op sequence, as-written B-row z flow) timed
+                on this box's host cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+DIMS = (784, 1200, 1200, 10)
+T_FLOWS = 2
+BATCH = 4096
+FP32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=BATCH, help="rows per GPU (headline: 4096)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-baseline sample")
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip per-kernel HIP-event timing")
+    return ap.parse_args()
+
+
+def host_cores():
+    """Host cores this job may actually use: the cgroup CPU quota when there is one (the GPU box
+    gives a 1-GPU job a share of the host), else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return min(n, int(os.environ.get("BNN_CPU_THREADS", "16")))   # gpurun: 16-core share per GPU
+
+
+def cpu_baseline(batch, seconds):
+    """The oracle's restatement of the reference op sequence on the host cores (kind 'port').
+
+    As written in the reference: the z flow runs on all B rows (of which only the last is kept),
+    randn draws included.  Returns samples/s (median of the timed iterations)."""
+    from oracle import lbbnn_oracle as orc
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(0)
+    layers, zf, rf = [], [], []
+    for i in range(3):
+        I, O = DIMS[i], DIMS[i + 1]
+        layers.append(orc.init_mnf_params(I, O, g))
+        zf.append(orc.init_planar_flow(I, T_FLOWS, g))
+        rf.append(orc.init_planar_flow(I, T_FLOWS, g))
+    x = torch.rand(batch, DIMS[0], generator=g)
+
+    def one():
+        noise = []
+        for i in range(3):
+            I, O = DIMS[i], DIMS[i + 1]
+            noise.append({"eps_z": torch.randn(batch, I), "eps_out": torch.randn(batch, O),
+                          "eps_z2": torch.randn(1, I), "eps_act": torch.randn(O)})
+        out, kl = orc.mnf_network_forward(x, layers, zf, rf, noise)
+        return out, kl
+
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        one()
+        first = time.perf_counter() - t0
+        one()
+        iters = max(3, min(50, int(seconds / max(first, 1e-3)) - 2))
+        ts = []
+        for _ in range(iters):
+            t0 = time.perf_counter()
+            one()
+            ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return {"value": batch / med, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "%d ELBO forwards of the same 784-1200-1200-10 MNF/planar net at batch %d "
+                      "(torch-CPU fp32 oracle, as-written B-row z flow, randn draws included), median %.1f ms"
+                      % (iters, batch, med * 1e3)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import bnn_amd
+    from bnn_amd import ops
+
+    torch.manual_seed(0)          # same parameters and same z-noise stream on every rank
+    net = bnn_amd.mnf.BayesianNetwork(DIMS, T_FLOWS, z_flow_type="Planar", r_flow_type="Planar").to(dev)
+    net.train()
+    net.set_row_offset(rank * args.batch)     # eps counters are global row indices: rank-distinct draws
+    B = args.batch
+    x = torch.rand(B, 1, 28, 28, device=dev, generator=torch.Generator(device=dev).manual_seed(1 + rank))
+
+    def step():
+        out = net(x, sample=True)
+        return out, net.kl()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        sync()
+        if not args.no_kernel_events:
+            ops.GEMM_EVENTS = []
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out, kl = step()
+        sync()
+        elapsed = time.perf_counter() - t0
+    events, ops.GEMM_EVENTS = ops.GEMM_EVENTS, None
+    assert torch.isfinite(out).all() and torch.isfinite(kl)
+
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        total = B * world * args.steps
+        sum_io = sum(DIMS[i] * DIMS[i + 1] for i in range(3))
+        res = {
+            "metric": "ELBO forward samples/sec, 784-1200^2-10 MNF MLP, batch 4096 per GPU",
+            "value": total / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "LBBNN-GP-MF-MNF 784-1200-1200-10, 2 planar flows/layer, batch %d per GPU, "
+                                   "training-mode ELBO forward (activations + log_softmax + kl), in-kernel Philox noise" % B,
+                       "global_batch": B * world, "parallelism": "dp%d (replicated parameters, no forward collective)" % world},
+            "gflop_per_step_algorithmic": 4.0 * B * sum_io / 1e9,
+        }
+        if events:
+            # dominant kernel: the <5,2,4> instantiation (80x128 tile) = the layer-1 and layer-2 GEMMs
+            big = [(b, i, o, s.elapsed_time(e)) for (b, i, o, s, e) in events if o > 16]
+            flops = sum(4.0 * b * i * o for (b, i, o, _) in big) / len(big)
+            avg_ms = sum(ms for (_, _, _, ms) in big) / len(big)
+            ach = flops / (avg_ms * 1e-3) / 1e12
+            res["roofline"] = {"bound": "mfma", "kernel": "lrt_gemm_f32_kernel<5,2,4> (dual-moment GEMM, 80x128 tile)",
+                               "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                               "avg_launch_us": avg_ms * 1e3, "launches": len(big),
+                               "gemm_share_of_step": sum(s.elapsed_time(e) for (_, _, _, s, e) in events) / (elapsed * 1e3)}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(B, args.cpu_seconds)
+            res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -43,6 +43,7 @@ extern "C" {
 #define LBBNN_F_RELU 0x1       /* fuse F.relu on the output (LBBNN-GP-MF-LRT.py:208-209)      */
 #define LBBNN_F_MEAN_ONLY 0x2  /* posterior-mean branch: out = x.e_w^T + b (…LRT.py:178-180)  */
 #define LBBNN_F_SPLIT16 0x4    /* split-precision MFMA path (bf16x3 mean, fp16 variance)      */
+#define LBBNN_F_LOG_SOFTMAX 0x8 /* fuse F.log_softmax(dim=1) on the output; O <= 16 only (…LRT.py:210) */
 
 /* Philox stream ids (third counter word) -- one per kind of draw, per layer (stream = kind*64+layer) */
 #define LBBNN_STREAM_EPS_OUT 0

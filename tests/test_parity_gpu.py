@@ -369,3 +369,62 @@ def test_error_paths(bnn, dev):
     with pytest.raises(NotImplementedError):
         l = bnn.mnf.BayesianLinear(8, 4, 2).to(dev)                                              # RNVP default
         l(x)
+
+
+# --------------------------------------------------------------------------- scheduling variants
+def test_stream_schedule_equals_sequential(bnn, dev, golden):
+    """The two-stream no-grad schedule (fused ReLU/log_softmax, deferred K5) and the per-layer
+    autograd path compute the same numbers."""
+    c = golden("mnf.npz").case("smallnet")
+    dims = [int(v) for v in c["dims"]]
+    net = bnn.mnf.BayesianNetwork(dims, 2, z_flow_type="Planar", r_flow_type="Planar")
+    for i, l in enumerate((net.l1, net.l2, net.l3)):
+        l.load_state_dict(sub(c, "l%d.p." % i))
+    net = net.to(dev).train()
+    for i, l in enumerate((net.l1, net.l2, net.l3)):
+        l.noise = {k: c["l%d.%s" % (i, k)].to(dev) for k in ("eps_z", "eps_out", "eps_z2", "eps_act")}
+    x = c["x"].to(dev)
+    with torch.no_grad():
+        a = net(x, sample=True); kla = net.kl().clone()
+    b = net(x, sample=True); klb = net.kl()
+    assert b.requires_grad and klb.requires_grad
+    assert rel_err(a, b) < 1e-6 and rel_err(kla, klb) < 1e-6
+    assert rel_err(net.l1.kl + net.l2.kl + net.l3.kl, kla) < 1e-6
+
+
+@pytest.mark.parametrize("B,I,O", [(4096, 1200, 10), (37, 100, 16), (16, 33, 3)])
+def test_skinny_gemm_fused_log_softmax(bnn, dev, B, I, O):
+    ops = bnn.ops
+    g = torch.Generator().manual_seed(B + O)
+    x = torch.rand(B, I, generator=g)
+    ld = ops.operand_ld(I)
+    ew = torch.zeros(O, ld); ew[:, :I] = 0.2 * (torch.rand(O, I, generator=g) - 0.5)
+    vw = torch.zeros(O, ld); vw[:, :I] = 1e-3 * torch.rand(O, I, generator=g)
+    bm = torch.rand(O, generator=g); bv = 1e-3 * torch.rand(O, generator=g)
+    eps = torch.randn(B, O, generator=g)
+    out = ops.lrt_gemm(x.to(dev), ew.to(dev), vw.to(dev), I=I, O=O, bias_mean=bm.to(dev), bias_var=bv.to(dev),
+                       eps=eps.to(dev), log_softmax=True)
+    x64 = x.double()
+    pre = x64 @ ew[:, :I].double().T + bm.double() + torch.sqrt((x64 ** 2) @ vw[:, :I].double().T + bv.double()) * eps.double()
+    assert rel_err(out, torch.log_softmax(pre, 1)) < TIGHT
+
+
+def test_hip_graph_capture_replays_with_fresh_noise(bnn, dev):
+    torch.manual_seed(3)
+    net = bnn.mnf.BayesianNetwork((784, 256, 128, 10), 2, z_flow_type="Planar", r_flow_type="Planar").to(dev).train()
+    x = torch.rand(64, 784, device=dev)
+    with torch.no_grad():
+        for _ in range(3):
+            net(x, sample=True)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = net(x, sample=True)
+            kl = net.kl()
+        g.replay(); torch.cuda.synchronize()
+        o1, k1 = out.clone(), kl.clone()
+        g.replay(); torch.cuda.synchronize()
+        o2, k2 = out.clone(), kl.clone()
+    assert torch.isfinite(o1).all() and torch.isfinite(o2).all()
+    assert not torch.equal(o1, o2)              # the device-side RNG offset advanced inside the graph
+    assert abs(float(k1) - float(k2)) / abs(float(k1)) < 1e-2 and float(k1) != float(k2)

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""GEMM-only driver for rocprofv3 passes: launches the dual-moment GEMM of the headline layers
+(B x 784 x 1200 and B x 1200 x 1200) N times with in-kernel noise.  Usage:
+    rocprofv3 --kernel-trace --pmc <counters> -d out -- python3 tools/profile_gemm.py [B] [N]
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bnn_amd
+from bnn_amd import ops
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+dev = torch.device("cuda:0")
+st = ops.RngState.get(dev)
+g = torch.Generator(device=dev).manual_seed(0)
+res = []
+for (I, O) in [(784, 1200), (1200, 1200)]:
+    ld = ops.operand_ld(I)
+    x = torch.rand(B, I, device=dev, generator=g)
+    ew = torch.zeros(O, ld, device=dev); ew[:, :I] = 0.02 * (torch.rand(O, I, device=dev, generator=g) - 0.5)
+    vw = torch.zeros(O, ld, device=dev); vw[:, :I] = 1e-4 * torch.rand(O, I, device=dev, generator=g)
+    bm = torch.rand(O, device=dev, generator=g); bv = 1e-4 * torch.rand(O, device=dev, generator=g)
+    out = torch.empty(B, O, device=dev)
+    for _ in range(3):
+        ops.lrt_gemm(x, ew, vw, I=I, O=O, bias_mean=bm, bias_var=bv, rng=st.t, relu=True, out=out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(N):
+        ops.lrt_gemm(x, ew, vw, I=I, O=O, bias_mean=bm, bias_var=bv, rng=st.t, relu=True, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / N
+    res.append((I, O, us, 4.0 * B * I * O / us / 1e6))
+for r in res:
+    print("B=%d I=%d O=%d  %.1f us/launch  %.1f TFLOP/s (algorithmic, 2 GEMMs)" % ((B,) + r))
