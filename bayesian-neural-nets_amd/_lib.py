@@ -28,6 +28,26 @@ class Priors(ctypes.Structure):
         super().__init__(mu_prior, sigma_prior, alpha_prior, bias_mu_prior, bias_sigma_prior)
 
 
+MAX_FLOW_T = 16
+MAX_LAYERS = 4
+
+
+class PlanarFlow(ctypes.Structure):
+    """lbbnn_planar_flow_t"""
+    _fields_ = [("u", c_p * MAX_FLOW_T), ("w", c_p * MAX_FLOW_T), ("b", c_p * MAX_FLOW_T), ("T", c_i)]
+
+
+class LayerDesc(ctypes.Structure):
+    """lbbnn_layer_desc_t (field order must match include/lbbnn.h)"""
+    _fields_ = [("weight_mu", c_p), ("weight_rho", c_p), ("lambdal", c_p), ("bias_mu", c_p), ("bias_rho", c_p),
+                ("q0_mean", c_p), ("q0_log_var", c_p), ("r0_c", c_p), ("r0_b1", c_p), ("r0_b2", c_p),
+                ("z_flow", PlanarFlow), ("r_flow", PlanarFlow), ("priors", Priors),
+                ("O", c_i), ("I", c_i), ("layer_id", c_u32), ("stochastic", c_i), ("want_kl", c_i),
+                ("eps_z", c_p), ("eps_z2", c_p), ("eps_act", c_p),
+                ("z_fwd", c_p), ("z_kl", c_p), ("scal", c_p), ("e_w", c_p), ("var_w", c_p),
+                ("kl_rows", c_p), ("act_mu", c_p), ("act_var", c_p), ("bias_var", c_p), ("kl_layer", c_p)]
+
+
 # name -> (restype, argtypes); must list every symbol include/lbbnn.h declares
 SIGNATURES = {
     "lbbnn_abi_version": (c_i, []),
@@ -41,6 +61,8 @@ SIGNATURES = {
                                     c_p, c_u32, c_p, c_p, c_p, c_i, c_i, c_p]),
     "lbbnn_kl_finalize": (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p,
                                 ctypes.POINTER(Priors), c_p, c_u32, c_p, c_p, c_i, c_p]),
+    "lbbnn_layers_prepare": (c_i, [ctypes.POINTER(LayerDesc), c_i, c_p, c_p]),
+    "lbbnn_forward_finish": (c_i, [c_p, c_u64, c_p, c_i, c_p, c_p]),
     "lbbnn_rng_advance": (c_i, [c_p, c_u64, c_p]),
     "lbbnn_philox_normal": (c_i, [c_p, c_u32, c_i64, c_i64, c_i64, c_p, c_p]),
     "lbbnn_log_softmax_rows": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_p]),

@@ -1,0 +1,50 @@
+// Internal (non-ABI) kernel argument structs and launchers shared by the translation units.
+// Every kernel here is batched over up to LBBNN_MAX_LAYERS layers; the single-layer C entry points
+// are n = 1 calls of the same launchers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/lbbnn.h"
+
+namespace lbbnn {
+
+#define LBBNN_HIDDEN __attribute__((visibility("hidden")))
+
+struct WeightPassArgs {
+    const float* mu; const float* rho; const float* lambdal;
+    const float* z_fwd; const float* z_kl; const float* r0_c; const float* bias_rho;
+    float* e_w; float* var_w;
+    float* kl_rows; float* act_mu; float* act_var; float* bias_var;
+    int O, I, ld, vec;
+    float mu_prior, sigma_prior, alpha_prior;
+};
+
+struct FlowArgs {
+    const float* q0_mean; const float* q0_log_var;
+    const float* eps_fwd; const float* eps_kl;
+    const uint64_t* rng;
+    float* z_fwd; float* z_kl; float* scal;
+    lbbnn_planar_flow_t zf, rf;
+    int I; int want_kl; uint32_t layer;
+};
+
+struct FinalizeArgs {
+    const float* kl_rows; const float* bias_mu; const float* bias_rho;
+    const float* act_mu; const float* act_var; const float* eps_act;
+    const float* r0_b1; const float* r0_b2; const float* scal;
+    const uint64_t* rng;
+    float* kl_out; float* kl_layer;
+    int O, I, accum; uint32_t layer;
+    float bias_mu_prior, bias_sigma_prior;
+};
+
+// Fill / validate helpers (return LBBNN_E_* or 0); launchers return hipGetLastError().
+LBBNN_HIDDEN int make_weight_pass_args(WeightPassArgs& a, const float* mu, const float* rho, const float* lambdal,
+                                       const float* z_fwd, const float* z_kl, const float* r0_c, const float* bias_rho,
+                                       const lbbnn_priors_t* priors, void* e_w, void* var_w, int ld,
+                                       float* kl_rows, float* act_mu, float* act_var, float* bias_var, int O, int I);
+LBBNN_HIDDEN int launch_weight_pass(const WeightPassArgs* a, int n, hipStream_t s);
+LBBNN_HIDDEN int launch_flow_planar(const FlowArgs* a, int n, hipStream_t s);
+LBBNN_HIDDEN int launch_kl_finalize(const FinalizeArgs* a, int n, hipStream_t s);
+
+}  // namespace lbbnn

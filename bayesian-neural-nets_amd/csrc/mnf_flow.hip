@@ -1,30 +1,25 @@
-// K3 / K5 and small utilities of the MNF layer (gfx950).
+// K3 / K5 and small utilities of the MNF layer (gfx950).  All kernels are batched over layers
+// (blockIdx.y / blockIdx.x selects the layer) so a network forward needs one launch per kind.
 //
-// K3  mnf_flow_planar : z sampling + planar normalizing flows + log_q0, one launch per layer.
+// K3  mnf_flow_planar : z sampling + planar normalizing flows + log_q0.
 //     Work is O(T*I) (a few KB): launch/latency bound, so everything a layer needs from the flows
-//     is done in ONE launch of two independent workgroups (forward multiplier z_k | KL branch z2,
-//     r_flow), each a single 256-thread workgroup with the z vector resident in LDS across all T
-//     transforms (no HBM round trip between transforms; the reference issues ~10 aten kernels per
-//     transform).  Dot products use fixed-order wave butterflies => deterministic.
+//     is done in ONE launch of two independent workgroups per layer (forward multiplier z_k | KL
+//     branch z2 + r_flow), each a single 256-thread workgroup.  Fast path: every parameter element a
+//     thread needs is loaded into registers before the first reduction (one HBM/L2 latency for the
+//     whole kernel); generic path: z resident in LDS.  Dot products use fixed-order wave butterflies
+//     => deterministic.
 // K5  kl_finalize     : O(O+I) tail of the KL: kl_bias, tanh/mean of the auxiliary activations,
-//     log_rb, and the final scalar (optionally accumulated into the network KL).
+//     log_rb, and the final scalar.
 #include "lbbnn_device.h"
-#include "../../include/lbbnn.h"
+#include "lbbnn_internal.h"
 
 namespace {
 
 using namespace lbbnn;
 
-struct PlanarSet { const float* u[LBBNN_MAX_FLOW_T]; const float* w[LBBNN_MAX_FLOW_T]; const float* b[LBBNN_MAX_FLOW_T]; int T; };
-
-struct FlowArgs {
-    const float* q0_mean; const float* q0_log_var;
-    const float* eps_fwd; const float* eps_kl;
-    const uint64_t* rng;
-    float* z_fwd; float* z_kl; float* scal;
-    PlanarSet zf, rf;
-    int I; int want_kl; uint32_t layer;
-};
+typedef lbbnn_planar_flow_t PlanarSet;
+struct FlowBatch { FlowArgs l[LBBNN_MAX_LAYERS]; };
+struct FinalizeBatch { FinalizeArgs l[LBBNN_MAX_LAYERS]; };
 
 // Apply the T planar transforms of `ps` to the LDS-resident z (flows2.py:86-95); returns sum of log-dets.
 __device__ __forceinline__ float planar_apply(const PlanarSet& ps, float* z, int I, double* scratch) {
@@ -50,7 +45,9 @@ __device__ __forceinline__ float planar_apply(const PlanarSet& ps, float* z, int
     return logdet;
 }
 
-__global__ __launch_bounds__(256) void mnf_flow_planar_kernel(const FlowArgs a) {
+__global__ __launch_bounds__(256) void mnf_flow_planar_kernel(const FlowBatch bt) {
+    const FlowArgs& a = bt.l[blockIdx.y];
+    if (blockIdx.x == 1 && !a.want_kl) return;
     extern __shared__ __attribute__((aligned(16))) float z[];
     __shared__ double scratch[4];
     const bool klblk = blockIdx.x == 1;
@@ -132,7 +129,9 @@ __device__ __forceinline__ float planar_apply_reg(const float (&u)[FT][KMAX], co
 }
 
 template <int KMAX>
-__global__ __launch_bounds__(256) void mnf_flow_planar_fast_kernel(const FlowArgs a) {
+__global__ __launch_bounds__(256) void mnf_flow_planar_fast_kernel(const FlowBatch bt) {
+    const FlowArgs& a = bt.l[blockIdx.y];
+    if (blockIdx.x == 1 && !a.want_kl) return;
     __shared__ double scratch[8];
     const bool klblk = blockIdx.x == 1;
     const float* eps = klblk ? a.eps_kl : a.eps_fwd;
@@ -207,17 +206,8 @@ __global__ __launch_bounds__(256) void mnf_flow_planar_fast_kernel(const FlowArg
 }
 
 // -------------------------------------------------------------------------------------------- K5
-struct FinalizeArgs {
-    const float* kl_rows; const float* bias_mu; const float* bias_rho;
-    const float* act_mu; const float* act_var; const float* eps_act;
-    const float* r0_b1; const float* r0_b2; const float* scal;
-    const uint64_t* rng;
-    float* kl_out; float* kl_layer;
-    int O, I, accum; uint32_t layer;
-    float bias_mu_prior, bias_sigma_prior;
-};
-
-__global__ __launch_bounds__(256) void kl_finalize_kernel(const FinalizeArgs a) {
+__global__ __launch_bounds__(256) void kl_finalize_kernel(const FinalizeBatch bt) {
+    const FinalizeArgs& a = bt.l[blockIdx.x];
     __shared__ double scratch[4];
     const bool mnf = a.scal != nullptr;
     uint64_t seed = 0, offs = 0;
@@ -264,6 +254,16 @@ __global__ __launch_bounds__(256) void kl_finalize_kernel(const FinalizeArgs a) 
 // -------------------------------------------------------------------------------------------- utilities
 __global__ void rng_advance_kernel(uint64_t* rng, uint64_t delta) { rng[1] += delta; }
 
+struct FinishArgs { const float* kl[LBBNN_MAX_LAYERS]; int n; float* total; uint64_t* rng; uint64_t delta; };
+__global__ void forward_finish_kernel(const FinishArgs a) {
+    if (a.total) {
+        float s = 0.f;
+        for (int i = 0; i < a.n; ++i) s += *a.kl[i];          // fixed order: l1 + l2 + l3
+        *a.total = s;
+    }
+    if (a.rng) a.rng[1] += a.delta;
+}
+
 __global__ __launch_bounds__(256) void philox_normal_kernel(const uint64_t* rng, uint32_t stream, long long row_base,
                                                             long long rows, long long cols, float* out) {
     // one counter (4 normals) per thread.  2-D (rows > 0): out[r][c] = N(ctr0 = row_base + r, ctr1 = c/4)[c%4],
@@ -308,6 +308,35 @@ bool fill_set(PlanarSet& ps, const float* const* u, const float* const* w, const
 
 }  // namespace
 
+namespace lbbnn {
+
+int launch_flow_planar(const FlowArgs* a, int n, hipStream_t s) {
+    FlowBatch bt;
+    int maxI = 0; bool small_t = true, any_kl = false;
+    for (int i = 0; i < n; ++i) {
+        bt.l[i] = a[i];
+        maxI = a[i].I > maxI ? a[i].I : maxI;
+        small_t = small_t && a[i].zf.T <= FT && (!a[i].want_kl || a[i].rf.T <= FT);
+        any_kl = any_kl || a[i].want_kl;
+    }
+    const dim3 grid(any_kl ? 2 : 1, n), block(256);
+    if (small_t && maxI <= 256 * 2)      hipLaunchKernelGGL(mnf_flow_planar_fast_kernel<2>, grid, block, 0, s, bt);
+    else if (small_t && maxI <= 256 * 5) hipLaunchKernelGGL(mnf_flow_planar_fast_kernel<5>, grid, block, 0, s, bt);
+    else hipLaunchKernelGGL(mnf_flow_planar_kernel, grid, block, (size_t)maxI * sizeof(float), s, bt);
+    return (int)hipGetLastError();
+}
+
+int launch_kl_finalize(const FinalizeArgs* a, int n, hipStream_t s) {
+    FinalizeBatch bt;
+    for (int i = 0; i < n; ++i) bt.l[i] = a[i];
+    hipLaunchKernelGGL(kl_finalize_kernel, dim3(n), dim3(256), 0, s, bt);
+    return (int)hipGetLastError();
+}
+
+}  // namespace lbbnn
+
+using namespace lbbnn;
+
 extern "C" int lbbnn_mnf_flow_planar(const float* q0_mean, const float* q0_log_var,
                                      const float* const* zu, const float* const* zw, const float* const* zb, int Tz,
                                      const float* const* ru, const float* const* rw, const float* const* rb, int Tr,
@@ -324,13 +353,7 @@ extern "C" int lbbnn_mnf_flow_planar(const float* q0_mean, const float* q0_log_v
     a.z_fwd = z_fwd; a.z_kl = z_kl; a.scal = scal; a.I = I; a.want_kl = want_kl; a.layer = layer_id & 63u;
     if (!fill_set(a.zf, zu, zw, zb, Tz)) return LBBNN_E_NULL;
     if (!fill_set(a.rf, ru, rw, rb, want_kl ? Tr : 0)) return LBBNN_E_NULL;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const dim3 grid(want_kl ? 2 : 1), block(256);
-    const bool small_t = Tz <= FT && (!want_kl || Tr <= FT);
-    if (small_t && I <= 256 * 2)      hipLaunchKernelGGL(mnf_flow_planar_fast_kernel<2>, grid, block, 0, s, a);
-    else if (small_t && I <= 256 * 5) hipLaunchKernelGGL(mnf_flow_planar_fast_kernel<5>, grid, block, 0, s, a);
-    else hipLaunchKernelGGL(mnf_flow_planar_kernel, grid, block, (size_t)I * sizeof(float), s, a);
-    return (int)hipGetLastError();
+    return launch_flow_planar(&a, 1, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int lbbnn_kl_finalize(const float* kl_rows, const float* bias_mu, const float* bias_rho, int O,
@@ -351,7 +374,18 @@ extern "C" int lbbnn_kl_finalize(const float* kl_rows, const float* bias_mu, con
     a.eps_act = eps_act; a.r0_b1 = r0_b1; a.r0_b2 = r0_b2; a.scal = scal; a.rng = rng;
     a.kl_out = kl_out; a.kl_layer = kl_layer; a.O = O; a.I = I; a.accum = kl_accum; a.layer = layer_id & 63u;
     a.bias_mu_prior = priors->bias_mu_prior; a.bias_sigma_prior = priors->bias_sigma_prior;
-    hipLaunchKernelGGL(kl_finalize_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return launch_kl_finalize(&a, 1, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int lbbnn_forward_finish(uint64_t* rng, uint64_t advance, const float* const* kl_layers, int n,
+                                    float* kl_total, void* stream) {
+    if (!rng && !kl_total) return LBBNN_E_NULL;
+    if (kl_total && (n <= 0 || n > LBBNN_MAX_LAYERS || !kl_layers)) return LBBNN_E_SHAPE;
+    FinishArgs a;
+    a.n = kl_total ? n : 0; a.total = kl_total; a.rng = rng; a.delta = advance;
+    for (int i = 0; i < LBBNN_MAX_LAYERS; ++i) a.kl[i] = (kl_total && i < n) ? kl_layers[i] : nullptr;
+    for (int i = 0; i < a.n; ++i) if (!a.kl[i]) return LBBNN_E_NULL;
+    hipLaunchKernelGGL(forward_finish_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), a);
     return (int)hipGetLastError();
 }
 

@@ -1,0 +1,58 @@
+// lbbnn_layers_prepare -- the x-independent part of a network forward for all layers in three
+// launches on one stream: K3 (flows of every MNF layer), K1 (one grid over the rows of every
+// layer), K5 (KL finalize of every layer).  See include/lbbnn.h.
+#include "lbbnn_internal.h"
+
+using namespace lbbnn;
+
+extern "C" int lbbnn_layers_prepare(const lbbnn_layer_desc_t* L, int n, const uint64_t* rng, void* stream) {
+    if (!L) return LBBNN_E_NULL;
+    if (n <= 0 || n > LBBNN_MAX_LAYERS) return LBBNN_E_SHAPE;
+    FlowArgs fa[LBBNN_MAX_LAYERS];
+    WeightPassArgs wa[LBBNN_MAX_LAYERS];
+    FinalizeArgs ka[LBBNN_MAX_LAYERS];
+    int nf = 0, nk = 0;
+    for (int i = 0; i < n; ++i) {
+        const lbbnn_layer_desc_t& d = L[i];
+        const bool mnf = d.q0_mean != nullptr;
+        if (!d.weight_mu || !d.weight_rho || !d.lambdal || !d.bias_mu || !d.bias_rho || !d.e_w || !d.bias_var) return LBBNN_E_NULL;
+        if (d.stochastic && !d.var_w) return LBBNN_E_NULL;
+        if (d.want_kl && (!d.kl_rows || !d.kl_layer)) return LBBNN_E_NULL;
+        if (mnf) {
+            if (!d.q0_log_var || !d.z_fwd) return LBBNN_E_NULL;
+            if (d.I > LBBNN_MAX_FLOW_DIM || d.z_flow.T < 0 || d.z_flow.T > LBBNN_MAX_FLOW_T ||
+                d.r_flow.T < 0 || d.r_flow.T > LBBNN_MAX_FLOW_T) return LBBNN_E_SHAPE;
+            if (d.want_kl && (!d.z_kl || !d.scal || !d.r0_c || !d.r0_b1 || !d.r0_b2 || !d.act_mu || !d.act_var)) return LBBNN_E_NULL;
+            if ((!d.eps_z || (d.want_kl && (!d.eps_z2 || !d.eps_act))) && !rng) return LBBNN_E_NOISE;
+            FlowArgs& f = fa[nf++];
+            f.q0_mean = d.q0_mean; f.q0_log_var = d.q0_log_var; f.eps_fwd = d.eps_z; f.eps_kl = d.eps_z2; f.rng = rng;
+            f.z_fwd = d.z_fwd; f.z_kl = d.z_kl; f.scal = d.scal; f.zf = d.z_flow; f.rf = d.r_flow;
+            if (!d.want_kl) f.rf.T = 0;
+            for (int t = 0; t < f.zf.T; ++t) if (!f.zf.u[t] || !f.zf.w[t] || !f.zf.b[t]) return LBBNN_E_NULL;
+            for (int t = 0; t < f.rf.T; ++t) if (!f.rf.u[t] || !f.rf.w[t] || !f.rf.b[t]) return LBBNN_E_NULL;
+            f.I = d.I; f.want_kl = d.want_kl; f.layer = d.layer_id & 63u;
+        }
+        const int rc = make_weight_pass_args(wa[i], d.weight_mu, d.weight_rho, d.lambdal,
+                                             mnf ? d.z_fwd : nullptr, (mnf && d.want_kl) ? d.z_kl : nullptr,
+                                             (mnf && d.want_kl) ? d.r0_c : nullptr, d.bias_rho, &d.priors,
+                                             d.e_w, d.stochastic ? d.var_w : nullptr, lbbnn_operand_ld(d.I),
+                                             d.want_kl ? d.kl_rows : nullptr,
+                                             (mnf && d.want_kl) ? d.act_mu : nullptr, (mnf && d.want_kl) ? d.act_var : nullptr,
+                                             d.bias_var, d.O, d.I);
+        if (rc) return rc;
+        if (d.want_kl) {
+            FinalizeArgs& k = ka[nk++];
+            k.kl_rows = d.kl_rows; k.bias_mu = d.bias_mu; k.bias_rho = d.bias_rho;
+            k.act_mu = mnf ? d.act_mu : nullptr; k.act_var = mnf ? d.act_var : nullptr; k.eps_act = d.eps_act;
+            k.r0_b1 = d.r0_b1; k.r0_b2 = d.r0_b2; k.scal = mnf ? d.scal : nullptr; k.rng = rng;
+            k.kl_out = nullptr; k.kl_layer = d.kl_layer; k.O = d.O; k.I = d.I; k.accum = 0; k.layer = d.layer_id & 63u;
+            k.bias_mu_prior = d.priors.bias_mu_prior; k.bias_sigma_prior = d.priors.bias_sigma_prior;
+        }
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc = 0;
+    if (nf) { rc = launch_flow_planar(fa, nf, s); if (rc) return rc; }
+    rc = launch_weight_pass(wa, n, s); if (rc) return rc;
+    if (nk) { rc = launch_kl_finalize(ka, nk, s); if (rc) return rc; }
+    return 0;
+}

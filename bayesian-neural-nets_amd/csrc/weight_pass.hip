@@ -10,20 +10,13 @@
 // t, t+256, ... so a wave reads 1 KiB contiguous per instruction.  Row sums use a fixed-order
 // wave butterfly + LDS, so kl_rows / act_* are bitwise reproducible.
 #include "lbbnn_device.h"
-#include "../../include/lbbnn.h"
+#include "lbbnn_internal.h"
 
 namespace {
 
 using namespace lbbnn;
 
-struct WeightPassArgs {
-    const float* mu; const float* rho; const float* lambdal;
-    const float* z_fwd; const float* z_kl; const float* r0_c; const float* bias_rho;
-    float* e_w; float* var_w;
-    float* kl_rows; float* act_mu; float* act_var; float* bias_var;
-    int O, I, ld;
-    float mu_prior, sigma_prior, alpha_prior;
-};
+struct WeightPassBatch { WeightPassArgs l[LBBNN_MAX_LAYERS]; int row_end[LBBNN_MAX_LAYERS]; int n; };
 
 struct Elem { float ew, vw, kl, amu, avar; };
 
@@ -52,10 +45,15 @@ __device__ __forceinline__ Elem weight_elem(float mu, float rho, float lam, floa
     return e;
 }
 
-template <bool VEC>
-__global__ __launch_bounds__(256) void weight_pass_kernel(const WeightPassArgs a) {
+// grid.x = total rows of all layers in the batch; a block finds its layer by the row prefix ends.
+__global__ __launch_bounds__(256) void weight_pass_kernel(const WeightPassBatch bt) {
     __shared__ float red[3][4];
-    const int o = blockIdx.x;
+    int li = 0;
+#pragma unroll
+    for (int t = 0; t < LBBNN_MAX_LAYERS - 1; ++t) if (t + 1 < bt.n && (int)blockIdx.x >= bt.row_end[t]) li = t + 1;
+    const WeightPassArgs& a = bt.l[li];
+    const int o = (int)blockIdx.x - (li ? bt.row_end[li - 1] : 0);
+    const bool VEC = a.vec != 0;
     const int tid = threadIdx.x;
     const size_t rowoff = (size_t)o * a.I;
     const bool want_kl = a.kl_rows != nullptr;
@@ -124,6 +122,42 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
+namespace lbbnn {
+
+int make_weight_pass_args(WeightPassArgs& a, const float* mu, const float* rho, const float* lambdal,
+                          const float* z_fwd, const float* z_kl, const float* r0_c, const float* bias_rho,
+                          const lbbnn_priors_t* priors, void* e_w, void* var_w, int ld,
+                          float* kl_rows, float* act_mu, float* act_var, float* bias_var, int O, int I) {
+    if (!mu || !rho || !lambdal || !priors) return LBBNN_E_NULL;
+    if (O <= 0 || I <= 0) return LBBNN_E_SHAPE;
+    if ((e_w || var_w) && (ld < I || (ld & 31))) return LBBNN_E_ALIGN;
+    if ((act_mu == nullptr) != (act_var == nullptr)) return LBBNN_E_NULL;
+    if (act_mu && (!z_kl || !r0_c)) return LBBNN_E_NULL;
+    if (bias_var && !bias_rho) return LBBNN_E_NULL;
+    if ((e_w && !aligned16(e_w)) || (var_w && !aligned16(var_w))) return LBBNN_E_ALIGN;
+    a.mu = mu; a.rho = rho; a.lambdal = lambdal; a.z_fwd = z_fwd; a.z_kl = z_kl; a.r0_c = r0_c;
+    a.bias_rho = bias_rho;
+    a.e_w = static_cast<float*>(e_w); a.var_w = static_cast<float*>(var_w);
+    a.kl_rows = kl_rows; a.act_mu = act_mu; a.act_var = act_var; a.bias_var = bias_var;
+    a.O = O; a.I = I; a.ld = (e_w || var_w) ? ld : lbbnn_operand_ld(I);
+    a.mu_prior = priors->mu_prior; a.sigma_prior = priors->sigma_prior; a.alpha_prior = priors->alpha_prior;
+    a.vec = ((I % 4 == 0) && aligned16(mu) && aligned16(rho) && aligned16(lambdal) &&
+             (!z_fwd || aligned16(z_fwd)) && (!z_kl || aligned16(z_kl)) && (!r0_c || aligned16(r0_c))) ? 1 : 0;
+    return 0;
+}
+
+int launch_weight_pass(const WeightPassArgs* a, int n, hipStream_t s) {
+    WeightPassBatch bt;
+    int rows = 0;
+    for (int i = 0; i < n; ++i) { bt.l[i] = a[i]; rows += a[i].O; bt.row_end[i] = rows; }
+    for (int i = n; i < LBBNN_MAX_LAYERS; ++i) bt.row_end[i] = rows;
+    bt.n = n;
+    hipLaunchKernelGGL(weight_pass_kernel, dim3(rows), dim3(256), 0, s, bt);
+    return (int)hipGetLastError();
+}
+
+}  // namespace lbbnn
+
 extern "C" int lbbnn_operand_ld(int I) { return I <= 0 ? 0 : ((I + 31) / 32) * 32; }
 
 extern "C" int lbbnn_weight_pass(const float* mu, const float* rho, const float* lambdal,
@@ -132,28 +166,11 @@ extern "C" int lbbnn_weight_pass(const float* mu, const float* rho, const float*
                                  void* e_w, void* var_w, int ld,
                                  float* kl_rows, float* act_mu, float* act_var, float* bias_var,
                                  int O, int I, int flags, void* stream) {
-    if (!mu || !rho || !lambdal || !priors) return LBBNN_E_NULL;
-    if (O <= 0 || I <= 0) return LBBNN_E_SHAPE;
     if (flags & ~LBBNN_F_SPLIT16) return LBBNN_E_FLAGS;
     if (flags & LBBNN_F_SPLIT16) return LBBNN_E_FLAGS;   // split-precision operands: not in this build
-    if ((e_w || var_w) && (ld < I || (ld & 31))) return LBBNN_E_ALIGN;
-    if ((act_mu == nullptr) != (act_var == nullptr)) return LBBNN_E_NULL;
-    if (act_mu && (!z_kl || !r0_c)) return LBBNN_E_NULL;
-    if (bias_var && !bias_rho) return LBBNN_E_NULL;
-    if ((e_w && !aligned16(e_w)) || (var_w && !aligned16(var_w))) return LBBNN_E_ALIGN;
-
-    WeightPassArgs a;
-    a.mu = mu; a.rho = rho; a.lambdal = lambdal; a.z_fwd = z_fwd; a.z_kl = z_kl; a.r0_c = r0_c;
-    a.bias_rho = bias_rho;
-    a.e_w = static_cast<float*>(e_w); a.var_w = static_cast<float*>(var_w);
-    a.kl_rows = kl_rows; a.act_mu = act_mu; a.act_var = act_var; a.bias_var = bias_var;
-    a.O = O; a.I = I; a.ld = (e_w || var_w) ? ld : lbbnn_operand_ld(I);
-    a.mu_prior = priors->mu_prior; a.sigma_prior = priors->sigma_prior; a.alpha_prior = priors->alpha_prior;
-
-    const bool vec = (I % 4 == 0) && aligned16(mu) && aligned16(rho) && aligned16(lambdal) &&
-                     (!z_fwd || aligned16(z_fwd)) && (!z_kl || aligned16(z_kl)) && (!r0_c || aligned16(r0_c));
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (vec) hipLaunchKernelGGL(weight_pass_kernel<true>, dim3(O), dim3(256), 0, s, a);
-    else     hipLaunchKernelGGL(weight_pass_kernel<false>, dim3(O), dim3(256), 0, s, a);
-    return (int)hipGetLastError();
+    lbbnn::WeightPassArgs a;
+    const int rc = lbbnn::make_weight_pass_args(a, mu, rho, lambdal, z_fwd, z_kl, r0_c, bias_rho, priors, e_w, var_w, ld,
+                                                kl_rows, act_mu, act_var, bias_var, O, I);
+    if (rc) return rc;
+    return lbbnn::launch_weight_pass(&a, 1, static_cast<hipStream_t>(stream));
 }

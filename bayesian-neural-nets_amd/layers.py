@@ -18,6 +18,7 @@ r_flow_type=`` (module globals in the reference, LBBNN-GP-MF-MNF.py:46-47), and 
 There is no CPU path: parameters may be *constructed* on CPU (as the reference does) but
 ``forward`` needs them on a HIP device.
 """
+import ctypes
 import itertools
 from typing import Dict, Optional
 
@@ -119,6 +120,21 @@ class _BayesLinearBase(nn.Module):
 
     def _param_list(self):
         raise NotImplementedError
+
+    def _fill_desc(self, d, cfg, kl_layer):
+        """Fill one lbbnn_layer_desc_t for lbbnn_layers_prepare (pointers into parameters / workspace)."""
+        ws = self._workspace()
+        noise = self.noise or {}
+        d.weight_mu, d.weight_rho, d.lambdal = self.weight_mu.data_ptr(), self.weight_rho.data_ptr(), self.lambdal.data_ptr()
+        d.bias_mu, d.bias_rho = self.bias_mu.data_ptr(), self.bias_rho.data_ptr()
+        d.priors = self.priors
+        d.O, d.I, d.layer_id = self.out_features, self.in_features, self._layer_id
+        d.stochastic, d.want_kl = int(cfg[0]), int(cfg[1])
+        d.e_w, d.var_w = ws.e_w.data_ptr(), ws.var_w.data_ptr()
+        d.kl_rows, d.bias_var = ws.kl_rows.data_ptr(), ws.bias_var.data_ptr()
+        d.kl_layer = kl_layer.data_ptr() if kl_layer is not None else None
+        d.q0_mean = None
+        return ws, noise
 
     def _forward_hip(self, x, cfg, advance=True, save_rng=False):
         """One layer, sequentially on the current stream: prep kernels, GEMM, RNG advance.
@@ -247,6 +263,32 @@ class MNFBayesianLinear(_BayesLinearBase):
     def _needed_noise(self, cfg):
         return ["eps_z"] + (["eps_out"] if cfg[0] else []) + (["eps_z2", "eps_act"] if cfg[1] else [])
 
+    def _fill_desc(self, d, cfg, kl_layer):
+        self._check_flows()
+        ws, noise = super()._fill_desc(d, cfg, kl_layer)
+        for name in ("q0_mean", "q0_log_var", "r0_c", "r0_b1", "r0_b2"):
+            setattr(d, name, getattr(self, name).data_ptr())
+        for fd, flow in ((d.z_flow, self.z_flow), (d.r_flow, self.r_flow)):
+            fd.T = len(flow.transforms)
+            for t, tr in enumerate(flow.transforms):
+                fd.u[t], fd.w[t], fd.b[t] = tr.u.data_ptr(), tr.w.data_ptr(), tr.bias.data_ptr()
+        keep = []                                   # keep reshaped noise views alive until the launch
+        eps_z = noise.get("eps_z")
+        if eps_z is not None:
+            eps_z = (eps_z[-1] if eps_z.dim() == 2 else eps_z).contiguous()
+            keep.append(eps_z)
+        eps_z2 = noise.get("eps_z2")
+        if eps_z2 is not None:
+            eps_z2 = eps_z2.reshape(-1).contiguous()
+            keep.append(eps_z2)
+        eps_act = noise.get("eps_act")
+        d.eps_z = eps_z.data_ptr() if eps_z is not None else None
+        d.eps_z2 = eps_z2.data_ptr() if eps_z2 is not None else None
+        d.eps_act = eps_act.data_ptr() if eps_act is not None else None
+        d.z_fwd, d.z_kl, d.scal = ws.z_fwd.data_ptr(), ws.z_kl.data_ptr(), ws.scal.data_ptr()
+        d.act_mu, d.act_var = ws.act_mu.data_ptr(), ws.act_var.data_ptr()
+        return keep
+
     def _uses_rng(self, cfg):
         noise = self.noise or {}
         need = self._needed_noise(cfg)
@@ -352,43 +394,45 @@ class _NetworkBase(nn.Module):
         return self._forward_streams(x.float(), sample)
 
     def _forward_streams(self, x, sample):
+        """Fused no-grad forward: ONE stream, 3 + 3 + 1 launches.
+
+        lbbnn_layers_prepare runs the x-independent kernels of all layers (flows, weight pass, KL
+        finalize: one launch per kind), then the three GEMMs run back to back (ReLU / log_softmax in
+        their epilogues), then lbbnn_forward_finish sums the layer KLs and advances the RNG offset.
+        (A two-stream schedule was measured first: every cross-stream dependency cost 13-15 us on
+        the critical path and the side-stream kernels were starved by the GEMM -- see DESIGN.md.)
+        """
+        from . import _lib
         layers = self._layers()
         dev = x.device
-        cfgs = [(bool(l.training or sample), bool(l.training), i < 2) for i, l in enumerate(layers)]
+        n = len(layers)
+        cfgs = [(bool(l.training or sample), bool(l.training), i < n - 1) for i, l in enumerate(layers)]
         st = None
         if any(l._uses_rng(c) for l, c in zip(layers, cfgs)):
             st = ops.RngState.get(dev)
         rng = st.t if st is not None else None
-        main = torch.cuda.current_stream(dev)
-        if getattr(self, "_side", None) is None or self._side.device != dev:
-            self._side = torch.cuda.Stream(device=dev)
-            self._events = [torch.cuda.Event() for _ in layers]
-        side = self._side
         want_kl = any(c[1] for c in cfgs)
-        kls = [torch.empty((), dtype=torch.float32, device=dev) if c[1] else None for c in cfgs]
-        total = torch.empty((), dtype=torch.float32, device=dev) if want_kl else None
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            for l, c, ev in zip(layers, cfgs, self._events):
-                l._prep(c, rng, finalize=False)                 # K5 deferred: keeps it off the critical path
-                ev.record(side)
-            first = True
-            for l, c, k in zip(layers, cfgs, kls):
-                if not c[1]:
-                    continue
-                l._finalize(rng, kl_layer=k, kl_total=total, accumulate=not first)
-                first = False
-        for i, (l, c, ev) in enumerate(zip(layers, cfgs, self._events)):
-            main.wait_event(ev)
-            x = l._gemm(x, c, rng, log_softmax=(i == len(layers) - 1 and l.out_features <= 16))
+        kls = torch.empty(n + 1, dtype=torch.float32, device=dev) if want_kl else None
+        descs = (_lib.LayerDesc * n)()
+        keep = []
+        for i, (l, c) in enumerate(zip(layers, cfgs)):
+            keep.append(l._fill_desc(descs[i], c, kls[i] if c[1] else None))
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(_lib.lib().lbbnn_layers_prepare(descs, n, rng.data_ptr() if rng is not None else None, stream),
+                   "lbbnn_layers_prepare")
+        for i, (l, c) in enumerate(zip(layers, cfgs)):
+            x = l._gemm(x, c, rng, log_softmax=(i == n - 1 and l.out_features <= 16))
         if layers[-1].out_features > 16:
             x = F.log_softmax(x, dim=1)
-        main.wait_stream(side)
-        if st is not None:
-            st.advance(1)
-        for l, c, k in zip(layers, cfgs, kls):
-            l.kl = k if c[1] else 0
-        self._kl_total = total
+        if want_kl or st is not None:
+            ptrs = (ctypes.c_void_p * n)(*[kls[i].data_ptr() if (want_kl and cfgs[i][1]) else None for i in range(n)])
+            all_kl = want_kl and all(c[1] for c in cfgs)
+            _lib.check(_lib.lib().lbbnn_forward_finish(rng.data_ptr() if st is not None else None, 1, ptrs, n,
+                                                       kls[n:].data_ptr() if all_kl else None, stream),
+                       "lbbnn_forward_finish")
+        for i, (l, c) in enumerate(zip(layers, cfgs)):
+            l.kl = kls[i] if c[1] else 0
+        self._kl_total = kls[n] if (want_kl and all(c[1] for c in cfgs)) else None
         return x
 
     def kl(self):

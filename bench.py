@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-baseline sample")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-kernel HIP-event timing")
+    ap.add_argument("--graph", action="store_true", help="capture one step in a HIP graph and replay it")
     return ap.parse_args()
 
 
@@ -144,13 +145,26 @@ def main():
         for _ in range(args.warmup):
             step()
         sync()
-        if not args.no_kernel_events:
-            ops.GEMM_EVENTS = []
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out, kl = step()
-        sync()
-        elapsed = time.perf_counter() - t0
+        if args.graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out, kl = step()
+            for _ in range(3):
+                graph.replay()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                graph.replay()
+            sync()
+            elapsed = time.perf_counter() - t0
+        else:
+            if not args.no_kernel_events:
+                ops.GEMM_EVENTS = []
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                out, kl = step()
+            sync()
+            elapsed = time.perf_counter() - t0
     events, ops.GEMM_EVENTS = ops.GEMM_EVENTS, None
     assert torch.isfinite(out).all() and torch.isfinite(kl)
 
@@ -167,7 +181,7 @@ def main():
             "value": total / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic", "hip_graph": bool(args.graph),
             "config": {"workload": "LBBNN-GP-MF-MNF 784-1200-1200-10, 2 planar flows/layer, batch %d per GPU, "
                                    "training-mode ELBO forward (activations + log_softmax + kl), in-kernel Philox noise" % B,
                        "global_batch": B * world, "parallelism": "dp%d (replicated parameters, no forward collective)" % world},

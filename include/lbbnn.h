@@ -155,6 +155,49 @@ int lbbnn_kl_finalize(const float* kl_rows, const float* bias_mu, const float* b
                       const uint64_t* rng, uint32_t layer_id,
                       float* kl_out, float* kl_layer, int kl_accum, void* stream);
 
+
+/* ---------------------------------------------------------------------------------------------
+ * Batched "prepare": everything in a network forward that does NOT depend on the activations
+ * (K3 flows, K1 weight pass, K5 KL finalize) for up to LBBNN_MAX_LAYERS layers in three launches
+ * on one stream -- one launch per kernel kind covering all layers -- so the critical path of
+ * BayesianNetwork.forward (LBBNN-GP-MF-MNF.py:252-257) is  prepare -> GEMM1 -> GEMM2 -> GEMM3.
+ * Field meaning = the arguments of the single-layer entry points above.
+ */
+#define LBBNN_MAX_LAYERS 4
+
+typedef struct lbbnn_planar_flow {
+    const float* u[LBBNN_MAX_FLOW_T];
+    const float* w[LBBNN_MAX_FLOW_T];
+    const float* b[LBBNN_MAX_FLOW_T];
+    int T;
+} lbbnn_planar_flow_t;
+
+typedef struct lbbnn_layer_desc {
+    /* parameters (state_dict names of the reference) */
+    const float *weight_mu, *weight_rho, *lambdal, *bias_mu, *bias_rho;
+    const float *q0_mean, *q0_log_var, *r0_c, *r0_b1, *r0_b2;      /* all NULL for an LRT layer */
+    lbbnn_planar_flow_t z_flow, r_flow;
+    lbbnn_priors_t priors;
+    int O, I;
+    uint32_t layer_id;
+    int stochastic;          /* produce var_w (training or sample)            */
+    int want_kl;             /* training or calculate_log_probs               */
+    /* explicit draws; NULL => Philox from rng */
+    const float *eps_z, *eps_z2, *eps_act;
+    /* caller-owned workspace */
+    float *z_fwd, *z_kl, *scal;                  /* (I), (I), 8 floats; MNF only */
+    void *e_w, *var_w;                           /* [O][lbbnn_operand_ld(I)]     */
+    float *kl_rows, *act_mu, *act_var, *bias_var;/* (O) each                     */
+    float* kl_layer;                             /* 1 float: this layer's KL     */
+} lbbnn_layer_desc_t;
+
+int lbbnn_layers_prepare(const lbbnn_layer_desc_t* layers, int n, const uint64_t* rng, void* stream);
+
+/* End of a network forward: *kl_total = sum_l *kl_layers[l] (fixed order; BayesianNetwork.kl(),
+ * …LRT.py:213-214) and rng[1] += advance, one tiny launch.  kl_total may be NULL (n ignored). */
+int lbbnn_forward_finish(uint64_t* rng, uint64_t advance, const float* const* kl_layers, int n,
+                         float* kl_total, void* stream);
+
 /* rng[1] += delta (device side, so graph replays draw fresh noise). */
 int lbbnn_rng_advance(uint64_t* rng, uint64_t delta, void* stream);
 
