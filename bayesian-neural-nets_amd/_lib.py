@@ -42,7 +42,7 @@ class LayerDesc(ctypes.Structure):
     _fields_ = [("weight_mu", c_p), ("weight_rho", c_p), ("lambdal", c_p), ("bias_mu", c_p), ("bias_rho", c_p),
                 ("q0_mean", c_p), ("q0_log_var", c_p), ("r0_c", c_p), ("r0_b1", c_p), ("r0_b2", c_p),
                 ("z_flow", PlanarFlow), ("r_flow", PlanarFlow), ("priors", Priors),
-                ("O", c_i), ("I", c_i), ("layer_id", c_u32), ("stochastic", c_i), ("want_kl", c_i),
+                ("O", c_i), ("I", c_i), ("layer_id", c_u32), ("stochastic", c_i), ("want_kl", c_i), ("split", c_i),
                 ("eps_z", c_p), ("eps_z2", c_p), ("eps_act", c_p),
                 ("z_fwd", c_p), ("z_kl", c_p), ("scal", c_p), ("e_w", c_p), ("var_w", c_p),
                 ("kl_rows", c_p), ("act_mu", c_p), ("act_var", c_p), ("bias_var", c_p), ("kl_layer", c_p)]

@@ -33,6 +33,27 @@ __device__ __forceinline__ T block_sum(T v, T* scratch) {
     return s;
 }
 
+// ------------------------------------------------------------------------------------------ LDS-DMA prefetch
+// Copy n floats global -> LDS with `global_load_lds_dword` (64 floats per wave-instruction, written at
+// wave-uniform base + lane*4).  Fire-and-forget: the caller issues every vector it needs, then waits ONCE
+// (dma_wait_all), so a latency-bound kernel pays a single memory latency for all of its inputs.
+// The LDS vector must be padded to a multiple of 64 floats (tail lanes re-read element n-1).
+__device__ __forceinline__ void dma_stage(float* lds_dst, const float* __restrict__ src, int n) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = blockDim.x >> 6;
+    for (int c = wave; c * 64 < n; c += nw) {
+        const int i = min(c * 64 + lane, n - 1);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i),
+                                         (__attribute__((address_space(3))) void*)(lds_dst + c * 64), 4, 0, 0);
+    }
+}
+__device__ __forceinline__ void dma_wait_all() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+__host__ __device__ __forceinline__ int pad64(int n) { return (n + 63) & ~63; }
+
 // ------------------------------------------------------------------------------------------ elementwise
 // softplus exactly as the reference spells it: log1p(exp(rho)) (LBBNN-GP-MF-LRT.py:81-82).
 __device__ __forceinline__ float softplus_ref(float rho) { return log1pf(expf(rho)); }

@@ -16,7 +16,9 @@ struct WeightPassArgs {
     float* e_w; float* var_w;
     float* kl_rows; float* act_mu; float* act_var; float* bias_var;
     int O, I, ld, vec;
+    int split;      // 1: e_w and var_w are two bf16 planes each, [2][O][ld] (hi, lo); 0: fp32 [O][ld]
     float mu_prior, sigma_prior, alpha_prior;
+    float log_sp, log_ap, log_1map, inv_2sp2;     // host-precomputed prior constants
 };
 
 struct FlowArgs {
@@ -42,7 +44,8 @@ struct FinalizeArgs {
 LBBNN_HIDDEN int make_weight_pass_args(WeightPassArgs& a, const float* mu, const float* rho, const float* lambdal,
                                        const float* z_fwd, const float* z_kl, const float* r0_c, const float* bias_rho,
                                        const lbbnn_priors_t* priors, void* e_w, void* var_w, int ld,
-                                       float* kl_rows, float* act_mu, float* act_var, float* bias_var, int O, int I);
+                                       float* kl_rows, float* act_mu, float* act_var, float* bias_var, int O, int I,
+                                       int split = 0);
 LBBNN_HIDDEN int launch_weight_pass(const WeightPassArgs* a, int n, hipStream_t s);
 LBBNN_HIDDEN int launch_flow_planar(const FlowArgs* a, int n, hipStream_t s);
 LBBNN_HIDDEN int launch_kl_finalize(const FinalizeArgs* a, int n, hipStream_t s);

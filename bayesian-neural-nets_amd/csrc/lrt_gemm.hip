@@ -430,6 +430,196 @@ __global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_f32_dma_kernel(const Gemm
 }
 
 // ------------------------------------------------------------------------------------------------
+// Split-precision variant (LBBNN_F_SPLIT16): the same two GEMMs on v_mfma_f32_16x16x32_bf16 (16 cycles
+// for 32 k, vs 2 x 4 x 32 cycles on the fp32 path = 8x fewer matrix-core cycles) without giving up the
+// 1e-4 contract:
+//   mean = x.e_w^T with x = xh + xl, e_w = wh + wl (bf16 each):  xh.wh + xh.wl + xl.wh   (fp32 accumulate;
+//          the dropped xl.wl term is ~2^-16 relative; measured ~4e-6 relative on the layer output)
+//   var  = x^2 . var_w^T the same way: s = x^2 = sh + sl, v = vh + vl:  sh.vh + sl.vh + sh.vl.  (A single
+//          bf16 product was measured first: its 2^-9 roundings do not average out under the max-norm --
+//          worst element 1.2e-4 at every K -- so the variance gets the 3-term split too; the kernel is
+//          operand-delivery bound, MFMA utilisation ~27 %, so the two extra MFMAs per tile are hidden.)
+// x stays fp32 in HBM and in LDS (the previous layer's output as it is); each lane splits its fragment in
+// registers: xh = bits & 0xFFFF0000 (truncation, so xl = x - xh is exact), xl -> bf16 RNE; same for x^2
+// (v_and, v_sub, v_perm, v_cvt_pk, v_mul: ~56 VALU per 8 values, hidden under the 60 MFMAs of the step).
+// Weight operands come from lbbnn_weight_pass(LBBNN_F_SPLIT16) as bf16 planes [hi | lo] of e_w and of var_w.
+//
+// K step = 32.  LDS image per step: X 128 rows x 128 B (fp32) | Wh, Wl, Vh, Vl 80 rows x 64 B (bf16), all filled
+// by LDS-DMA; conflict-free swizzles on the source side: X slots (16 B) ^ G[row&15],
+// G(r) = ((r>>1)&3)*2 + ((r>>3)&1); W slots ^ F[(row>>2)&3] as in the fp32 kernel.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+constexpr int BKS = 32;
+
+__device__ __forceinline__ int swzx(int r) { return (((r >> 1) & 3) << 1) | ((r >> 3) & 1); }
+
+template <int TO, int TB, int WB, bool MEAN_ONLY>
+__global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_bf16x3_kernel(const GemmArgs a) {
+    constexpr int BN = TO * 16, BM = TB * WB * 16;
+    constexpr int NPL = MEAN_ONLY ? 2 : 4;               // weight planes: e_w hi, lo (, var_w hi, lo)
+    constexpr int XB = BM * 128;                         // bytes of the X region
+    constexpr int PB = BN * 64;                          // bytes of one weight plane region
+    constexpr int BUFB = XB + NPL * PB;                  // bytes per buffer
+    constexpr int NGX = BM / 8, NGW = BN / 16;           // 1-KiB DMA groups: X (8 rows each), per plane (16 rows each)
+    constexpr int NG = NGX + NPL * NGW;
+    constexpr int NPW = (NG + WB - 1) / WB;
+    extern __shared__ __attribute__((aligned(16))) char smc[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, q = lane >> 4;
+    const int o0 = blockIdx.x * BN;
+    const int b0 = blockIdx.y * BM;
+    const char* const eh = reinterpret_cast<const char*>(a.e_w);
+    const char* const el = eh + (size_t)a.O * a.ld * 2;
+    const char* const vh = reinterpret_cast<const char*>(a.var_w);
+    const char* const vl = vh + (size_t)a.O * a.ld * 2;
+    // 16 B of zeros for x lanes past I in the K tail: the zero-filled tail of row 0 of the hi plane
+    const char* const zsrc = eh + (size_t)a.I * 2;
+
+    const char* gp[NPW];      // per-lane source (byte pointer) of DMA group wv + WB*u at K step 0
+    int adv[NPW];             // bytes per K step: 128 (x) or 64 (weights)
+    int kx[NPW];              // first k of this lane's x slot (for the tail redirect), or -1
+#pragma unroll
+    for (int u = 0; u < NPW; ++u) {
+        const int g = wv + WB * u;
+        if (g < NGX) {
+            const int row = 8 * g + (lane >> 3);
+            const int slot = (lane & 7) ^ swzx(row & 15);
+            gp[u] = reinterpret_cast<const char*>(a.x + (size_t)min(b0 + row, a.B - 1) * a.ldx) + 16 * slot;
+            adv[u] = 128; kx[u] = 4 * slot;
+        } else {
+            const int gw = g - NGX, pl = gw / NGW, row = 16 * (gw % NGW) + (lane >> 2);
+            const int slot = (lane & 3) ^ swz(row >> 2);
+            const char* base = pl == 0 ? eh : (pl == 1 ? el : (pl == 2 ? vh : vl));
+            gp[u] = base + ((size_t)min(o0 + row, a.O - 1) * a.ld) * 2 + 16 * slot;
+            adv[u] = 64; kx[u] = -1;
+        }
+    }
+    const int nsteps = (a.I + BKS - 1) / BKS;
+    const bool has_tail = (a.I % BKS) != 0;
+    auto dma_step = [&](int c, char* buf) {
+        const bool tail = has_tail && c == nsteps - 1;
+#pragma unroll
+        for (int u = 0; u < NPW; ++u) {
+            const int g = wv + WB * u;                   // wave-uniform
+            if (g < NG) {
+                const char* src = gp[u] + (size_t)c * adv[u];
+                if (tail && kx[u] >= 0 && c * BKS + kx[u] >= a.I) src = zsrc;
+                const int loff = g < NGX ? g * 1024 : XB + (g - NGX) * 1024;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(buf + loff), 16, 0, 0);
+            }
+        }
+    };
+
+    floatx4 accm[TO][TB], accv[TO][TB];
+#pragma unroll
+    for (int i = 0; i < TO; ++i)
+#pragma unroll
+        for (int j = 0; j < TB; ++j) { accm[i][j] = floatx4{0.f, 0.f, 0.f, 0.f}; accv[i][j] = floatx4{0.f, 0.f, 0.f, 0.f}; }
+
+    // fragment read byte offsets
+    const int gx = swzx(lr);
+    const int xo0 = (wv * TB * 16 + lr) * 128 + 16 * ((2 * q) ^ gx);
+    const int xo1 = (wv * TB * 16 + lr) * 128 + 16 * ((2 * q + 1) ^ gx);
+    const int wo = XB + lr * 64 + 16 * (q ^ swz(lr >> 2));
+
+    float4 xr[TB][2];
+    uint4 wh[TO], wl[TO], wvh[TO], wvl[TO];
+    auto read_frags = [&](const char* cur) {
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            xr[j][0] = *reinterpret_cast<const float4*>(cur + xo0 + j * 16 * 128);
+            xr[j][1] = *reinterpret_cast<const float4*>(cur + xo1 + j * 16 * 128);
+        }
+#pragma unroll
+        for (int i = 0; i < TO; ++i) {
+            wh[i] = *reinterpret_cast<const uint4*>(cur + wo + i * 16 * 64);
+            wl[i] = *reinterpret_cast<const uint4*>(cur + wo + PB + i * 16 * 64);
+            if (!MEAN_ONLY) {
+                wvh[i] = *reinterpret_cast<const uint4*>(cur + wo + 2 * PB + i * 16 * 64);
+                wvl[i] = *reinterpret_cast<const uint4*>(cur + wo + 3 * PB + i * 16 * 64);
+            }
+        }
+    };
+    auto mfmas = [&]() {
+        bf16x8 xh[TB], xl[TB], sh[TB], sl[TB];
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            const float v[8] = {xr[j][0].x, xr[j][0].y, xr[j][0].z, xr[j][0].w, xr[j][1].x, xr[j][1].y, xr[j][1].z, xr[j][1].w};
+            uint32_t ph[4], pl[4], qh[4], ql[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint32_t u0 = __float_as_uint(v[2 * t]), u1 = __float_as_uint(v[2 * t + 1]);
+                ph[t] = __builtin_amdgcn_perm(u1, u0, 0x07060302);                       // {hi16(v1), hi16(v0)}
+                const floatx2 lo = {v[2 * t] - __uint_as_float(u0 & 0xFFFF0000u), v[2 * t + 1] - __uint_as_float(u1 & 0xFFFF0000u)};
+                pl[t] = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2));
+                if (!MEAN_ONLY) {
+                    const float s0 = v[2 * t] * v[2 * t], s1 = v[2 * t + 1] * v[2 * t + 1];
+                    const uint32_t w0 = __float_as_uint(s0), w1 = __float_as_uint(s1);
+                    qh[t] = __builtin_amdgcn_perm(w1, w0, 0x07060302);
+                    const floatx2 slo = {s0 - __uint_as_float(w0 & 0xFFFF0000u), s1 - __uint_as_float(w1 & 0xFFFF0000u)};
+                    ql[t] = __builtin_bit_cast(uint32_t, __builtin_convertvector(slo, bf16x2));
+                }
+            }
+            xh[j] = __builtin_bit_cast(bf16x8, make_uint4(ph[0], ph[1], ph[2], ph[3]));
+            xl[j] = __builtin_bit_cast(bf16x8, make_uint4(pl[0], pl[1], pl[2], pl[3]));
+            if (!MEAN_ONLY) {
+                sh[j] = __builtin_bit_cast(bf16x8, make_uint4(qh[0], qh[1], qh[2], qh[3]));
+                sl[j] = __builtin_bit_cast(bf16x8, make_uint4(ql[0], ql[1], ql[2], ql[3]));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TO; ++i) {
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, wh[i]);
+            const bf16x8 al = __builtin_bit_cast(bf16x8, wl[i]);
+#pragma unroll
+            for (int j = 0; j < TB; ++j) {
+                accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh[j], accm[i][j], 0, 0, 0);
+                accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xh[j], accm[i][j], 0, 0, 0);
+                accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xl[j], accm[i][j], 0, 0, 0);
+                if (!MEAN_ONLY) {
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, wvh[i]);
+                    accv[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, sh[j], accv[i][j], 0, 0, 0);
+                    accv[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wvl[i]), sh[j], accv[i][j], 0, 0, 0);
+                    accv[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, sl[j], accv[i][j], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    dma_step(0, smc);
+    __syncthreads();
+    for (int c = 0; c < nsteps; ++c) {
+        read_frags(smc + (c & 1) * BUFB);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < nsteps) dma_step(c + 1, smc + ((c & 1) ^ 1) * BUFB);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas();
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    }
+
+    const EpiCtx ec = make_epi_ctx<MEAN_ONLY>(a);
+#pragma unroll
+    for (int i = 0; i < TO; ++i) {
+        const int o = o0 + i * 16 + 4 * q;
+        if (o >= a.O) continue;
+        const OConst oc = load_oconst(a, o);
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            const int b = b0 + (wv * TB + j) * 16 + lr;
+            if (b >= a.B) continue;
+            float res[4];
+            epilogue4<MEAN_ONLY>(a, ec, oc, b, o, accm[i][j], accv[i][j], res);
+            store4(a, ec, b, o, res);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Skinny-output variant (O <= 16: the 10-class head).  One 16(o) x 16(b) accumulator pair per wave;
 // the 16 waves of a 1024-thread workgroup split K 16 ways (chunk c -> wave c mod 16), every wave
 // issues ALL its global loads (x fragment straight to registers: the tile is read once, LDS staging
@@ -576,6 +766,24 @@ int launch_cfg(const GemmArgs& a, bool mean_only, bool xvec, hipStream_t s) {
     return launch_one(lrt_gemm_f32_kernel<TO, TB, WB, false, false>, grid, block, lds_full, s, a);
 }
 
+template <int TO, int TB, int WB>
+int launch_split_cfg(const GemmArgs& a, bool mean_only, hipStream_t s) {
+    constexpr int BN = TO * 16, BM = TB * WB * 16;
+    dim3 grid((a.O + BN - 1) / BN, (a.B + BM - 1) / BM);
+    dim3 block(WB * 64);
+    const long nblocks = (long)grid.x * grid.y;
+    const size_t l_full = lds_request(2u * (BM * 128 + 4 * BN * 64), nblocks);
+    const size_t l_mean = lds_request(2u * (BM * 128 + 2 * BN * 64), nblocks);
+    if (mean_only) return launch_one(lrt_gemm_bf16x3_kernel<TO, TB, WB, true>, grid, block, l_mean, s, a);
+    return launch_one(lrt_gemm_bf16x3_kernel<TO, TB, WB, false>, grid, block, l_full, s, a);
+}
+
+int launch_split(const GemmArgs& a, bool mean_only, hipStream_t s) {
+    const long blocks_big = (long)((a.O + 79) / 80) * ((a.B + 127) / 128);
+    if (blocks_big >= 256) return launch_split_cfg<5, 2, 4>(a, mean_only, s);
+    return launch_split_cfg<5, 1, 2>(a, mean_only, s);
+}
+
 }  // namespace
 
 extern "C" int lbbnn_lrt_gemm(const float* x, int ldx, const void* e_w, const void* var_w, int ld,
@@ -586,7 +794,7 @@ extern "C" int lbbnn_lrt_gemm(const float* x, int ldx, const void* e_w, const vo
     if (B <= 0 || I <= 0 || O <= 0 || ldx < I || ldo < O) return LBBNN_E_SHAPE;
     if (flags & ~(LBBNN_F_RELU | LBBNN_F_MEAN_ONLY | LBBNN_F_SPLIT16 | LBBNN_F_LOG_SOFTMAX)) return LBBNN_E_FLAGS;
     if ((flags & LBBNN_F_LOG_SOFTMAX) && (O > 16 || (flags & LBBNN_F_RELU))) return LBBNN_E_FLAGS;
-    if (flags & LBBNN_F_SPLIT16) return LBBNN_E_FLAGS;    // split-precision path: not in this build
+    const bool split = (flags & LBBNN_F_SPLIT16) != 0;
     const bool mean_only = (flags & LBBNN_F_MEAN_ONLY) != 0;
     if (!mean_only && !var_w) return LBBNN_E_NULL;
     if (!mean_only && !eps && !rng) return LBBNN_E_NOISE;
@@ -606,6 +814,12 @@ extern "C" int lbbnn_lrt_gemm(const float* x, int ldx, const void* e_w, const vo
     // Tile choice: 80(o) x 128(b) fills the chip for the headline shapes (B=4096, O=1200 -> 15x32 = 480
     // workgroups, 2 resident per CU); small problems take a 80x32 tile for more workgroups; a skinny
     // output (O <= 16, the 10-class head) takes the split-K kernel above.
+    if (split) {
+        // split-precision operands: aligned x, I % 8 == 0, >= 16 B of zero tail when there is a K tail, O > 16
+        const bool tail = (I % BKS) != 0;
+        if (!xvec || (I & 7) || O <= 16 || (tail && (ld - I) < 8)) return LBBNN_E_ALIGN;
+        return launch_split(a, mean_only, s);
+    }
     if (O <= 16) {
         dim3 grid((B + 15) / 16), block(SK_WAVES * 64);
         if (mean_only) {

@@ -91,14 +91,14 @@ __global__ __launch_bounds__(256) void mnf_flow_planar_kernel(const FlowBatch bt
 }
 
 
-// ---- fast path: I <= 256*KMAX and T <= 4.  Everything one thread needs (its KMAX elements of z, of
-// q0_mean / q0_log_var / eps and of every transform's u, w) is loaded into registers BEFORE the first
-// reduction, so the whole kernel pays one HBM/L2 latency instead of one per transform; z never leaves
-// registers and the only LDS traffic is the two-value block reductions.
-constexpr int FT = 4;     // max transforms per flow on the fast path
+// ---- compact path (used whenever everything fits LDS): every vector the workgroup needs (q0 mean /
+// log-var, the explicit draw, u and w of every transform) is prefetched into LDS by LDS-DMA with ALL
+// loads issued before a single wait, and the arithmetic runs as small loops.  (A fully unrolled
+// register-resident version was measured first: ~9000 straight-line instructions executed once made the
+// kernel instruction-fetch bound at 13 us.)
+constexpr int kFlowLdsBudget = 144 * 1024;
 
-template <typename T2>
-__device__ __forceinline__ void block_sum2(double& a, double& b, T2* scratch) {
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* scratch) {
     a = wave_sum(a); b = wave_sum(b);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     __syncthreads();
@@ -108,101 +108,91 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, T2* scratch) {
     b = (scratch[4] + scratch[5]) + (scratch[6] + scratch[7]);
 }
 
-template <int KMAX>
-__device__ __forceinline__ float planar_apply_reg(const float (&u)[FT][KMAX], const float (&w)[FT][KMAX],
-                                                  const float (&bias)[FT], int T, float (&z)[KMAX], double* scratch) {
-    float logdet = 0.f;
-#pragma unroll
-    for (int t = 0; t < FT; ++t) {
-        if (t < T) {
-            double s_wz = 0.0, s_uw = 0.0;
-#pragma unroll
-            for (int k = 0; k < KMAX; ++k) { s_wz += (double)(w[t][k] * z[k]); s_uw += (double)(u[t][k] * w[t][k]); }
-            block_sum2(s_wz, s_uw, scratch);
-            const float th = tanhf((float)s_wz + bias[t]);
-#pragma unroll
-            for (int k = 0; k < KMAX; ++k) z[k] += u[t][k] * th;
-            logdet += logf(fabsf(1.f + (1.f - th * th) * (float)s_uw));
-        }
-    }
-    return logdet;
-}
-
-template <int KMAX>
-__global__ __launch_bounds__(256) void mnf_flow_planar_fast_kernel(const FlowBatch bt) {
+__global__ __launch_bounds__(256) void mnf_flow_planar_lds_kernel(const FlowBatch bt) {
     const FlowArgs& a = bt.l[blockIdx.y];
-    if (blockIdx.x == 1 && !a.want_kl) return;
-    __shared__ double scratch[8];
     const bool klblk = blockIdx.x == 1;
+    if (klblk && !a.want_kl) return;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ double scratch[8];
+    const int I = a.I, P = pad64(I), tid = threadIdx.x;
     const float* eps = klblk ? a.eps_kl : a.eps_fwd;
-    const int tid = threadIdx.x;
-    float zu[FT][KMAX], zw[FT][KMAX], ru[FT][KMAX], rw[FT][KMAX], zb[FT], rb[FT];
-    float qm[KMAX], lv[KMAX], e[KMAX];
-    // ---- issue every load first (indices past I read as 0 and contribute nothing)
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-        const int i = tid + 256 * k;
-        const bool in = i < a.I;
-        qm[k] = in ? a.q0_mean[i] : 0.f;
-        lv[k] = in ? a.q0_log_var[i] : 0.f;
-        e[k] = (in && eps) ? eps[i] : 0.f;
-#pragma unroll
-        for (int t = 0; t < FT; ++t) {
-            zu[t][k] = (in && t < a.zf.T) ? a.zf.u[t][i] : 0.f;
-            zw[t][k] = (in && t < a.zf.T) ? a.zf.w[t][i] : 0.f;
-            ru[t][k] = (in && klblk && t < a.rf.T) ? a.rf.u[t][i] : 0.f;
-            rw[t][k] = (in && klblk && t < a.rf.T) ? a.rf.w[t][i] : 0.f;
-        }
+    const int Tz = a.zf.T, Tr = klblk ? a.rf.T : 0;
+    float* z = sm;                 // [P]
+    float* qm = sm + P;            // [P]
+    float* lv = sm + 2 * P;        // [P]
+    float* ep = sm + 3 * P;        // [P]   (unused with Philox)
+    float* uw = sm + 4 * P;        // (u, w) per transform: z-flow first, then r-flow
+    dma_stage(qm, a.q0_mean, I);
+    dma_stage(lv, a.q0_log_var, I);
+    if (eps) dma_stage(ep, eps, I);
+#pragma unroll 1
+    for (int t = 0; t < Tz + Tr; ++t) {
+        const float* u = t < Tz ? a.zf.u[t] : a.rf.u[t - Tz];
+        const float* w = t < Tz ? a.zf.w[t] : a.rf.w[t - Tz];
+        dma_stage(uw + (2 * t) * P, u, I);
+        dma_stage(uw + (2 * t + 1) * P, w, I);
     }
-#pragma unroll
-    for (int t = 0; t < FT; ++t) {
-        zb[t] = t < a.zf.T ? a.zf.b[t][0] : 0.f;
-        rb[t] = (klblk && t < a.rf.T) ? a.rf.b[t][0] : 0.f;
-    }
-    if (!eps) {
-        const uint64_t seed = a.rng[0], offs = a.rng[1];
-        const uint32_t stream = (klblk ? LBBNN_STREAM_EPS_Z2 : LBBNN_STREAM_EPS_Z) * 64u + a.layer;
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            const int i = tid + 256 * k;
-            float n[4];
-            philox_normal4(seed, offs, stream, (uint64_t)(i >> 2), 0u, n);
-            e[k] = n[i & 3];
-        }
-    }
-    float z[KMAX];
+    uint64_t seed = 0, offs = 0;
+    if (!eps) { seed = a.rng[0]; offs = a.rng[1]; }
+    const uint32_t stream = (klblk ? LBBNN_STREAM_EPS_Z2 : LBBNN_STREAM_EPS_Z) * 64u + a.layer;
+    dma_wait_all();
+
+    // z0 = q0_mean + exp(q0_log_var)^.5 * eps  (LBBNN-GP-MF-MNF.py:183-185); log_q0 (:213-214, -0.5*log(pi))
     double lq0 = 0.0;
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-        const int i = tid + 256 * k;
-        const float ev = expf(lv[k]);
-        const float z0 = qm[k] + sqrtf(ev) * e[k];                    // LBBNN-GP-MF-MNF.py:183-185
-        z[k] = (i < a.I) ? z0 : 0.f;
-        if (klblk && i < a.I) {
-            const float d = z0 - qm[k];
-            lq0 += (double)(-0.5f * 1.1447298858494002f - 0.5f * lv[k] - 0.5f * ((d * d) / ev));   // :213-214
+#pragma unroll 1
+    for (int i = tid; i < I; i += 256) {
+        float e;
+        if (eps) e = ep[i];
+        else { float n[4]; philox_normal4(seed, offs, stream, (uint64_t)(i >> 2), 0u, n); e = n[i & 3]; }
+        const float ev = expf(lv[i]);
+        const float z0 = qm[i] + sqrtf(ev) * e;
+        z[i] = z0;
+        if (klblk) {
+            const float d = z0 - qm[i];
+            lq0 += (double)(-0.5f * 1.1447298858494002f - 0.5f * lv[i] - 0.5f * ((d * d) / ev));
         }
     }
-    const float ldq = planar_apply_reg<KMAX>(zu, zw, zb, a.zf.T, z, scratch);
-    float* zo = klblk ? a.z_kl : a.z_fwd;
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) { const int i = tid + 256 * k; if (i < a.I) zo[i] = z[k]; }
+    __syncthreads();
+    float ld_q = 0.f, ld_r = 0.f;
+#pragma unroll 1
+    for (int t = 0; t < Tz + Tr; ++t) {
+        const float* u = uw + (2 * t) * P;
+        const float* w = uw + (2 * t + 1) * P;
+        const float bias = (t < Tz ? a.zf.b[t] : a.rf.b[t - Tz])[0];
+        double s_wz = 0.0, s_uw = 0.0;
+#pragma unroll 1
+        for (int i = tid; i < I; i += 256) { s_wz += (double)(w[i] * z[i]); s_uw += (double)(u[i] * w[i]); }
+        block_sum2(s_wz, s_uw, scratch);
+        const float th = tanhf((float)s_wz + bias);                       // flows2.py:87
+        const float ld = logf(fabsf(1.f + (1.f - th * th) * (float)s_uw));  // flows2.py:89,95
+        if (t < Tz) ld_q += ld; else ld_r += ld;
+        if (t == Tz - 1) {
+            // last z-flow transform: update and publish z (z_k or z2) in the same sweep
+            float* zo = klblk ? a.z_kl : a.z_fwd;
+#pragma unroll 1
+            for (int i = tid; i < I; i += 256) { const float v = z[i] + u[i] * th; z[i] = v; zo[i] = v; }
+        } else {
+#pragma unroll 1
+            for (int i = tid; i < I; i += 256) z[i] += u[i] * th;        // flows2.py:88
+        }
+        __syncthreads();
+    }
+    if (Tz == 0) {
+        float* zo = klblk ? a.z_kl : a.z_fwd;
+        for (int i = tid; i < I; i += 256) zo[i] = z[i];
+    }
     if (!klblk) {
-        if (tid == 0 && a.scal) a.scal[4] = ldq;
+        if (tid == 0 && a.scal) a.scal[4] = ld_q;
         return;
     }
     double dummy = 0.0;
     block_sum2(lq0, dummy, scratch);
-    const float ldr = planar_apply_reg<KMAX>(ru, rw, rb, a.rf.T, z, scratch);
-    // z_b[-1]: the thread that owns element I-1 publishes it                        :224
-    const int last = a.I - 1;
-    if (tid == (last & 255)) {
-        float zl = 0.f;
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) if (k == (last >> 8)) zl = z[k];
-        a.scal[3] = zl;
+    if (tid == 0) {
+        a.scal[0] = ld_q;
+        a.scal[1] = (float)lq0;
+        a.scal[2] = ld_r;
+        a.scal[3] = z[I - 1];                                            // z_b[-1]: last ELEMENT (:224)
     }
-    if (tid == 0) { a.scal[0] = ldq; a.scal[1] = (float)lq0; a.scal[2] = ldr; }
 }
 
 // -------------------------------------------------------------------------------------------- K5
@@ -245,6 +235,69 @@ __global__ __launch_bounds__(256) void kl_finalize_kernel(const FinalizeBatch bt
         kl += log_q - log_r;                                                              // :235
     }
     if (threadIdx.x == 0) {
+        const float k = (float)kl;
+        if (a.kl_layer) *a.kl_layer = k;
+        if (a.kl_out) *a.kl_out = a.accum ? (*a.kl_out + k) : k;
+    }
+}
+
+// K5, compact form: the eight input vectors are prefetched into LDS by LDS-DMA (all loads issued, one
+// wait), then reduced from LDS.  Used when they fit; otherwise kl_finalize_kernel above reads from global.
+__global__ __launch_bounds__(256) void kl_finalize_lds_kernel(const FinalizeBatch bt) {
+    const FinalizeArgs& a = bt.l[blockIdx.x];
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ double scratch[8];
+    const bool mnf = a.scal != nullptr;
+    const int O = a.O, I = a.I, PO = pad64(O), PI = pad64(mnf ? I : 1), tid = threadIdx.x;
+    float* klr = sm;            float* bmu = sm + PO;       float* brho = sm + 2 * PO;
+    float* amu = sm + 3 * PO;   float* avar = sm + 4 * PO;  float* eact = sm + 5 * PO;
+    float* b1 = sm + 6 * PO;    float* b2 = b1 + PI;
+    dma_stage(klr, a.kl_rows, O);
+    dma_stage(bmu, a.bias_mu, O);
+    dma_stage(brho, a.bias_rho, O);
+    if (mnf) {
+        dma_stage(amu, a.act_mu, O);
+        dma_stage(avar, a.act_var, O);
+        if (a.eps_act) dma_stage(eact, a.eps_act, O);
+        dma_stage(b1, a.r0_b1, I);
+        dma_stage(b2, a.r0_b2, I);
+    }
+    uint64_t seed = 0, offs = 0;
+    if (mnf && !a.eps_act) { seed = a.rng[0]; offs = a.rng[1]; }
+    const float zb = mnf ? a.scal[3] : 0.f, ldq = mnf ? a.scal[0] : 0.f, lq0 = mnf ? a.scal[1] : 0.f, ldr = mnf ? a.scal[2] : 0.f;
+    dma_wait_all();
+
+    double s_rows = 0.0, s_bias = 0.0, s_act = 0.0;
+#pragma unroll 1
+    for (int o = tid; o < O; o += 256) {
+        s_rows += (double)klr[o];
+        const float sb = softplus_ref(brho[o]);
+        const float d = bmu[o] - a.bias_mu_prior;
+        const float sp = a.bias_sigma_prior;
+        s_bias += (double)(logf(sp / sb) - 0.5f + (sb * sb + d * d) / (2.f * sp * sp));       // …LRT.py:185-186
+        if (mnf) {
+            float e;
+            if (a.eps_act) e = eact[o];
+            else { float n[4]; philox_normal4(seed, offs, LBBNN_STREAM_EPS_ACT * 64u + a.layer, (uint64_t)(o >> 2), 0u, n); e = n[o & 3]; }
+            s_act += (double)tanhf(amu[o] + sqrtf(avar[o]) * e);                               // …MNF.py:218-219
+        }
+    }
+    block_sum2(s_rows, s_bias, scratch);
+    double kl = s_bias + s_rows;
+    if (mnf) {
+        double s_rb = 0.0, dummy = 0.0;
+        block_sum2(s_act, dummy, scratch);
+        const float m = (float)(s_act / (double)O);          // outer(b, act).mean(-1) = b * mean(act)   :220-221
+#pragma unroll 1
+        for (int i = tid; i < I; i += 256) {
+            const float mr = b1[i] * m, lvr = b2[i] * m;
+            const float d = zb - mr;
+            s_rb += (double)(-0.5f * 1.1447298858494002f - 0.5f * lvr - 0.5f * ((d * d) / expf(lvr)));  // :223-224
+        }
+        block_sum2(s_rb, dummy, scratch);
+        kl += (-(double)ldq + (double)lq0) - ((double)ldr + s_rb);                             // :215,:225,:235
+    }
+    if (tid == 0) {
         const float k = (float)kl;
         if (a.kl_layer) *a.kl_layer = k;
         if (a.kl_out) *a.kl_out = a.accum ? (*a.kl_out + k) : k;
@@ -316,20 +369,46 @@ int launch_flow_planar(const FlowArgs* a, int n, hipStream_t s) {
     for (int i = 0; i < n; ++i) {
         bt.l[i] = a[i];
         maxI = a[i].I > maxI ? a[i].I : maxI;
-        small_t = small_t && a[i].zf.T <= FT && (!a[i].want_kl || a[i].rf.T <= FT);
         any_kl = any_kl || a[i].want_kl;
     }
     const dim3 grid(any_kl ? 2 : 1, n), block(256);
-    if (small_t && maxI <= 256 * 2)      hipLaunchKernelGGL(mnf_flow_planar_fast_kernel<2>, grid, block, 0, s, bt);
-    else if (small_t && maxI <= 256 * 5) hipLaunchKernelGGL(mnf_flow_planar_fast_kernel<5>, grid, block, 0, s, bt);
-    else hipLaunchKernelGGL(mnf_flow_planar_kernel, grid, block, (size_t)maxI * sizeof(float), s, bt);
+    (void)small_t;
+    size_t need = 0;
+    for (int i = 0; i < n; ++i) {
+        const size_t v = (size_t)(4 + 2 * (a[i].zf.T + (a[i].want_kl ? a[i].rf.T : 0))) * pad64(a[i].I) * sizeof(float);
+        need = v > need ? v : need;
+    }
+    if (need <= (size_t)kFlowLdsBudget) {
+        if (need > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnf_flow_planar_lds_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(mnf_flow_planar_lds_kernel, grid, block, need, s, bt);
+    } else {
+        hipLaunchKernelGGL(mnf_flow_planar_kernel, grid, block, (size_t)maxI * sizeof(float), s, bt);
+    }
     return (int)hipGetLastError();
 }
 
 int launch_kl_finalize(const FinalizeArgs* a, int n, hipStream_t s) {
     FinalizeBatch bt;
-    for (int i = 0; i < n; ++i) bt.l[i] = a[i];
-    hipLaunchKernelGGL(kl_finalize_kernel, dim3(n), dim3(256), 0, s, bt);
+    size_t need = 0;
+    for (int i = 0; i < n; ++i) {
+        bt.l[i] = a[i];
+        const size_t v = (size_t)(6 * pad64(a[i].O) + 2 * pad64(a[i].scal ? a[i].I : 1)) * sizeof(float);
+        need = v > need ? v : need;
+    }
+    if (need <= (size_t)kFlowLdsBudget) {
+        if (need > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kl_finalize_lds_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(kl_finalize_lds_kernel, dim3(n), dim3(256), need, s, bt);
+    } else {
+        hipLaunchKernelGGL(kl_finalize_kernel, dim3(n), dim3(256), 0, s, bt);
+    }
     return (int)hipGetLastError();
 }
 

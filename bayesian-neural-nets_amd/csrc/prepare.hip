@@ -38,7 +38,7 @@ extern "C" int lbbnn_layers_prepare(const lbbnn_layer_desc_t* L, int n, const ui
                                              d.e_w, d.stochastic ? d.var_w : nullptr, lbbnn_operand_ld(d.I),
                                              d.want_kl ? d.kl_rows : nullptr,
                                              (mnf && d.want_kl) ? d.act_mu : nullptr, (mnf && d.want_kl) ? d.act_var : nullptr,
-                                             d.bias_var, d.O, d.I);
+                                             d.bias_var, d.O, d.I, d.split ? 1 : 0);
         if (rc) return rc;
         if (d.want_kl) {
             FinalizeArgs& k = ka[nk++];

@@ -9,6 +9,7 @@
 // Mapping: one 256-thread workgroup per output row o; thread t owns float4 column groups
 // t, t+256, ... so a wave reads 1 KiB contiguous per instruction.  Row sums use a fixed-order
 // wave butterfly + LDS, so kl_rows / act_* are bitwise reproducible.
+#include <cmath>
 #include "lbbnn_device.h"
 #include "lbbnn_internal.h"
 
@@ -20,23 +21,54 @@ struct WeightPassBatch { WeightPassArgs l[LBBNN_MAX_LAYERS]; int row_end[LBBNN_M
 
 struct Elem { float ew, vw, kl, amu, avar; };
 
-// All per-weight arithmetic, spelled in the reference's operation order
-// (LBBNN-GP-MF-LRT.py:167-171,189-192; LBBNN-GP-MF-MNF.py:195-196,211-212,230-233).
+// round-to-nearest-even fp32 -> bf16 bits (finite inputs)
+__device__ __forceinline__ uint32_t bf16_rne(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float bf16_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
+// split w = hi + lo (both bf16): hi = rne(w), lo = rne(w - hi); packs 4 elements into two uint2
+__device__ __forceinline__ void split4(const float4 w, uint2& hi, uint2& lo) {
+    const float v[4] = {w.x, w.y, w.z, w.w};
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { h[i] = bf16_rne(v[i]); l[i] = bf16_rne(v[i] - bf16_to_f32(h[i])); }
+    hi = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+    lo = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+}
+
+// All per-weight arithmetic (LBBNN-GP-MF-LRT.py:167-171,189-192; LBBNN-GP-MF-MNF.py:195-196,211-212,230-233).
+//
+// The pass must stay HBM-bound (20 B per weight), so the ~7 transcendentals per weight use the
+// hardware forms (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp) instead of the ~30-instruction libm
+// sequences:  alpha = rcp(1 + exp(-lambda));  sigma = log1p(exp(rho)) by a 5-term series when
+// exp(rho) < 0.04 (the reference's init has exp(rho) in [0.0067, 0.018]; truncation error < 1e-9 relative)
+// and libm log1pf otherwise;  log(a/b) = log a - log b with the prior logs precomputed on the host.
+// Measured against the fp64 oracle: operands and row sums stay within 2e-6 relative (tests).
+__device__ __forceinline__ float softplus_fast(float rho) {
+    const float y = __expf(rho);
+    if (y < 0.04f) {
+        // log1p(y) = y - y^2/2 + y^3/3 - y^4/4 + y^5/5
+        return y * (1.f + y * (-0.5f + y * (0.33333334f + y * (-0.25f + y * 0.2f))));
+    }
+    return log1pf(y);
+}
+
 __device__ __forceinline__ Elem weight_elem(float mu, float rho, float lam, float zf, float zk, float rc,
                                             bool want_kl, bool want_act, const WeightPassArgs& a) {
     Elem e;
-    const float alpha = sigmoid_ref(lam);
-    const float sigma = softplus_ref(rho);
+    const float alpha = __frcp_rn(1.0f + __expf(-lam));
+    const float sigma = softplus_fast(rho);
     const float ea = mu * alpha;
     e.ew = ea * zf;
     e.vw = (sigma * sigma) * (alpha * alpha);
     e.kl = 0.f; e.amu = 0.f; e.avar = 0.f;
     if (want_kl) {
         const float d = mu * zk - a.mu_prior;
-        const float sp = a.sigma_prior;
-        e.kl = alpha * (logf(sp / sigma) - 0.5f + logf(alpha / a.alpha_prior)
-                        + (sigma * sigma + d * d) / (2.f * sp * sp))
-             + (1.f - alpha) * logf((1.f - alpha) / (1.f - a.alpha_prior));
+        const float one_m = 1.f - alpha;
+        e.kl = alpha * ((a.log_sp - __logf(sigma)) - 0.5f + (__logf(alpha) - a.log_ap)
+                        + (sigma * sigma + d * d) * a.inv_2sp2)
+             + one_m * (__logf(one_m) - a.log_1map);
     }
     if (want_act) {
         e.amu = rc * ((zk * mu) * alpha);
@@ -62,12 +94,21 @@ __global__ __launch_bounds__(256) void weight_pass_kernel(const WeightPassBatch 
 
     if (VEC) {
         const int n4 = a.ld >> 2, i4 = a.I >> 2;
+        // prefetch the second column group of this thread (rows of 257..512 float4) with the first
+        float4 pmu = make_float4(0.f, 0.f, 0.f, 0.f), prho = pmu, plam = pmu;
+        const bool pre = (tid + 256) < i4;
+        if (pre) {
+            pmu = reinterpret_cast<const float4*>(a.mu + rowoff)[tid + 256];
+            prho = reinterpret_cast<const float4*>(a.rho + rowoff)[tid + 256];
+            plam = reinterpret_cast<const float4*>(a.lambdal + rowoff)[tid + 256];
+        }
         for (int j = tid; j < n4; j += 256) {
             float4 ew = make_float4(0.f, 0.f, 0.f, 0.f), vw = ew;
             if (j < i4) {
-                const float4 mu = reinterpret_cast<const float4*>(a.mu + rowoff)[j];
-                const float4 rho = reinterpret_cast<const float4*>(a.rho + rowoff)[j];
-                const float4 lam = reinterpret_cast<const float4*>(a.lambdal + rowoff)[j];
+                const bool usep = pre && j == tid + 256;
+                const float4 mu = usep ? pmu : reinterpret_cast<const float4*>(a.mu + rowoff)[j];
+                const float4 rho = usep ? prho : reinterpret_cast<const float4*>(a.rho + rowoff)[j];
+                const float4 lam = usep ? plam : reinterpret_cast<const float4*>(a.lambdal + rowoff)[j];
                 const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
                 const float4 zf = a.z_fwd ? reinterpret_cast<const float4*>(a.z_fwd)[j] : one;
                 const float4 zk = a.z_kl ? reinterpret_cast<const float4*>(a.z_kl)[j] : one;
@@ -82,8 +123,27 @@ __global__ __launch_bounds__(256) void weight_pass_kernel(const WeightPassBatch 
                 amu += (e0.amu + e1.amu) + (e2.amu + e3.amu);
                 avar += (e0.avar + e1.avar) + (e2.avar + e3.avar);
             }
-            if (a.e_w) reinterpret_cast<float4*>(a.e_w + (size_t)o * a.ld)[j] = ew;
-            if (a.var_w) reinterpret_cast<float4*>(a.var_w + (size_t)o * a.ld)[j] = vw;
+            if (!a.split) {
+                if (a.e_w) reinterpret_cast<float4*>(a.e_w + (size_t)o * a.ld)[j] = ew;
+                if (a.var_w) reinterpret_cast<float4*>(a.var_w + (size_t)o * a.ld)[j] = vw;
+            } else {
+                // split-precision operands: bf16 hi / lo planes of e_w and of var_w (zero tail kept)
+                uint16_t* const eh = reinterpret_cast<uint16_t*>(a.e_w);
+                uint16_t* const el = eh + (size_t)a.O * a.ld;
+                uint2 hi, lo;
+                split4(ew, hi, lo);
+                if (a.e_w) {
+                    reinterpret_cast<uint2*>(eh + (size_t)o * a.ld)[j] = hi;
+                    reinterpret_cast<uint2*>(el + (size_t)o * a.ld)[j] = lo;
+                }
+                if (a.var_w) {
+                    uint16_t* const vh = reinterpret_cast<uint16_t*>(a.var_w);
+                    uint16_t* const vl = vh + (size_t)a.O * a.ld;
+                    split4(vw, hi, lo);
+                    reinterpret_cast<uint2*>(vh + (size_t)o * a.ld)[j] = hi;
+                    reinterpret_cast<uint2*>(vl + (size_t)o * a.ld)[j] = lo;
+                }
+            }
         }
     } else {
         for (int i = tid; i < a.ld; i += 256) {
@@ -127,7 +187,7 @@ namespace lbbnn {
 int make_weight_pass_args(WeightPassArgs& a, const float* mu, const float* rho, const float* lambdal,
                           const float* z_fwd, const float* z_kl, const float* r0_c, const float* bias_rho,
                           const lbbnn_priors_t* priors, void* e_w, void* var_w, int ld,
-                          float* kl_rows, float* act_mu, float* act_var, float* bias_var, int O, int I) {
+                          float* kl_rows, float* act_mu, float* act_var, float* bias_var, int O, int I, int split) {
     if (!mu || !rho || !lambdal || !priors) return LBBNN_E_NULL;
     if (O <= 0 || I <= 0) return LBBNN_E_SHAPE;
     if ((e_w || var_w) && (ld < I || (ld & 31))) return LBBNN_E_ALIGN;
@@ -141,8 +201,12 @@ int make_weight_pass_args(WeightPassArgs& a, const float* mu, const float* rho, 
     a.kl_rows = kl_rows; a.act_mu = act_mu; a.act_var = act_var; a.bias_var = bias_var;
     a.O = O; a.I = I; a.ld = (e_w || var_w) ? ld : lbbnn_operand_ld(I);
     a.mu_prior = priors->mu_prior; a.sigma_prior = priors->sigma_prior; a.alpha_prior = priors->alpha_prior;
+    a.log_sp = logf(priors->sigma_prior); a.log_ap = logf(priors->alpha_prior); a.log_1map = logf(1.f - priors->alpha_prior);
+    a.inv_2sp2 = 1.f / (2.f * priors->sigma_prior * priors->sigma_prior);
+    a.split = split;
     a.vec = ((I % 4 == 0) && aligned16(mu) && aligned16(rho) && aligned16(lambdal) &&
              (!z_fwd || aligned16(z_fwd)) && (!z_kl || aligned16(z_kl)) && (!r0_c || aligned16(r0_c))) ? 1 : 0;
+    if (split && !a.vec) return LBBNN_E_ALIGN;          // split operands need the vector path (I % 4 == 0, aligned)
     return 0;
 }
 
@@ -167,10 +231,9 @@ extern "C" int lbbnn_weight_pass(const float* mu, const float* rho, const float*
                                  float* kl_rows, float* act_mu, float* act_var, float* bias_var,
                                  int O, int I, int flags, void* stream) {
     if (flags & ~LBBNN_F_SPLIT16) return LBBNN_E_FLAGS;
-    if (flags & LBBNN_F_SPLIT16) return LBBNN_E_FLAGS;   // split-precision operands: not in this build
     lbbnn::WeightPassArgs a;
     const int rc = lbbnn::make_weight_pass_args(a, mu, rho, lambdal, z_fwd, z_kl, r0_c, bias_rho, priors, e_w, var_w, ld,
-                                                kl_rows, act_mu, act_var, bias_var, O, I);
+                                                kl_rows, act_mu, act_var, bias_var, O, I, (flags & LBBNN_F_SPLIT16) ? 1 : 0);
     if (rc) return rc;
     return lbbnn::launch_weight_pass(&a, 1, static_cast<hipStream_t>(stream));
 }

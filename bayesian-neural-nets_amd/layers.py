@@ -88,6 +88,7 @@ class _BayesLinearBase(nn.Module):
         self.row_offset = 0            # global row index of this rank's first batch row (data parallel)
         self._layer_id = next(_layer_ids) % 64
         self._ws = None
+        self._split_now = False        # decided per forward (prep and GEMM must agree on the operand format)
 
     # reference keeps the prior tensors as attributes; expose them lazily with the same names
     @property
@@ -111,6 +112,14 @@ class _BayesLinearBase(nn.Module):
     def _alpha_now(self):
         return 1 / (1 + torch.exp(-self.lambdal))
 
+    def _split(self, x=None):
+        """Use the split-precision (bf16x3) operands/kernels for this layer call?"""
+        if ops.get_precision() != "bf16x3" or not ops.split_eligible(self.in_features, self.out_features):
+            return False
+        if x is not None and (x.stride(0) % 4 != 0 or x.data_ptr() % 16 != 0 or x.stride(1) != 1):
+            return False
+        return True
+
     @property
     def alpha_q(self):
         """sigmoid(lambdal) (…LRT.py:167).  The reference refreshes this attribute (and
@@ -130,6 +139,7 @@ class _BayesLinearBase(nn.Module):
         d.priors = self.priors
         d.O, d.I, d.layer_id = self.out_features, self.in_features, self._layer_id
         d.stochastic, d.want_kl = int(cfg[0]), int(cfg[1])
+        d.split = int(self._split_now)
         d.e_w, d.var_w = ws.e_w.data_ptr(), ws.var_w.data_ptr()
         d.kl_rows, d.bias_var = ws.kl_rows.data_ptr(), ws.bias_var.data_ptr()
         d.kl_layer = kl_layer.data_ptr() if kl_layer is not None else None
@@ -146,6 +156,7 @@ class _BayesLinearBase(nn.Module):
             rng = st.t
             saved["rng"] = rng.clone() if save_rng else None
         kl = torch.empty((), dtype=torch.float32, device=x.device) if cfg[1] else None
+        self._split_now = self._split(x)
         self._prep(cfg, rng, kl_layer=kl)
         out = self._gemm(x, cfg, rng)
         if st is not None and advance:
@@ -188,7 +199,7 @@ class LRTBayesianLinear(_BayesLinearBase):
         ws = self._workspace()
         ops.weight_pass(self.weight_mu, self.weight_rho, self.lambdal, bias_rho=self.bias_rho,
                         priors=self.priors, e_w=ws.e_w, var_w=ws.var_w if stochastic else None,
-                        kl_rows=ws.kl_rows if want_kl else None, bias_var=ws.bias_var)
+                        kl_rows=ws.kl_rows if want_kl else None, bias_var=ws.bias_var, split=self._split_now)
         if want_kl and finalize:
             self._finalize(rng, kl_layer, kl_total, accumulate)
 
@@ -204,7 +215,7 @@ class LRTBayesianLinear(_BayesLinearBase):
         return ops.lrt_gemm(x, ws.e_w, ws.var_w, I=self.in_features, O=self.out_features,
                             bias_mean=self.bias_mu, bias_var=ws.bias_var, eps=eps, rng=rng,
                             rng_stream=ops.STREAM_EPS_OUT * 64 + self._layer_id, row_offset=self.row_offset,
-                            relu=relu, mean_only=not stochastic, log_softmax=log_softmax)
+                            relu=relu, mean_only=not stochastic, log_softmax=log_softmax, split=self._split_now)
 
     def _noise_for_backward(self, saved, B):
         if saved.get("noise") and "eps_out" in saved["noise"]:
@@ -322,7 +333,7 @@ class MNFBayesianLinear(_BayesLinearBase):
                         var_w=ws.var_w if stochastic else None,
                         kl_rows=ws.kl_rows if want_kl else None,
                         act_mu=ws.act_mu if want_kl else None, act_var=ws.act_var if want_kl else None,
-                        bias_var=ws.bias_var)
+                        bias_var=ws.bias_var, split=self._split_now)
         if want_kl and finalize:
             self._finalize(rng, kl_layer, kl_total, accumulate)
 
@@ -340,7 +351,7 @@ class MNFBayesianLinear(_BayesLinearBase):
                             bias_mean=self.bias_mu, bias_var=ws.bias_var, eps=(self.noise or {}).get("eps_out"),
                             rng=rng, rng_stream=ops.STREAM_EPS_OUT * 64 + self._layer_id,
                             row_offset=self.row_offset, relu=relu, mean_only=not stochastic,
-                            log_softmax=log_softmax)
+                            log_softmax=log_softmax, split=self._split_now)
 
     def _noise_for_backward(self, saved, B):
         if saved.get("noise"):
@@ -416,6 +427,8 @@ class _NetworkBase(nn.Module):
         descs = (_lib.LayerDesc * n)()
         keep = []
         for i, (l, c) in enumerate(zip(layers, cfgs)):
+            # activations produced by our own GEMMs are dense 16-B aligned rows; the network input is checked
+            l._split_now = l._split(x if i == 0 else None) and (i == 0 or layers[i - 1].out_features % 4 == 0)
             keep.append(l._fill_desc(descs[i], c, kls[i] if c[1] else None))
         stream = torch.cuda.current_stream(dev).cuda_stream
         _lib.check(_lib.lib().lbbnn_layers_prepare(descs, n, rng.data_ptr() if rng is not None else None, stream),

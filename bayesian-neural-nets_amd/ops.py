@@ -23,6 +23,28 @@ STREAM_EPS_Z2 = 2
 STREAM_EPS_ACT = 3
 
 
+# GEMM arithmetic: "fp32" = exact fp32 MFMA path; "bf16x3" = split-precision path (bf16 hi/lo mean
+# products + bf16 variance product on the bf16 matrix cores, fp32 accumulation; ~1e-5 relative on the
+# layer output, inside the 1e-4 contract).  Layers fall back to fp32 where the split format does not apply.
+_PRECISION = "fp32"
+
+
+def set_precision(name: str):
+    global _PRECISION
+    if name not in ("fp32", "bf16x3"):
+        raise ValueError("precision must be 'fp32' or 'bf16x3'")
+    _PRECISION = name
+
+
+def get_precision() -> str:
+    return _PRECISION
+
+
+def split_eligible(I: int, O: int) -> bool:
+    """Shapes the split-precision kernels accept (see lbbnn_lrt_gemm, LBBNN_F_SPLIT16)."""
+    return O > 16 and I % 8 == 0 and (I % 32 == 0 or operand_ld(I) - I >= 8)
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -108,7 +130,7 @@ def philox_normal(rng: torch.Tensor, stream_id: int, rows: int, cols: int, row_b
 # ----------------------------------------------------------------------------------------- K1
 def weight_pass(mu, rho, lambdal, *, z_fwd=None, z_kl=None, r0_c=None, bias_rho=None,
                 priors: Priors, e_w=None, var_w=None, kl_rows=None, act_mu=None, act_var=None,
-                bias_var=None):
+                bias_var=None, split: bool = False):
     """lbbnn_weight_pass.  Output tensors are caller-allocated (see LayerWorkspace)."""
     O, I = mu.shape
     ld = operand_ld(I)
@@ -116,7 +138,7 @@ def weight_pass(mu, rho, lambdal, *, z_fwd=None, z_kl=None, r0_c=None, bias_rho=
         _ptr(mu, "weight_mu"), _ptr(rho, "weight_rho"), _ptr(lambdal, "lambdal"),
         _ptr(z_fwd), _ptr(z_kl), _ptr(r0_c), _ptr(bias_rho), ctypes.byref(priors),
         _ptr(e_w), _ptr(var_w), ld, _ptr(kl_rows), _ptr(act_mu), _ptr(act_var), _ptr(bias_var),
-        O, I, 0, _stream())
+        O, I, F_SPLIT16 if split else 0, _stream())
     _lib.check(rc, "lbbnn_weight_pass")
 
 
@@ -129,7 +151,7 @@ GEMM_EVENTS = None
 def lrt_gemm(x, e_w, var_w, *, I: int, O: int, bias_mean=None, bias_var=None, var_scale=None,
              eps=None, rng: Optional[torch.Tensor] = None, rng_stream: int = 0, row_offset: int = 0,
              relu: bool = False, mean_only: bool = False, log_softmax: bool = False,
-             out: Optional[torch.Tensor] = None):
+             split: bool = False, out: Optional[torch.Tensor] = None):
     """lbbnn_lrt_gemm: out = x.e_w^T + b [+ sqrt(x^2.var_w^T + bv) * eps] [ReLU]."""
     if x.dim() != 2 or x.shape[1] != I:
         raise RuntimeError("bnn_amd: input must be (B,%d), got %s" % (I, tuple(x.shape)))
@@ -138,7 +160,8 @@ def lrt_gemm(x, e_w, var_w, *, I: int, O: int, bias_mean=None, bias_var=None, va
         out = torch.empty((B, O), dtype=torch.float32, device=x.device)
     if eps is not None and tuple(eps.shape) != (B, O):
         raise RuntimeError("bnn_amd: eps must be (%d,%d), got %s" % (B, O, tuple(eps.shape)))
-    flags = (F_RELU if relu else 0) | (F_MEAN_ONLY if mean_only else 0) | (F_LOG_SOFTMAX if log_softmax else 0)
+    flags = ((F_RELU if relu else 0) | (F_MEAN_ONLY if mean_only else 0) | (F_LOG_SOFTMAX if log_softmax else 0)
+             | (F_SPLIT16 if split else 0))
     if x.stride(1) != 1 or (x.stride(0) < I):
         x = x.contiguous()
     ev = None

@@ -182,6 +182,7 @@ typedef struct lbbnn_layer_desc {
     uint32_t layer_id;
     int stochastic;          /* produce var_w (training or sample)            */
     int want_kl;             /* training or calculate_log_probs               */
+    int split;               /* operands in split-precision format (LBBNN_F_SPLIT16) */
     /* explicit draws; NULL => Philox from rng */
     const float *eps_z, *eps_z2, *eps_act;
     /* caller-owned workspace */

@@ -428,3 +428,70 @@ def test_hip_graph_capture_replays_with_fresh_noise(bnn, dev):
     assert torch.isfinite(o1).all() and torch.isfinite(o2).all()
     assert not torch.equal(o1, o2)              # the device-side RNG offset advanced inside the graph
     assert abs(float(k1) - float(k2)) / abs(float(k1)) < 1e-2 and float(k1) != float(k2)
+
+
+# --------------------------------------------------------------------------- split-precision (bf16x3) path
+@pytest.mark.parametrize("B,I,O", [(128, 64, 80), (100, 784, 400), (257, 1200, 1200), (1024, 784, 400), (64, 40, 17)])
+def test_split_gemm_vs_fp64(bnn, dev, B, I, O):
+    """bf16x3 mean and variance products on the bf16 matrix cores: inside the 1e-4 contract (measured ~5e-6)."""
+    ops = bnn.ops
+    g = torch.Generator().manual_seed(B + I + O)
+    x = torch.rand(B, I, generator=g)
+    p = orc.init_mnf_params(I, O, g)
+    z = 1 + 0.1 * torch.randn(I, generator=g)
+    d = {k: v.to(dev) for k, v in p.items()}
+    ld = ops.operand_ld(I)
+    e_w = torch.empty(O, ld, device=dev); var_w = torch.empty(O, ld, device=dev); bias_var = torch.empty(O, device=dev)
+    ops.weight_pass(d["weight_mu"], d["weight_rho"], d["lambdal"], z_fwd=z.to(dev), bias_rho=d["bias_rho"],
+                    priors=bnn.Priors(), e_w=e_w, var_w=var_w, bias_var=bias_var, split=True)
+    eps = torch.randn(B, O, generator=g)
+    out = ops.lrt_gemm(x.to(dev), e_w, var_w, I=I, O=O, bias_mean=d["bias_mu"], bias_var=bias_var,
+                       eps=eps.to(dev), relu=False, split=True)
+    alpha = orc.alpha_of(p["lambdal"].double()); sigma = orc.sigma_of(p["weight_rho"].double())
+    ew = p["weight_mu"].double() * alpha * z.double()
+    vw = sigma ** 2 * alpha ** 2
+    x64 = x.double()
+    ref = x64 @ ew.T + p["bias_mu"].double() + torch.sqrt((x64 ** 2) @ vw.T + orc.sigma_of(p["bias_rho"].double()) ** 2) * eps.double()
+    err = rel_err(out, ref)
+    assert err < 2e-5, err
+    # mean-only path too
+    out = ops.lrt_gemm(x.to(dev), e_w, var_w, I=I, O=O, bias_mean=d["bias_mu"], mean_only=True, split=True)
+    assert rel_err(out, x64 @ ew.T + p["bias_mu"].double()) < 5e-5
+
+
+def test_split_headline_network_vs_oracle(bnn, dev):
+    """Whole 784-1200-1200-10 MNF/planar net at B=4096 under set_precision('bf16x3') vs the fp32 oracle."""
+    dims, B, T = (784, 1200, 1200, 10), 4096, 2
+    torch.manual_seed(21)
+    net = bnn.mnf.BayesianNetwork(dims, T, z_flow_type="Planar", r_flow_type="Planar")
+    layers = [net.l1, net.l2, net.l3]
+    g = torch.Generator().manual_seed(22)
+    x = torch.rand(B, 784, generator=g)
+    noises, P, zf, rf = [], [], [], []
+    for l in layers:
+        sd = {k: v.detach().clone() for k, v in l.state_dict().items()}
+        P.append(sd)
+        zf.append(orc.flow_from_state("z_flow", "Planar", sd, T))
+        rf.append(orc.flow_from_state("r_flow", "Planar", sd, T))
+        noises.append({"eps_z": torch.randn(1, l.in_features, generator=g),
+                       "eps_out": torch.randn(B, l.out_features, generator=g),
+                       "eps_z2": torch.randn(1, l.in_features, generator=g),
+                       "eps_act": torch.randn(l.out_features, generator=g)})
+    ref_out, ref_kl = orc.mnf_network_forward(x, P, zf, rf, noises)
+    net = net.to(dev).train()
+    for l, n in zip(layers, noises):
+        l.noise = {k: v.to(dev) for k, v in n.items()}
+    bnn.set_precision("bf16x3")
+    try:
+        with torch.no_grad():
+            out = net(x.to(dev), sample=True)
+            kl = net.kl()
+            assert net.l1._split_now and net.l2._split_now and not net.l3._split_now
+        # per-layer path (autograd Function) uses the same kernels
+        out2 = net.l1(x.to(dev), sample=True)
+    finally:
+        bnn.set_precision("fp32")
+    e = rel_err(out, ref_out)
+    assert e < TOL, e
+    assert rel_err(kl, ref_kl) < TIGHT          # KL never touches the reduced-precision operands
+    assert torch.isfinite(out2).all()

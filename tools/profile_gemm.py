@@ -13,6 +13,7 @@ import bnn_amd
 from bnn_amd import ops
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+SPLIT = os.environ.get("SPLIT", "0") == "1"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 dev = torch.device("cuda:0")
 st = ops.RngState.get(dev)
@@ -23,15 +24,19 @@ for (I, O) in [(784, 1200), (1200, 1200)]:
     x = torch.rand(B, I, device=dev, generator=g)
     ew = torch.zeros(O, ld, device=dev); ew[:, :I] = 0.02 * (torch.rand(O, I, device=dev, generator=g) - 0.5)
     vw = torch.zeros(O, ld, device=dev); vw[:, :I] = 1e-4 * torch.rand(O, I, device=dev, generator=g)
+    if SPLIT:   # operands in split format via the weight pass (values irrelevant for timing, must be finite)
+        mu = 0.02 * (torch.rand(O, I, device=dev, generator=g) - 0.5); rho = -5 + torch.rand(O, I, device=dev, generator=g)
+        lam = torch.rand(O, I, device=dev, generator=g)
+        ops.weight_pass(mu, rho, lam, priors=bnn_amd.Priors(), e_w=ew, var_w=vw, split=True)
     bm = torch.rand(O, device=dev, generator=g); bv = 1e-4 * torch.rand(O, device=dev, generator=g)
     out = torch.empty(B, O, device=dev)
     for _ in range(3):
-        ops.lrt_gemm(x, ew, vw, I=I, O=O, bias_mean=bm, bias_var=bv, rng=st.t, relu=True, out=out)
+        ops.lrt_gemm(x, ew, vw, I=I, O=O, bias_mean=bm, bias_var=bv, rng=st.t, relu=True, out=out, split=SPLIT)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(N):
-        ops.lrt_gemm(x, ew, vw, I=I, O=O, bias_mean=bm, bias_var=bv, rng=st.t, relu=True, out=out)
+        ops.lrt_gemm(x, ew, vw, I=I, O=O, bias_mean=bm, bias_var=bv, rng=st.t, relu=True, out=out, split=SPLIT)
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / N
