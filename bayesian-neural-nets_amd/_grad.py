@@ -41,6 +41,41 @@ def _planar(z, tr):
     return z, logdet
 
 
+def _leaky(x, a=0.1):
+    return torch.where(x >= 0, x, a * x)
+
+
+def _dense(z, kind, tr, masks):
+    """RNVP (flows2.py:206-219) / MNF (flows2.py:233-241) flow on a 1-D z.
+    tr: list of parameter dicts keyed like the module's state_dict; masks: list of (I,) tensors."""
+    logdet = z.new_zeros(())
+    for t, m in zip(tr, masks):
+        if kind == "RNVP":
+            y = m * z
+            for li, idx in enumerate((0, 2, 4, 6)):
+                y = t["network.%d.weight" % idx] @ y + t["network.%d.bias" % idx]
+                if li < 3:
+                    y = _leaky(y)
+            shift = t["t.weight"] @ y + t["t.bias"]
+            gate = torch.sigmoid(t["s.weight"] @ y + t["s.bias"])
+            z = ((1 - m) * z) * gate + (1 - gate) * shift + m * z
+            logdet = logdet + ((1 - m) * gate.log()).sum()
+        else:
+            h = torch.tanh(t["f.weight"] @ (m * z) + t["f.bias"])
+            mu = t["g.weight"] @ h + t["g.bias"]
+            sig = torch.sigmoid(t["k.weight"] @ h + t["k.bias"])
+            z = m * z + (1 - m) * (z * sig + (1 - sig) * mu)
+            logdet = logdet + ((1 - m) * sig.log()).sum()
+    return z, logdet
+
+
+def _flow(z, spec, masks):
+    kind, tr = spec
+    if kind == "Planar":
+        return _planar(z, tr)
+    return _dense(z, kind, tr, masks)
+
+
 def lrt_torch(x, P, noise, *, stochastic, want_kl, priors, relu):
     """LBBNN-GP-MF-LRT.py:166-197 as differentiable torch ops. P: dict of tensors."""
     alpha = _alpha(P["lambdal"])
@@ -61,13 +96,14 @@ def lrt_torch(x, P, noise, *, stochastic, want_kl, priors, relu):
 
 
 def mnf_planar_torch(x, P, zf, rf, noise, *, stochastic, want_kl, priors, relu):
-    """LBBNN-GP-MF-MNF.py:190-239 with planar flows, only the kept z row.
+    """LBBNN-GP-MF-MNF.py:190-239, only the kept z row.
 
-    zf / rf: lists of (u, w, bias) tensors.  noise: eps_z (I,), eps_out (B,O), eps_z2 (I,), eps_act (O,).
+    zf / rf: (kind, transforms): planar -> list of (u, w, bias); RNVP/MNF -> list of parameter dicts.
+    noise: eps_z (I,), eps_out (B,O), eps_z2 (I,), eps_act (O,) [+ zmask / zmask2 / rmask lists of (I,)].
     """
     alpha = _alpha(P["lambdal"])
     q0_std = P["q0_log_var"].exp().sqrt()
-    z_k, _ = _planar(P["q0_mean"] + q0_std * noise["eps_z"], zf)
+    z_k, _ = _flow(P["q0_mean"] + q0_std * noise["eps_z"], zf, noise.get("zmask"))
     e_w = P["weight_mu"] * alpha
     out = (x * z_k) @ e_w.T + P["bias_mu"]
     sigma = None
@@ -81,7 +117,7 @@ def mnf_planar_torch(x, P, zf, rf, noise, *, stochastic, want_kl, priors, relu):
     if want_kl:
         sigma = _sigma(P["weight_rho"]) if sigma is None else sigma
         z0 = P["q0_mean"] + q0_std * noise["eps_z2"]
-        z2, log_det_q = _planar(z0, zf)
+        z2, log_det_q = _flow(z0, zf, noise.get("zmask2"))
         log_q0 = (-0.5 * math.log(math.pi) - 0.5 * P["q0_log_var"]
                   - 0.5 * ((z0 - P["q0_mean"]) ** 2 / P["q0_log_var"].exp())).sum()
         log_q = -log_det_q + log_q0
@@ -93,7 +129,7 @@ def mnf_planar_torch(x, P, zf, rf, noise, *, stochastic, want_kl, priors, relu):
         m = act.mean()
         mean_r = P["r0_b1"] * m
         log_var_r = P["r0_b2"] * m
-        z_b, log_det_r = _planar(z2, rf)
+        z_b, log_det_r = _flow(z2, rf, noise.get("rmask"))
         log_rb = (-0.5 * math.log(math.pi) - 0.5 * log_var_r
                   - 0.5 * ((z_b[-1] - mean_r) ** 2 / log_var_r.exp())).sum()
         log_r = log_det_r + log_rb

@@ -48,6 +48,13 @@ class LayerDesc(ctypes.Structure):
                 ("kl_rows", c_p), ("act_mu", c_p), ("act_var", c_p), ("bias_var", c_p), ("kl_layer", c_p)]
 
 
+class DenseTransform(ctypes.Structure):
+    """lbbnn_dense_transform_t"""
+    _fields_ = [("kind", c_i), ("hidden", c_i), ("w_in", c_p), ("b_in", c_p),
+                ("w_mid", c_p * 3), ("b_mid", c_p * 3), ("w_a", c_p), ("b_a", c_p), ("w_b", c_p), ("b_b", c_p),
+                ("mask_fwd", c_p), ("mask_kl", c_p)]
+
+
 # name -> (restype, argtypes); must list every symbol include/lbbnn.h declares
 SIGNATURES = {
     "lbbnn_abi_version": (c_i, []),
@@ -59,6 +66,9 @@ SIGNATURES = {
                              c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "lbbnn_mnf_flow_planar": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p,
                                     c_p, c_u32, c_p, c_p, c_p, c_i, c_i, c_p]),
+    "lbbnn_flow_dense_workspace": (c_i64, [c_i]),
+    "lbbnn_mnf_flow_dense": (c_i, [c_p, c_p, ctypes.POINTER(DenseTransform), c_i, ctypes.POINTER(DenseTransform), c_i,
+                                   c_p, c_p, c_p, c_u32, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
     "lbbnn_kl_finalize": (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p,
                                 ctypes.POINTER(Priors), c_p, c_u32, c_p, c_p, c_i, c_p]),
     "lbbnn_layers_prepare": (c_i, [ctypes.POINTER(LayerDesc), c_i, c_p, c_p]),

@@ -76,6 +76,35 @@ class PropagateFlow(nn.Module):
     def planar_params(self):
         return [(t.u, t.w, t.bias) for t in self.transforms]
 
+    def dense_descs(self, masks_fwd, masks_kl):
+        """ctypes array of lbbnn_dense_transform_t for an RNVP / MNF flow; masks: lists of (dim,) {0,1} tensors
+        (or None) for the forward-draw call and the KL-branch call.  Returns (array, T, keepalive)."""
+        from . import _lib
+        T = len(self.transforms)
+        arr = (_lib.DenseTransform * max(T, 1))()
+        keep = []
+        for t, tr in enumerate(self.transforms):
+            d = arr[t]
+            if self.kind == "RNVP":
+                lin = [tr.network[0], tr.network[2], tr.network[4], tr.network[6]]
+                d.kind, d.hidden = 0, lin[0].out_features
+                d.w_in, d.b_in = lin[0].weight.data_ptr(), lin[0].bias.data_ptr()
+                for l in range(3):
+                    d.w_mid[l], d.b_mid[l] = lin[l + 1].weight.data_ptr(), lin[l + 1].bias.data_ptr()
+                d.w_a, d.b_a, d.w_b, d.b_b = (tr.t.weight.data_ptr(), tr.t.bias.data_ptr(),
+                                              tr.s.weight.data_ptr(), tr.s.bias.data_ptr())
+            else:
+                d.kind, d.hidden = 1, tr.f.out_features
+                d.w_in, d.b_in = tr.f.weight.data_ptr(), tr.f.bias.data_ptr()
+                d.w_a, d.b_a, d.w_b, d.b_b = (tr.g.weight.data_ptr(), tr.g.bias.data_ptr(),
+                                              tr.k.weight.data_ptr(), tr.k.bias.data_ptr())
+            for name, ms in (("mask_fwd", masks_fwd), ("mask_kl", masks_kl)):
+                if ms is not None:
+                    m = ms[t].reshape(-1).contiguous().float()
+                    keep.append(m)
+                    setattr(d, name, m.data_ptr())
+        return arr, T, keep
+
     def forward(self, z):
         """Stand-alone flow on a 1-D z (what ``r_flow(z2)`` does at LBBNN-GP-MF-MNF.py:222)."""
         if self.kind != "Planar":

@@ -89,6 +89,7 @@ class _BayesLinearBase(nn.Module):
         self._layer_id = next(_layer_ids) % 64
         self._ws = None
         self._split_now = False        # decided per forward (prep and GEMM must agree on the operand format)
+        self._last_masks = None
 
     # reference keeps the prior tensors as attributes; expose them lazily with the same names
     @property
@@ -130,6 +131,9 @@ class _BayesLinearBase(nn.Module):
     def _param_list(self):
         raise NotImplementedError
 
+    def _fusable(self):
+        return True
+
     def _fill_desc(self, d, cfg, kl_layer):
         """Fill one lbbnn_layer_desc_t for lbbnn_layers_prepare (pointers into parameters / workspace)."""
         ws = self._workspace()
@@ -157,7 +161,9 @@ class _BayesLinearBase(nn.Module):
             saved["rng"] = rng.clone() if save_rng else None
         kl = torch.empty((), dtype=torch.float32, device=x.device) if cfg[1] else None
         self._split_now = self._split(x)
+        self._last_masks = None
         self._prep(cfg, rng, kl_layer=kl)
+        saved["masks"] = self._last_masks
         out = self._gemm(x, cfg, rng)
         if st is not None and advance:
             st.advance(1)
@@ -256,26 +262,59 @@ class MNFBayesianLinear(_BayesLinearBase):
         return ps
 
     def _check_flows(self):
-        if self.z_flow.kind != "Planar" or self.r_flow.kind != "Planar":
-            raise NotImplementedError("bnn_amd: MNF layer forward has HIP kernels for planar flows only in this "
-                                      "build (got z=%s, r=%s)" % (self.z_flow.kind, self.r_flow.kind))
+        """'planar' (K3) or 'dense' (K4: RNVP / MNF-type coupling flows); mixing the two families is not built."""
+        zp, rp = self.z_flow.kind == "Planar", self.r_flow.kind == "Planar"
+        if zp != rp:
+            raise NotImplementedError("bnn_amd: z_flow=%s with r_flow=%s: planar and dense flows cannot be mixed in "
+                                      "one layer in this build" % (self.z_flow.kind, self.r_flow.kind))
+        return "planar" if zp else "dense"
+
+    def _masks(self, cfg, B):
+        """Bernoulli(0.5) masks of the dense flows (flows2.py:209,234): from layer.noise or drawn on the device."""
+        noise = self.noise or {}
+        T = len(self.z_flow.transforms)
+        dev, I = self.q0_mean.device, self.in_features
+
+        def draw(n):
+            return [torch.bernoulli(torch.full((I,), 0.5, device=dev)) for _ in range(n)]
+        zm = [m[-1] if m.dim() == 2 else m for m in noise["zmask"]] if "zmask" in noise else draw(T)
+        out = {"zmask": zm}
+        if cfg[1]:
+            out["zmask2"] = [m.reshape(-1) for m in noise["zmask2"]] if "zmask2" in noise else draw(T)
+            out["rmask"] = [m.reshape(-1) for m in noise["rmask"]] if "rmask" in noise else draw(len(self.r_flow.transforms))
+        return out
 
     def sample_z(self, batch_size=1):
         """LBBNN-GP-MF-MNF.py:182-187: returns (z_flow(z0)[-1], logdet) -- only the kept row is computed."""
-        self._check_flows()
-        ws = self._workspace()
         st = ops.RngState.get(self.q0_mean.device)
         with torch.no_grad():
-            ops.mnf_flow_planar(self.q0_mean, self.q0_log_var, self.z_flow.planar_params(), [], rng=st.t,
-                                layer_id=self._layer_id, z_fwd=ws.z_fwd, scal=ws.scal, want_kl=False)
+            self._prep_flows_only(st.t)
             st.advance(1)
+        ws = self._workspace()
         return ws.z_fwd.clone(), ws.scal[4].clone()
+
+    def _prep_flows_only(self, rng):
+        ws = self._workspace()
+        if self._check_flows() == "planar":
+            ops.mnf_flow_planar(self.q0_mean, self.q0_log_var, self.z_flow.planar_params(), [], rng=rng,
+                                layer_id=self._layer_id, z_fwd=ws.z_fwd, scal=ws.scal, want_kl=False)
+        else:
+            masks = self._masks((True, False, False), 0)
+            zd, Tz, keep = self.z_flow.dense_descs(masks["zmask"], None)
+            if getattr(ws, "flow_work", None) is None:
+                ws.flow_work = torch.empty(ops.flow_dense_workspace(self.in_features), dtype=torch.float32,
+                                           device=self.q0_mean.device)
+            ops.mnf_flow_dense(self.q0_mean, self.q0_log_var, zd, Tz, None, 0, rng=rng, layer_id=self._layer_id,
+                               z_fwd=ws.z_fwd, scal=ws.scal, work=ws.flow_work, want_kl=False)
+            del keep
 
     def _needed_noise(self, cfg):
         return ["eps_z"] + (["eps_out"] if cfg[0] else []) + (["eps_z2", "eps_act"] if cfg[1] else [])
 
+    def _fusable(self):
+        return self._check_flows() == "planar"
+
     def _fill_desc(self, d, cfg, kl_layer):
-        self._check_flows()
         ws, noise = super()._fill_desc(d, cfg, kl_layer)
         for name in ("q0_mean", "q0_log_var", "r0_c", "r0_b1", "r0_b2"):
             setattr(d, name, getattr(self, name).data_ptr())
@@ -312,7 +351,7 @@ class MNFBayesianLinear(_BayesLinearBase):
         """x-independent kernels: K3 flows, K1 weight pass, K5 KL finalize (``finalize=False`` defers K5
         to ``_finalize`` so a network can keep it off the critical path)."""
         stochastic, want_kl, _ = cfg
-        self._check_flows()
+        family = self._check_flows()
         ws = self._workspace()
         noise = self.noise or {}
         eps_z = noise.get("eps_z")
@@ -321,12 +360,25 @@ class MNFBayesianLinear(_BayesLinearBase):
         eps_z2 = noise.get("eps_z2")
         if eps_z2 is not None:
             eps_z2 = eps_z2.reshape(-1)
-        ops.mnf_flow_planar(self.q0_mean, self.q0_log_var, self.z_flow.planar_params(),
-                            self.r_flow.planar_params(),
-                            eps_fwd=None if eps_z is None else eps_z.contiguous(),
-                            eps_kl=None if eps_z2 is None else eps_z2.contiguous(),
-                            rng=rng, layer_id=self._layer_id, z_fwd=ws.z_fwd, z_kl=ws.z_kl, scal=ws.scal,
-                            want_kl=want_kl)
+        eps_z = None if eps_z is None else eps_z.contiguous()
+        eps_z2 = None if eps_z2 is None else eps_z2.contiguous()
+        if family == "planar":
+            ops.mnf_flow_planar(self.q0_mean, self.q0_log_var, self.z_flow.planar_params(),
+                                self.r_flow.planar_params(), eps_fwd=eps_z, eps_kl=eps_z2,
+                                rng=rng, layer_id=self._layer_id, z_fwd=ws.z_fwd, z_kl=ws.z_kl, scal=ws.scal,
+                                want_kl=want_kl)
+        else:
+            masks = self._masks(cfg, 0)
+            self._last_masks = masks
+            zd, Tz, k1 = self.z_flow.dense_descs(masks["zmask"], masks.get("zmask2"))
+            rd, Tr, k2 = self.r_flow.dense_descs(None, masks.get("rmask")) if want_kl else (None, 0, None)
+            if getattr(ws, "flow_work", None) is None:
+                ws.flow_work = torch.empty(ops.flow_dense_workspace(self.in_features), dtype=torch.float32,
+                                           device=self.q0_mean.device)
+            ops.mnf_flow_dense(self.q0_mean, self.q0_log_var, zd, Tz, rd, Tr, eps_fwd=eps_z, eps_kl=eps_z2,
+                               rng=rng, layer_id=self._layer_id, z_fwd=ws.z_fwd, z_kl=ws.z_kl, scal=ws.scal,
+                               work=ws.flow_work, want_kl=want_kl)
+            del k1, k2
         ops.weight_pass(self.weight_mu, self.weight_rho, self.lambdal, z_fwd=ws.z_fwd,
                         z_kl=ws.z_kl if want_kl else None, r0_c=self.r0_c if want_kl else None,
                         bias_rho=self.bias_rho, priors=self.priors, e_w=ws.e_w,
@@ -354,27 +406,41 @@ class MNFBayesianLinear(_BayesLinearBase):
                             log_softmax=log_softmax, split=self._split_now)
 
     def _noise_for_backward(self, saved, B):
+        masks = saved.get("masks") or {}
         if saved.get("noise"):
             n = dict(saved["noise"])
             if n["eps_z"].dim() == 2:
                 n["eps_z"] = n["eps_z"][-1]
             if "eps_z2" in n:
                 n["eps_z2"] = n["eps_z2"].reshape(-1)
+            n.update(masks)
             return n
         r, L, I, O = saved["rng"], self._layer_id, self.in_features, self.out_features
-        return {"eps_out": ops.philox_normal(r, ops.STREAM_EPS_OUT * 64 + L, B, O, self.row_offset),
-                "eps_z": ops.philox_normal(r, ops.STREAM_EPS_Z * 64 + L, 0, I),
-                "eps_z2": ops.philox_normal(r, ops.STREAM_EPS_Z2 * 64 + L, 0, I),
-                "eps_act": ops.philox_normal(r, ops.STREAM_EPS_ACT * 64 + L, 0, O)}
+        n = {"eps_out": ops.philox_normal(r, ops.STREAM_EPS_OUT * 64 + L, B, O, self.row_offset),
+             "eps_z": ops.philox_normal(r, ops.STREAM_EPS_Z * 64 + L, 0, I),
+             "eps_z2": ops.philox_normal(r, ops.STREAM_EPS_Z2 * 64 + L, 0, I),
+             "eps_act": ops.philox_normal(r, ops.STREAM_EPS_ACT * 64 + L, 0, O)}
+        n.update(masks)
+        return n
 
     def _forward_torch(self, x, ps, cfg, noise):
         n = len(self._names)
         P = dict(zip(self._names, ps[:n]))
-        rest = ps[n:]
-        T = len(self.z_flow.transforms)
-        zf = [tuple(rest[3 * t:3 * t + 3]) for t in range(T)]
-        rf = [tuple(rest[3 * T + 3 * t:3 * T + 3 * t + 3]) for t in range(len(self.r_flow.transforms))]
-        return _grad.mnf_planar_torch(x, P, zf, rf, noise, stochastic=cfg[0], want_kl=cfg[1],
+        rest = list(ps[n:])
+        specs = []
+        for flow in (self.z_flow, self.r_flow):
+            if flow.kind == "Planar":
+                T = len(flow.transforms)
+                specs.append(("Planar", [tuple(rest[3 * t:3 * t + 3]) for t in range(T)]))
+                rest = rest[3 * T:]
+            else:
+                trs = []
+                for tr in flow.transforms:
+                    names = [k for k, _ in tr.named_parameters()]
+                    trs.append(dict(zip(names, rest[:len(names)])))
+                    rest = rest[len(names):]
+                specs.append((flow.kind, trs))
+        return _grad.mnf_planar_torch(x, P, specs[0], specs[1], noise, stochastic=cfg[0], want_kl=cfg[1],
                                       priors=self.priors, relu=cfg[2])
 
 
@@ -397,7 +463,7 @@ class _NetworkBase(nn.Module):
         x = x.view(-1, self.dims[0])                                  # …LRT.py:207
         layers = self._layers()
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
-        if needs_grad or not x.is_cuda:
+        if needs_grad or not x.is_cuda or not all(l._fusable() for l in layers):
             self._kl_total = None
             for i, l in enumerate(layers):
                 x = l.forward(x, sample, _relu=(i < 2))               # F.relu fused into the GEMM epilogue

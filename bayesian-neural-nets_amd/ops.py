@@ -203,6 +203,24 @@ def mnf_flow_planar(q0_mean, q0_log_var, z_params, r_params, *, eps_fwd=None, ep
     _lib.check(rc, "lbbnn_mnf_flow_planar")
 
 
+# ----------------------------------------------------------------------------------------- K4
+def mnf_flow_dense(q0_mean, q0_log_var, z_descs, Tz, r_descs, Tr, *, eps_fwd=None, eps_kl=None,
+                   rng: Optional[torch.Tensor] = None, layer_id: int = 0, z_fwd, z_kl=None, scal=None, work=None,
+                   want_kl: bool = True):
+    """lbbnn_mnf_flow_dense.  z_descs / r_descs: ctypes arrays of _lib.DenseTransform (see flows.dense_descs)."""
+    I = q0_mean.shape[0]
+    rc = _lib.lib().lbbnn_mnf_flow_dense(
+        _ptr(q0_mean, "q0_mean"), _ptr(q0_log_var, "q0_log_var"),
+        z_descs, Tz, r_descs, Tr,
+        _ptr(eps_fwd), _ptr(eps_kl), rng.data_ptr() if rng is not None else None, layer_id,
+        _ptr(z_fwd), _ptr(z_kl), _ptr(scal), _ptr(work), I, 1 if want_kl else 0, _stream())
+    _lib.check(rc, "lbbnn_mnf_flow_dense")
+
+
+def flow_dense_workspace(I: int) -> int:
+    return int(_lib.lib().lbbnn_flow_dense_workspace(I))
+
+
 # ----------------------------------------------------------------------------------------- K5
 def kl_finalize(kl_rows, bias_mu, bias_rho, *, priors: Priors, act_mu=None, act_var=None, eps_act=None,
                 r0_b1=None, r0_b2=None, scal=None, rng: Optional[torch.Tensor] = None, layer_id: int = 0,

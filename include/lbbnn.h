@@ -138,6 +138,46 @@ int lbbnn_mnf_flow_planar(const float* q0_mean, const float* q0_log_var,
                           float* z_fwd, float* z_kl, float* scal,
                           int I, int want_kl, void* stream);
 
+
+/* ---------------------------------------------------------------------------------------------
+ * K4  lbbnn_mnf_flow_dense -- z sampling + dense coupling flows (RNVP / MNF type) of one MNF layer.
+ *
+ * Same outputs as lbbnn_mnf_flow_planar (z_fwd, z_kl, scal[0..4]) for the reference's default flow
+ * types: RNVP (flows2.py:188-219: mask, 4-layer LeakyReLU(0.1) MLP I->75->75->75->75, t/s heads,
+ * sigmoid gate, Sum (1-m) log gate) and MNF (flows2.py:225-241: mask, tanh(f(m z)) 100 hidden units,
+ * g/k heads, Sum (1-m) log sigma).  Only the kept row (zs[-1]) is computed, so every dense step is a
+ * GEMV; per transform: one launch spreads the I-long dot products of the hidden units over
+ * workgroups, one launch produces the I outputs (recomputing the tiny H x H chain per workgroup) and
+ * per-workgroup log-det partials that are summed in a fixed order (deterministic).
+ *
+ * Bernoulli(0.5) masks (flows2.py:209,234) are explicit inputs (the host wrapper draws them):
+ * mask_fwd = the forward draw's z_flow call, mask_kl = the KL branch's z_flow / r_flow call.
+ * work: caller-owned scratch of lbbnn_flow_dense_workspace(I) floats.
+ */
+#define LBBNN_FLOW_RNVP 0
+#define LBBNN_FLOW_MNF 1
+#define LBBNN_MAX_HIDDEN 128
+
+typedef struct lbbnn_dense_transform {
+    int kind;                               /* LBBNN_FLOW_RNVP / LBBNN_FLOW_MNF                         */
+    int hidden;                             /* 75 (RNVP) / 100 (MNF); <= LBBNN_MAX_HIDDEN               */
+    const float *w_in, *b_in;               /* (H,I),(H): RNVP network.0 | MNF f                        */
+    const float *w_mid[3], *b_mid[3];       /* (H,H),(H): RNVP network.2/4/6 | NULL for MNF             */
+    const float *w_a, *b_a;                 /* (I,H),(I): RNVP t (shift) | MNF g (mu)                   */
+    const float *w_b, *b_b;                 /* (I,H),(I): RNVP s (scale) | MNF k (sigma pre-activation) */
+    const float *mask_fwd, *mask_kl;        /* (I) each, values in {0,1}                                */
+} lbbnn_dense_transform_t;
+
+int64_t lbbnn_flow_dense_workspace(int I);
+
+int lbbnn_mnf_flow_dense(const float* q0_mean, const float* q0_log_var,
+                         const lbbnn_dense_transform_t* zt, int Tz,
+                         const lbbnn_dense_transform_t* rt, int Tr,
+                         const float* eps_fwd, const float* eps_kl,
+                         const uint64_t* rng, uint32_t layer_id,
+                         float* z_fwd, float* z_kl, float* scal, float* work,
+                         int I, int want_kl, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K5  lbbnn_kl_finalize -- the O(O+I) tail of the KL and the final scalar.
  *

@@ -367,8 +367,10 @@ def test_error_paths(bnn, dev):
     with pytest.raises(RuntimeError, match="noise"):
         ops.lrt_gemm(x, w, w, I=8, O=4)                                                          # no eps, no rng
     with pytest.raises(NotImplementedError):
-        l = bnn.mnf.BayesianLinear(8, 4, 2).to(dev)                                              # RNVP default
+        l = bnn.mnf.BayesianLinear(8, 4, 2, z_flow_type="Planar", r_flow_type="RNVP").to(dev)   # mixed families
         l(x)
+    with pytest.raises(NotImplementedError):
+        bnn.flows.PropagateFlow("Sylvester", 8, 2)
 
 
 # --------------------------------------------------------------------------- scheduling variants
@@ -495,3 +497,82 @@ def test_split_headline_network_vs_oracle(bnn, dev):
     assert e < TOL, e
     assert rel_err(kl, ref_kl) < TIGHT          # KL never touches the reduced-precision operands
     assert torch.isfinite(out2).all()
+
+
+# --------------------------------------------------------------------------- dense coupling flows (RNVP / MNF type)
+@pytest.mark.parametrize("case", ["c4", "c5", "c6", "c7"])
+def test_mnf_layer_dense_flows_vs_golden(bnn, dev, golden, case):
+    """The reference's DEFAULT flow type (RNVP, LBBNN-GP-MF-MNF.py:46-47) and the MNF-type flow."""
+    c = golden("mnf.npz").case(case)
+    B, I, O, T = [int(v) for v in c["shape"]]
+    kind = str(c["kind"])
+    assert kind in ("RNVP", "MNF")
+    layer = _load_layer(bnn.mnf.BayesianLinear(I, O, T, z_flow_type=kind, r_flow_type=kind), sub(c, "p."), dev)
+    x = c["x"].to(dev)
+    with torch.no_grad():
+        layer.train()
+        n = {k: c[k].to(dev) for k in ("eps_z", "eps_out", "eps_z2", "eps_act")}
+        n["zmask"] = [c["zmask%d" % t].to(dev) for t in range(T)]
+        n["zmask2"] = [c["zmask2_%d" % t].to(dev) for t in range(T)]
+        n["rmask"] = [c["rmask%d" % t].to(dev) for t in range(T)]
+        layer.noise = n
+        out = layer(x, sample=True)
+        assert rel_err(out, c["out_train"]) < TIGHT
+        assert rel_err(layer.kl, c["kl"]) < TIGHT
+        layer.eval()
+        layer.noise = {"eps_z": c["eps_z_eval"].to(dev), "zmask": [c["zmask_eval%d" % t].to(dev) for t in range(T)]}
+        out = layer(x, sample=False)
+        assert rel_err(out, c["out_eval_mean"]) < TIGHT
+        # default construction (RNVP, in-kernel noise, device-drawn masks) runs and is finite
+        layer.noise = None
+        layer.train()
+        out = layer(x, sample=True)
+        assert torch.isfinite(out).all() and torch.isfinite(layer.kl)
+        z, ld = layer.sample_z(B)
+        assert z.shape == (I,) and torch.isfinite(z).all() and torch.isfinite(ld)
+
+
+def test_dense_flow_backward_matches_oracle_autograd(bnn, dev, golden):
+    c = golden("mnf.npz").case("c5")           # RNVP, (5,33,17), T=2
+    B, I, O, T = [int(v) for v in c["shape"]]
+    p = sub(c, "p.")
+    layer = _load_layer(bnn.mnf.BayesianLinear(I, O, T), p, dev).train()
+    noise = {k: c[k] for k in ("eps_z", "eps_out", "eps_z2", "eps_act")}
+    noise["zmask"] = [c["zmask%d" % t] for t in range(T)]
+    noise["zmask2"] = [c["zmask2_%d" % t] for t in range(T)]
+    noise["rmask"] = [c["rmask%d" % t] for t in range(T)]
+    layer.noise = {k: ([m.to(dev) for m in v] if isinstance(v, list) else v.to(dev)) for k, v in noise.items()}
+    x = c["x"].to(dev).requires_grad_(True)
+    out = layer(x, sample=True)
+    ((out ** 2).sum() + layer.kl / 600).backward()
+    pc = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    xc = c["x"].clone().requires_grad_(True)
+    zf = orc.flow_from_state("z_flow", "RNVP", pc, T)
+    rf = orc.flow_from_state("r_flow", "RNVP", pc, T)
+    o, kl, _ = orc.mnf_forward(xc, pc, zf, rf, noise)
+    ((o ** 2).sum() + kl / 600).backward()
+    assert rel_err(x.grad, xc.grad) < TOL
+    for name, prm in layer.named_parameters():
+        assert rel_err(prm.grad, pc[name].grad) < 5e-4, name     # tiny gradients through the 4-layer MLP: looser
+
+
+def test_reference_default_network_trains(bnn, dev):
+    """BayesianNetwork() exactly as the reference constructs it (RNVP flows, 784-400-600-10) takes SGD steps."""
+    torch.manual_seed(0)
+    net = bnn.mnf.BayesianNetwork().to(dev)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    data = torch.rand(16, 1, 28, 28, device=dev)
+    target = torch.randint(0, 10, (16,), device=dev)
+    net.train()
+    vals = []
+    for _ in range(3):
+        net.zero_grad()
+        loss = torch.nn.functional.nll_loss(net(data, sample=True), target, reduction="sum") + net.kl() / 600
+        loss.backward()
+        opt.step()
+        vals.append(float(loss.detach()))
+    assert all(math.isfinite(v) for v in vals)
+    with torch.no_grad():
+        net.eval()
+        out = net(data, sample=False)
+    assert out.shape == (16, 10) and torch.isfinite(out).all()
