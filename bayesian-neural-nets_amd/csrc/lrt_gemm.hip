@@ -43,6 +43,18 @@ struct GemmArgs {
     int relu, log_softmax;
 };
 
+// XCD-aware tile assignment (cdna guide T1).  Workgroups are dealt round-robin over the 8 XCDs, each with
+// its own L2; with the natural order the 15 workgroups that share one x tile land on 8 different L2s.
+// Remap the linear id so that each XCD owns a contiguous run of tiles in (b-tile major, o-tile minor)
+// order: an XCD then works on ~4 x tiles x all W tiles and every x tile is fetched into ONE L2.
+// Bijective when the grid size is a multiple of 8 (identity otherwise).  Speed only, never correctness.
+__device__ __forceinline__ void tile_of_block(int& ox, int& by) {
+    const int nx = gridDim.x, n = gridDim.x * gridDim.y;
+    int t = blockIdx.y * nx + blockIdx.x;
+    if ((n & 7) == 0) t = (t & 7) * (n >> 3) + (t >> 3);
+    ox = t % nx; by = t / nx;
+}
+
 struct EpiCtx { bool ovec; uint64_t seed, offs; };
 
 template <bool MEAN_ONLY>
@@ -316,8 +328,10 @@ __global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_f32_dma_kernel(const Gemm
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, q = lane >> 4;
-    const int o0 = blockIdx.x * BN;
-    const int b0 = blockIdx.y * BM;
+    int tox, tby;
+    tile_of_block(tox, tby);
+    const int o0 = tox * BN;
+    const int b0 = tby * BM;
 
     // ---- per-lane DMA sources: group g = wv + WB*u covers image rows [16g, 16g+16); this lane feeds
     // row 16g + (lane>>2), LDS slot lane&3, i.e. global slot (lane&3) ^ F[(lane>>4)&3].
@@ -469,8 +483,10 @@ __global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_bf16x3_kernel(const GemmA
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, q = lane >> 4;
-    const int o0 = blockIdx.x * BN;
-    const int b0 = blockIdx.y * BM;
+    int tox, tby;
+    tile_of_block(tox, tby);
+    const int o0 = tox * BN;
+    const int b0 = tby * BM;
     const char* const eh = reinterpret_cast<const char*>(a.e_w);
     const char* const el = eh + (size_t)a.O * a.ld * 2;
     const char* const vh = reinterpret_cast<const char*>(a.var_w);
@@ -571,12 +587,13 @@ __global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_bf16x3_kernel(const GemmA
                 sl[j] = __builtin_bit_cast(bf16x8, make_uint4(ql[0], ql[1], ql[2], ql[3]));
             }
         }
+        // b-tile outer: the second tile's conversions can issue under the first tile's MFMAs
 #pragma unroll
-        for (int i = 0; i < TO; ++i) {
-            const bf16x8 ah = __builtin_bit_cast(bf16x8, wh[i]);
-            const bf16x8 al = __builtin_bit_cast(bf16x8, wl[i]);
+        for (int j = 0; j < TB; ++j) {
 #pragma unroll
-            for (int j = 0; j < TB; ++j) {
+            for (int i = 0; i < TO; ++i) {
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, wh[i]);
+                const bf16x8 al = __builtin_bit_cast(bf16x8, wl[i]);
                 accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh[j], accm[i][j], 0, 0, 0);
                 accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xh[j], accm[i][j], 0, 0, 0);
                 accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xl[j], accm[i][j], 0, 0, 0);
@@ -600,6 +617,239 @@ __global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_bf16x3_kernel(const GemmA
         mfmas();
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
+    }
+
+    const EpiCtx ec = make_epi_ctx<MEAN_ONLY>(a);
+#pragma unroll
+    for (int i = 0; i < TO; ++i) {
+        const int o = o0 + i * 16 + 4 * q;
+        if (o >= a.O) continue;
+        const OConst oc = load_oconst(a, o);
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            const int b = b0 + (wv * TB + j) * 16 + lr;
+            if (b >= a.B) continue;
+            float res[4];
+            epilogue4<MEAN_ONLY>(a, ec, oc, b, o, accm[i][j], accv[i][j], res);
+            store4(a, ec, b, o, res);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ring variant of the split-precision kernel: 256(b) x 80(o) tile, 8 waves, ONE workgroup per CU, and a
+// 3-buffer LDS ring (3 x 52 KB) with LDS-DMA running TWO K steps ahead.
+//
+// Why: with a 2-buffer scheme the DMA for step c+1 is issued at the top of step c and must have landed by
+// its end; measured alone, a workgroup spent 1.64 us per step for 0.4 us of MFMA work -- the L2->LDS
+// latency was exposed every step.  Here the DMA of step c+2 is issued during step c, so it has two full
+// steps to land.  The larger tile also cuts LDS fill per flop by 28 % (the W planes are shared by 256 rows).
+//
+// Synchronisation (cdna guide 5 "Pipelining across barriers"): each wave retires ITS OWN DMA of step c with
+// a COUNTED s_waitcnt vmcnt(n) that leaves the step-(c+1) DMA in flight, then ONE raw s_barrier makes every
+// wave's step-c image visible; fragments are read one phase after that wait; the DMA for step c+2 is issued
+// after the barrier, into the buffer whose last reads (step c-1) every wave completed before arriving.
+// hipcc would drain vmcnt(0) before any LDS read it can see while an LDS-DMA is pending, so the fragment
+// reads are inline-asm ds_read_b128 with their own lgkmcnt wait (+sched_barrier, guide 5.4 rule 18).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#define LBBNN_DS_READ128(dst, addr, off) \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off) : "memory")
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
+
+template <int TO, bool MEAN_ONLY, bool STAGGER = true>
+__global__ __launch_bounds__(512, 2) void lrt_gemm_bf16x3_ring_kernel(const GemmArgs a) {
+    constexpr int TB = 2, WB = 8;
+    constexpr int BN = TO * 16, BM = TB * WB * 16;       // 80 x 256
+    constexpr int NPL = MEAN_ONLY ? 2 : 4;
+    constexpr int XB = BM * 128;
+    constexpr int PB = BN * 64;
+    constexpr int BUFB = XB + NPL * PB;                  // 52 KB (full) / 41.5 KB (mean only)
+    constexpr int NGX = BM / 8, NGW = BN / 16;
+    constexpr int NG = NGX + NPL * NGW;
+    constexpr int NPW = (NG + WB - 1) / WB;              // DMA instructions per step of the "long" waves
+    constexpr int REM = NG % WB;                         // waves < REM issue NPW, the others NPW - 1 (REM == 0: all NPW)
+    extern __shared__ __attribute__((aligned(16))) char smc[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, q = lane >> 4;
+    int tox, tby;
+    tile_of_block(tox, tby);
+    const int o0 = tox * BN;
+    const int b0 = tby * BM;
+    const char* const eh = reinterpret_cast<const char*>(a.e_w);
+    const char* const el = eh + (size_t)a.O * a.ld * 2;
+    const char* const vh = reinterpret_cast<const char*>(a.var_w);
+    const char* const vl = vh + (size_t)a.O * a.ld * 2;
+    const char* const zsrc = eh + (size_t)a.I * 2;
+
+    const char* gp[NPW];
+    int adv[NPW], kx[NPW];
+#pragma unroll
+    for (int u = 0; u < NPW; ++u) {
+        const int g = wv + WB * u;
+        if (g < NGX) {
+            const int row = 8 * g + (lane >> 3);
+            const int slot = (lane & 7) ^ swzx(row & 15);
+            gp[u] = reinterpret_cast<const char*>(a.x + (size_t)min(b0 + row, a.B - 1) * a.ldx) + 16 * slot;
+            adv[u] = 128; kx[u] = 4 * slot;
+        } else {
+            const int gw = min(g, NG - 1) - NGX, pl = gw / NGW, row = 16 * (gw % NGW) + (lane >> 2);
+            const int slot = (lane & 3) ^ swz(row >> 2);
+            const char* base = pl == 0 ? eh : (pl == 1 ? el : (pl == 2 ? vh : vl));
+            gp[u] = base + ((size_t)min(o0 + row, a.O - 1) * a.ld) * 2 + 16 * slot;
+            adv[u] = 64; kx[u] = -1;
+        }
+    }
+    const int nsteps = (a.I + BKS - 1) / BKS;
+    const bool has_tail = (a.I % BKS) != 0;
+    auto dma_step = [&](int c) {
+        char* buf = smc + (c % 3) * BUFB;
+        const bool tail = has_tail && c == nsteps - 1;
+#pragma unroll
+        for (int u = 0; u < NPW; ++u) {
+            const int g = wv + WB * u;                   // wave-uniform
+            if (g < NG) {
+                const char* src = gp[u] + (size_t)c * adv[u];
+                if (tail && kx[u] >= 0 && c * BKS + kx[u] >= a.I) src = zsrc;
+                const int loff = g < NGX ? g * 1024 : XB + (g - NGX) * 1024;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(buf + loff), 16, 0, 0);
+            }
+        }
+    };
+    const bool long_wave = (REM == 0) || (wv < REM);
+
+    floatx4 accm[TO][TB], accv[TO][TB];
+#pragma unroll
+    for (int i = 0; i < TO; ++i)
+#pragma unroll
+        for (int j = 0; j < TB; ++j) { accm[i][j] = floatx4{0.f, 0.f, 0.f, 0.f}; accv[i][j] = floatx4{0.f, 0.f, 0.f, 0.f}; }
+
+    // LDS byte addresses of this lane's fragments inside buffer 0 (the dynamic region starts at LDS address 0)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smc;
+    const int gx = swzx(lr);
+    const uint32_t xa0 = lds0 + (wv * TB * 16 + lr) * 128 + 16 * ((2 * q) ^ gx);
+    const uint32_t xa1 = lds0 + (wv * TB * 16 + lr) * 128 + 16 * ((2 * q + 1) ^ gx);
+    const uint32_t wa = lds0 + XB + lr * 64 + 16 * (q ^ swz(lr >> 2));
+
+    // Fragment registers live across the barrier for the staggered half (see below)
+    u32x4 xr[TB][2], wh[TO], wl[TO], wvh[TO], wvl[TO];
+    bf16x8 xh[TB], xl[TB], sh[TB], sl[TB];
+
+    auto retire = [&](int c) {       // my DMA of step c has landed (step c+1's may stay in flight); then everyone's
+        if (c + 1 < nsteps) { if (long_wave) wait_vmcnt<NPW>(); else wait_vmcnt<(NPW > 1 ? NPW - 1 : 0)>(); }
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+    };
+    auto read_frags = [&](int c) {   // inline asm: invisible to hipcc's LDS-DMA alias waits
+        const uint32_t bo = (uint32_t)((c % 3) * BUFB);
+        const uint32_t x0 = xa0 + bo, x1 = xa1 + bo, w0 = wa + bo;
+        LBBNN_DS_READ128(xr[0][0], x0, 0);
+        LBBNN_DS_READ128(xr[0][1], x1, 0);
+        LBBNN_DS_READ128(xr[1][0], x0, 16 * 128);
+        LBBNN_DS_READ128(xr[1][1], x1, 16 * 128);
+#pragma unroll
+        for (int i = 0; i < TO; ++i) {
+            LBBNN_DS_READ128(wh[i], w0, i * 1024);
+            LBBNN_DS_READ128(wl[i], w0, PB + i * 1024);
+            if (!MEAN_ONLY) {
+                LBBNN_DS_READ128(wvh[i], w0, 2 * PB + i * 1024);
+                LBBNN_DS_READ128(wvl[i], w0, 3 * PB + i * 1024);
+            }
+        }
+    };
+    auto wait_frags = [&]() {        // every destination is named so no use can be scheduled above the wait
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xr[0][0]), "+v"(xr[0][1]), "+v"(xr[1][0]), "+v"(xr[1][1]) :: "memory");
+#pragma unroll
+        for (int i = 0; i < TO; ++i) {
+            asm volatile("" : "+v"(wh[i]), "+v"(wl[i]) :: "memory");
+            if (!MEAN_ONLY) asm volatile("" : "+v"(wvh[i]), "+v"(wvl[i]) :: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto convert = [&]() {           // split x and x^2 into bf16 hi/lo
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            const float v[8] = {__uint_as_float(xr[j][0][0]), __uint_as_float(xr[j][0][1]), __uint_as_float(xr[j][0][2]),
+                                __uint_as_float(xr[j][0][3]), __uint_as_float(xr[j][1][0]), __uint_as_float(xr[j][1][1]),
+                                __uint_as_float(xr[j][1][2]), __uint_as_float(xr[j][1][3])};
+            uint32_t ph[4], pl[4], qh[4], ql[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint32_t u0 = __float_as_uint(v[2 * t]), u1 = __float_as_uint(v[2 * t + 1]);
+                ph[t] = __builtin_amdgcn_perm(u1, u0, 0x07060302);
+                const floatx2 lo = {v[2 * t] - __uint_as_float(u0 & 0xFFFF0000u), v[2 * t + 1] - __uint_as_float(u1 & 0xFFFF0000u)};
+                pl[t] = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2));
+                if (!MEAN_ONLY) {
+                    const float s0 = v[2 * t] * v[2 * t], s1 = v[2 * t + 1] * v[2 * t + 1];
+                    const uint32_t y0 = __float_as_uint(s0), y1 = __float_as_uint(s1);
+                    qh[t] = __builtin_amdgcn_perm(y1, y0, 0x07060302);
+                    const floatx2 slo = {s0 - __uint_as_float(y0 & 0xFFFF0000u), s1 - __uint_as_float(y1 & 0xFFFF0000u)};
+                    ql[t] = __builtin_bit_cast(uint32_t, __builtin_convertvector(slo, bf16x2));
+                }
+            }
+            xh[j] = __builtin_bit_cast(bf16x8, u32x4{ph[0], ph[1], ph[2], ph[3]});
+            xl[j] = __builtin_bit_cast(bf16x8, u32x4{pl[0], pl[1], pl[2], pl[3]});
+            if (!MEAN_ONLY) {
+                sh[j] = __builtin_bit_cast(bf16x8, u32x4{qh[0], qh[1], qh[2], qh[3]});
+                sl[j] = __builtin_bit_cast(bf16x8, u32x4{ql[0], ql[1], ql[2], ql[3]});
+            }
+        }
+    };
+    auto mfmas = [&]() {             // 6 MFMAs per (o-tile, b-tile)
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+#pragma unroll
+            for (int i = 0; i < TO; ++i) {
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, wh[i]);
+                const bf16x8 al = __builtin_bit_cast(bf16x8, wl[i]);
+                accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh[j], accm[i][j], 0, 0, 0);
+                accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xh[j], accm[i][j], 0, 0, 0);
+                accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xl[j], accm[i][j], 0, 0, 0);
+                if (!MEAN_ONLY) {
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, wvh[i]);
+                    accv[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, sh[j], accv[i][j], 0, 0, 0);
+                    accv[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wvl[i]), sh[j], accv[i][j], 0, 0, 0);
+                    accv[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, sl[j], accv[i][j], 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // Stagger (cdna guide, "Two waves per SIMD" item 9): all 8 waves share one barrier per step, so run in
+    // lockstep they ALL read LDS / convert, then ALL issue MFMAs, and the matrix pipe idles during the first
+    // phase (measured: 67 us for barrier + reads + MFMAs alone).  Waves 4-7 (the SIMD partners of waves 0-3)
+    // therefore run half a step late: after the barrier of step c they first issue the MFMAs of step c-1 from
+    // operands kept in registers, THEN read and convert step c -- while waves 0-3 read/convert first and
+    // issue MFMAs second.  Same barriers, same buffers (a buffer is refilled two steps after its last read by
+    // either half), bit-identical results.
+    const bool late = STAGGER && wv >= WB / 2;
+    dma_step(0);
+    if (nsteps > 1) dma_step(1);
+    if (!late) {
+        for (int c = 0; c < nsteps; ++c) {
+            retire(c);
+            read_frags(c);
+            if (c + 2 < nsteps) dma_step(c + 2);                    // into the buffer last read in step c-1
+            wait_frags();
+            convert();
+            mfmas();
+        }
+    } else {
+        for (int c = 0; c < nsteps; ++c) {
+            retire(c);
+            if (c + 2 < nsteps) dma_step(c + 2);
+            if (c > 0) mfmas();                                       // step c-1, operands already in registers
+            read_frags(c);
+            wait_frags();
+            convert();
+        }
+        mfmas();                                                      // step nsteps-1
     }
 
     const EpiCtx ec = make_epi_ctx<MEAN_ONLY>(a);
@@ -779,6 +1029,21 @@ int launch_split_cfg(const GemmArgs& a, bool mean_only, hipStream_t s) {
 }
 
 int launch_split(const GemmArgs& a, bool mean_only, hipStream_t s) {
+    // Measured on MI355X at the headline shapes (B=4096, O=1200; I=784 / 1200), layer-1 / layer-2 us:
+    //   128x80 tile, 2 workgroups/CU, 2 LDS buffers (below)        59.5 / 87.2   <- default
+    //   256x80 ring, 1 workgroup/CU, 3 buffers, no stagger          68.7 / 97.1
+    //   256x80 ring + half-step stagger of waves 4-7                64.5 / 90.2
+    // The ring kernel is kept selectable (LBBNN_GEMM_RING=1) and tested: it wins nothing here because the VALU
+    // port (bf16 splitting + MFMA issue) is as loaded as the matrix pipe, not because of exposed DMA latency.
+    const char* ring_env = getenv("LBBNN_GEMM_RING");
+    const bool use_ring = ring_env && ring_env[0] == '1';
+    const long blocks_ring = (long)((a.O + 79) / 80) * ((a.B + 255) / 256);
+    if (blocks_ring >= 128 && use_ring) {
+        // 256 x 80 tiles, one 8-wave workgroup per CU, 3-buffer LDS ring
+        dim3 grid((a.O + 79) / 80, (a.B + 255) / 256), block(512);
+        if (mean_only) return launch_one(lrt_gemm_bf16x3_ring_kernel<5, true>, grid, block, 3u * (256 * 128 + 2 * 80 * 64), s, a);
+        return launch_one(lrt_gemm_bf16x3_ring_kernel<5, false>, grid, block, 3u * (256 * 128 + 4 * 80 * 64), s, a);
+    }
     const long blocks_big = (long)((a.O + 79) / 80) * ((a.B + 127) / 128);
     if (blocks_big >= 256) return launch_split_cfg<5, 2, 4>(a, mean_only, s);
     return launch_split_cfg<5, 1, 2>(a, mean_only, s);
