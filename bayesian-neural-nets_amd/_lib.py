@@ -55,6 +55,15 @@ class DenseTransform(ctypes.Structure):
                 ("mask_fwd", c_p), ("mask_kl", c_p)]
 
 
+class GateArgs(ctypes.Structure):
+    """lbbnn_gate_args_t"""
+    _fields_ = [(n, c_p) for n in ("mu", "rho", "gamma_alpha", "cgamma", "eps_w", "alpha_attr",
+                                   "bias_mu", "bias_rho", "eps_b", "bias_a", "bias_b", "tau_b",
+                                   "weight_a", "weight_b", "tau_w", "pa", "pb",
+                                   "w_out", "bias_out", "rows", "log_prior", "log_q")] + \
+               [(n, c_i) for n in ("O", "I", "ld", "mode", "exact", "want_lp", "flags")] + [("layer_id", c_u32)]
+
+
 # name -> (restype, argtypes); must list every symbol include/lbbnn.h declares
 SIGNATURES = {
     "lbbnn_abi_version": (c_i, []),
@@ -73,6 +82,8 @@ SIGNATURES = {
                                 ctypes.POINTER(Priors), c_p, c_u32, c_p, c_p, c_i, c_p]),
     "lbbnn_layers_prepare": (c_i, [ctypes.POINTER(LayerDesc), c_i, c_p, c_p]),
     "lbbnn_forward_finish": (c_i, [c_p, c_u64, c_p, c_i, c_p, c_p]),
+    "lbbnn_gate_sample": (c_i, [ctypes.POINTER(GateArgs), c_p, c_p]),
+    "lbbnn_vd_operands": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "lbbnn_rng_advance": (c_i, [c_p, c_u64, c_p]),
     "lbbnn_philox_normal": (c_i, [c_p, c_u32, c_i64, c_i64, c_i64, c_p, c_p]),
     "lbbnn_log_softmax_rows": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_p]),

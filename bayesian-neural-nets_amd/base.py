@@ -1,0 +1,246 @@
+"""Baseline LBBNN (explicit latent-binary gate x Gaussian weight sampling), names as in LBBNN-GP-MF.py:
+
+``BayesianLinear(in_features, out_features, layer_id)`` :182-255 -- ``forward(input, cgamma, sample=False,
+medimean=False, calculate_log_probs=False)``, attributes ``log_prior``, ``log_variational_posterior``,
+``alpha``, ``gammas``, ``gamma``, ``weight_prior``, ``bias_prior``, ``gamma_prior`` (each with ``.exact``);
+``BayesianNetwork`` :259-319 with ``sample_elbo``.  The fused pass (sample W = gamma*(mu+sigma*eps), all four
+Monte-Carlo log-probability sums) and ``F.linear`` run in HIP (lbbnn_gate_sample + lbbnn_lrt_gemm).
+"""
+import ctypes
+import itertools
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _grad, _lib, ops
+from .distributions import Bernoulli, Gaussian, TEMPER_PRIOR
+
+_ids = itertools.count(32)
+
+
+class GaussGamma(object):
+    """Normal-Gamma prior helper (LBBNN-GP-MF.py:132-151): holds a, b and the ``exact`` switch; the density is
+    evaluated inside the HIP pass, the Gamma(a,b) draw of :141 with torch."""
+
+    def __init__(self, a, b):
+        self.a, self.b = a, b
+        self.exact = False
+
+    def rsample_tau(self):
+        return torch.distributions.Gamma(self.a, self.b).rsample()
+
+
+class BetaBinomial(object):
+    """LBBNN-GP-MF.py:155-179."""
+
+    def __init__(self, pa, pb):
+        self.pa, self.pb = pa, pb
+        self.exact = False
+
+    def rsample(self):
+        p = torch.distributions.Beta(self.pa, self.pb).rsample()
+        return torch.distributions.RelaxedBernoulli(probs=p, temperature=0.001).rsample()
+
+
+class _BaseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, layer, x, cgamma, tau_w, tau_b, cfg, *params):
+        out, lp, lq, saved = layer._forward_hip(x, cgamma, tau_w, tau_b, cfg, save_rng=True)
+        ctx.layer, ctx.cfg, ctx.saved = layer, cfg, saved
+        ctx.save_for_backward(x, cgamma, tau_w, tau_b, *params)
+        z = out.new_zeros(())
+        return out, (lp if lp is not None else z), (lq if lq is not None else z)
+
+    @staticmethod
+    def backward(ctx, g_out, g_lp, g_lq):
+        layer, cfg = ctx.layer, ctx.cfg
+        x, cgamma, tau_w, tau_b, *params = ctx.saved_tensors
+        noise = layer._noise_for_backward(ctx.saved)
+        with torch.enable_grad():
+            leaves = [t.detach().requires_grad_(True) for t in (x, cgamma, tau_w, tau_b)] + \
+                     [p.detach().requires_grad_(True) for p in params]
+            P = dict(zip(layer._names, leaves[4:]))
+            out_t, lp_t, lq_t = _grad.base_torch(leaves[0], leaves[1], leaves[2], leaves[3], P, noise,
+                                                 mode=cfg[0], want_lp=cfg[1], exact=cfg[2],
+                                                 alpha_attr=ctx.saved["alpha_attr"], gamma_alpha=ctx.saved["gamma_alpha"])
+            outs, gs = [out_t], [g_out]
+            if lp_t is not None:
+                outs += [lp_t, lq_t]
+                gs += [g_lp, g_lq]
+            grads = torch.autograd.grad(outs, leaves, gs, allow_unused=True)
+        return (None, grads[0], grads[1], grads[2], grads[3], None, *grads[4:])
+
+
+class BayesianLinear(nn.Module):
+    _names = ("weight_mu", "weight_rho", "weight_a", "weight_b", "lambdal", "pa", "pb",
+              "bias_mu", "bias_rho", "bias_a", "bias_b")
+
+    def __init__(self, in_features, out_features, layer_id):
+        super().__init__()
+        self.layer = layer_id
+        self.in_features, self.out_features = in_features, out_features
+        O, I = out_features, in_features
+        # creation order == LBBNN-GP-MF.py:192-219 (seeded construction reproduces the reference's values)
+        self.weight_mu = nn.Parameter(torch.Tensor(O, I).uniform_(-0.2, 0.2))
+        self.weight_rho = nn.Parameter(torch.Tensor(O, I).uniform_(-5, -4))
+        self.weight = Gaussian(self.weight_mu, self.weight_rho)
+        self.weight_a = nn.Parameter(torch.Tensor(1).uniform_(1, 1.1))
+        self.weight_b = nn.Parameter(torch.Tensor(1).uniform_(1, 1.1))
+        self.weight_prior = GaussGamma(self.weight_a, self.weight_b)
+        self.lambdal = nn.Parameter(torch.Tensor(O, I).uniform_(0, 1))
+        self.gammas = torch.Tensor(O, I).uniform_(0.99, 1)
+        self.alpha = torch.Tensor(O, I).uniform_(0.999, 0.9999)
+        self.gamma = Bernoulli(self.alpha, exact=False)
+        self.pa = nn.Parameter(torch.Tensor(1).uniform_(1, 1.1))
+        self.pb = nn.Parameter(torch.Tensor(1).uniform_(1, 1.1))
+        self.gamma_prior = BetaBinomial(pa=self.pa, pb=self.pb)
+        self.bias_mu = nn.Parameter(torch.Tensor(O).uniform_(-0.2, 0.2))
+        self.bias_rho = nn.Parameter(torch.Tensor(O).uniform_(-5, -4))
+        self.bias = Gaussian(self.bias_mu, self.bias_rho)
+        self.bias_a = nn.Parameter(torch.Tensor(O).uniform_(1, 1.1))
+        self.bias_b = nn.Parameter(torch.Tensor(O).uniform_(1, 1.1))
+        self.bias_prior = GaussGamma(self.bias_a, self.bias_b)
+        self.log_prior = 0
+        self.log_variational_posterior = 0
+        self.lagrangian = 0
+        self.noise = None              # parity tests: {"eps_w","eps_b","tau_w","tau_b"}
+        self._layer_id = next(_ids) % 64
+        self._ws = None
+
+    def _workspace(self):
+        dev = self.weight_mu.device
+        if self._ws is None or self._ws["dev"] != dev:
+            O, ld = self.out_features, ops.operand_ld(self.in_features)
+            f = dict(dtype=torch.float32, device=dev)
+            self._ws = {"dev": dev, "w": torch.empty((O, ld), **f), "rows": torch.empty(4 * O, **f)}
+        return self._ws
+
+    def _exact_bits(self):
+        return ((1 if self.weight_prior.exact else 0) | (2 if self.bias_prior.exact else 0)
+                | (4 if self.gamma_prior.exact else 0) | (8 if self.gamma.exact else 0))
+
+    def _forward_hip(self, x, cgamma, tau_w, tau_b, cfg, save_rng=False):
+        mode, want_lp, exact = cfg
+        ws = self._workspace()
+        dev = x.device
+        noise = self.noise or {}
+        O, I = self.out_features, self.in_features
+        split = (ops.get_precision() == "bf16x3" and ops.split_eligible(I, O)
+                 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
+        a = _lib.GateArgs()
+        P = lambda t: None if t is None else ops._ptr(t.detach() if t.requires_grad else t, "tensor")
+        gamma_alpha = self.gamma.alpha
+        gamma_alpha = gamma_alpha.detach().to(dev).float().contiguous() if torch.is_tensor(gamma_alpha) else None
+        alpha_attr = self.alpha.detach().to(dev).float().contiguous() if torch.is_tensor(self.alpha) else None
+        cg = None if cgamma is None else cgamma.detach().to(dev).float().contiguous()
+        eps_w, eps_b = noise.get("eps_w"), noise.get("eps_b")
+        rng, st, saved = None, None, {"noise": self.noise, "alpha_attr": alpha_attr, "gamma_alpha": gamma_alpha}
+        if mode == 0 and (eps_w is None or eps_b is None):
+            st = ops.RngState.get(dev)
+            rng = st.t
+            saved["rng"] = rng.clone() if save_rng else None
+        bias = torch.empty(O, dtype=torch.float32, device=dev)
+        lp = torch.empty((), dtype=torch.float32, device=dev) if want_lp else None
+        lq = torch.empty((), dtype=torch.float32, device=dev) if want_lp else None
+        a.mu, a.rho, a.gamma_alpha, a.cgamma = P(self.weight_mu), P(self.weight_rho), P(gamma_alpha), P(cg)
+        a.eps_w, a.alpha_attr = P(eps_w), P(alpha_attr)
+        a.bias_mu, a.bias_rho, a.eps_b = P(self.bias_mu), P(self.bias_rho), P(eps_b)
+        a.bias_a, a.bias_b, a.tau_b = P(self.bias_a), P(self.bias_b), P(tau_b)
+        a.weight_a, a.weight_b, a.tau_w, a.pa, a.pb = P(self.weight_a), P(self.weight_b), P(tau_w), P(self.pa), P(self.pb)
+        a.w_out, a.bias_out, a.rows = ws["w"].data_ptr(), bias.data_ptr(), ws["rows"].data_ptr()
+        a.log_prior, a.log_q = P(lp), P(lq)
+        a.O, a.I, a.ld, a.mode, a.exact, a.want_lp = O, I, ops.operand_ld(I), mode, exact, int(want_lp)
+        a.flags, a.layer_id = (ops.F_SPLIT16 if split else 0), self._layer_id
+        _lib.check(_lib.lib().lbbnn_gate_sample(ctypes.byref(a), rng.data_ptr() if rng is not None else None,
+                                                ops._stream()), "lbbnn_gate_sample")
+        out = ops.lrt_gemm(x, ws["w"], None, I=I, O=O, bias_mean=bias, mean_only=True, split=split)   # F.linear :255
+        if st is not None:
+            st.advance(1)
+        saved["cg"] = cg
+        return out, lp, lq, saved
+
+    def _noise_for_backward(self, saved):
+        n = dict(saved.get("noise") or {})
+        if "eps_w" not in n and saved.get("rng") is not None:
+            O, I, L = self.out_features, self.in_features, self._layer_id
+            n["eps_w"] = ops.philox_normal(saved["rng"], ops.STREAM_EPS_W * 64 + L, O, I)
+            n["eps_b"] = ops.philox_normal(saved["rng"], ops.STREAM_EPS_B * 64 + L, 0, O)
+        return n
+
+    def forward(self, input, cgamma, sample=False, medimean=False, calculate_log_probs=False):
+        if not input.is_cuda:
+            raise RuntimeError("bnn_amd: forward needs a HIP device tensor (input is on %s); there is no CPU path"
+                               % input.device)
+        if self.training or sample:
+            self.gammas = cgamma                                      # :231
+            mode = 0
+        elif medimean:
+            mode = 1
+        else:
+            mode = 2
+        want_lp = bool(self.training or calculate_log_probs)
+        noise = self.noise or {}
+        dev = input.device
+        tau_w = tau_b = None
+        if want_lp:
+            tau_w = noise["tau_w"] if "tau_w" in noise else self.weight_prior.rsample_tau()      # :141
+            tau_b = noise["tau_b"] if "tau_b" in noise else self.bias_prior.rsample_tau()
+        cfg = (mode, want_lp, self._exact_bits())
+        x = input.float()
+        params = [getattr(self, n) for n in self._names]
+        needs = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        if needs and want_lp:
+            out, lp, lq = _BaseFn.apply(self, x, cgamma.to(dev), tau_w, tau_b, cfg, *params)
+        else:
+            out, lp, lq, _ = self._forward_hip(x, cgamma, tau_w, tau_b, cfg)
+        if want_lp:
+            self.alpha = 1 / (1 + torch.exp(-self.lambdal))           # :246
+            self.log_prior, self.log_variational_posterior = lp, lq
+        else:
+            self.log_prior, self.log_variational_posterior = 0, 0     # :253
+        return out
+
+
+class BayesianNetwork(nn.Module):
+    """LBBNN-GP-MF.py:259-319 (reference dims 784-400-600-10; ``dims=`` added)."""
+
+    def __init__(self, dims=(28 * 28, 400, 600, 10)):
+        super().__init__()
+        self.dims = tuple(dims)
+        self.l1 = BayesianLinear(dims[0], dims[1], 1)
+        self.l2 = BayesianLinear(dims[1], dims[2], 1)
+        self.l3 = BayesianLinear(dims[2], dims[3], 1)
+
+    def forward(self, x, g1, g2, g3, sample=False, medimean=False):
+        x = x.view(-1, self.dims[0])
+        x = F.relu(self.l1.forward(x, g1, sample, medimean))
+        x = F.relu(self.l2.forward(x, g2, sample, medimean))
+        return F.log_softmax(self.l3.forward(x, g3, sample, medimean), dim=1)
+
+    def log_prior(self):
+        return self.l1.log_prior + self.l2.log_prior + self.l3.log_prior
+
+    def log_variational_posterior(self):
+        return (self.l1.log_variational_posterior + self.l2.log_variational_posterior
+                + self.l3.log_variational_posterior)
+
+    def sample_elbo(self, input, target, samples=1, num_batches=600):
+        """:285-319 (NUM_BATCHES / CLASSES / BATCH_SIZE were module globals there)."""
+        dev = input.device
+        lps, lqs, nlls = [], [], []
+        for _ in range(samples):
+            gs = []
+            for l in (self.l1, self.l2, self.l3):
+                l.alpha = 1 / (1 + torch.exp(-l.lambdal))             # :292-297
+                l.gamma.alpha = l.alpha
+                gs.append(l.gamma.rsample().to(dev))                  # :300-302
+            out = self.forward(input, gs[0], gs[1], gs[2], sample=True, medimean=False)
+            lps.append(self.log_prior())
+            lqs.append(self.log_variational_posterior())
+            nlls.append(F.nll_loss(out, target, reduction="sum"))
+        log_prior = torch.stack(lps).mean()
+        log_q = torch.stack(lqs).mean()
+        nll = torch.stack(nlls).mean()
+        loss = nll + (log_q - log_prior) / num_batches                # :318
+        return loss, log_prior, log_q, nll

@@ -1,0 +1,182 @@
+// K6 (baseline LBBNN gate x Gaussian weight sampling + Monte-Carlo log-probabilities) and
+// K7 (variational-dropout operand pass) -- see include/lbbnn.h.  Both are one-pass HBM-bound kernels
+// that feed the same dual-moment GEMM.
+#include <cmath>
+#include "lbbnn_device.h"
+#include "lbbnn_internal.h"
+
+namespace {
+
+using namespace lbbnn;
+
+__device__ __forceinline__ uint32_t bf16_rne_bits(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+// store one operand value at [o][i] either as fp32 or as bf16 hi/lo planes
+__device__ __forceinline__ void store_operand(void* base, int split, size_t O, int ld, int o, int i, float v) {
+    if (!split) { static_cast<float*>(base)[(size_t)o * ld + i] = v; return; }
+    uint16_t* hi = static_cast<uint16_t*>(base);
+    uint16_t* lo = hi + O * (size_t)ld;
+    const uint32_t h = bf16_rne_bits(v);
+    hi[(size_t)o * ld + i] = (uint16_t)h;
+    lo[(size_t)o * ld + i] = (uint16_t)bf16_rne_bits(v - __uint_as_float(h << 16));
+}
+
+// ------------------------------------------------------------------------------------------------ K6
+// One workgroup per output row; rows[0..3][o] = row sums of
+//   0: GaussGamma weight integrand (without the scalar C*gamma part folded: kept exact as the reference sums it)
+//   1: BetaBinomial integrand      2: Gaussian.full_log_prob integrand     3: Bernoulli.log_prob integrand
+__global__ __launch_bounds__(256) void gate_sample_kernel(const lbbnn_gate_args_t a, const uint64_t* rng) {
+    __shared__ double red[4][4];
+    const int o = blockIdx.x, tid = threadIdx.x;
+    const size_t ro = (size_t)o * a.I;
+    const int split = (a.flags & LBBNN_F_SPLIT16) ? 1 : 0;
+    uint64_t seed = 0, offs = 0;
+    if (a.mode == LBBNN_MODE_SAMPLE && !a.eps_w) { seed = rng[0]; offs = rng[1]; }
+    float C = 0.f, cbb = 0.f, pa = 0.f, pb = 0.f, tau = 0.f;
+    if (a.want_lp) {
+        const float wa = a.weight_a[0], wb = a.weight_b[0];
+        tau = a.tau_w[0];
+        // a*log(b) + (a-0.5)*tau - b*tau - lgamma(a) - 0.5*log(2*pi)      LBBNN-GP-MF.py:144-145
+        C = wa * logf(wb) + (wa - 0.5f) * tau - wb * tau - lgammaf(wa) - 0.5f * 1.8378770664093453f;
+        pa = a.pa[0]; pb = a.pb[0];
+        // lgamma(1) + lgamma(pa+pb) - lgamma(1+pa+pb) - lgamma(pa) - lgamma(pb)   (the g-independent terms of :167-173)
+        cbb = lgammaf(pa + pb) - lgammaf(1.f + pa + pb) - lgammaf(pa) - lgammaf(pb);
+    }
+    double s_gg = 0.0, s_bb = 0.0, s_fq = 0.0, s_be = 0.0;
+    for (int i = tid; i < a.ld; i += 256) {
+        float w = 0.f;
+        if (i < a.I) {
+            const float mu = a.mu[ro + i];
+            const float g = a.cgamma ? a.cgamma[ro + i] : 1.f;
+            float sigma = 0.f;
+            if (a.mode == LBBNN_MODE_SAMPLE) {
+                float e;
+                if (a.eps_w) e = a.eps_w[ro + i];
+                else { float n[4]; philox_normal4(seed, offs, LBBNN_STREAM_EPS_W * 64u + a.layer_id, (uint64_t)o, (uint32_t)(i >> 2), n); e = n[i & 3]; }
+                sigma = softplus_ref(a.rho[ro + i]);
+                w = g * (mu + sigma * e);                                          // :232-233
+            } else if (a.mode == LBBNN_MODE_MEDIMEAN) {
+                w = g * mu;                                                        // :237
+            } else {
+                w = a.alpha_attr[ro + i] * mu;                                     // :241
+            }
+            if (a.want_lp) {
+                if (a.mode != LBBNN_MODE_SAMPLE) sigma = softplus_ref(a.rho[ro + i]);
+                const float g_wp = (a.exact & 1) ? rintf(g) : g;
+                s_gg += (double)(g_wp * C - tau * (w * w) + (1.f - g_wp) + 1e-8f);                  // :144-150
+                const float g_bb = (a.exact & 4) ? rintf(g) : g;
+                s_bb += (double)(cbb + lgammaf(1.f + pb - g_bb) - lgammaf(2.f - g_bb));              // :167-173
+                const float d = w - mu;
+                const float lp = -0.9189385332046727f - logf(sigma) - (d * d) / (2.f * sigma * sigma);   // :94-97
+                s_fq += (double)logf(g * expf(lp) + (1.f - g) + 1e-8f);                              // :99-101
+                const float al = a.gamma_alpha[ro + i];
+                const float g_be = (a.exact & 8) ? rintf(g) : g;
+                s_be += (double)(g_be * logf(al + 1e-8f) + (1.f - g_be) * logf(1.f - al + 1e-8f));   // :125-127
+            }
+        }
+        if (a.w_out) store_operand(a.w_out, split, a.O, a.ld, o, i, w);
+    }
+    if (a.want_lp) {
+        s_gg = wave_sum(s_gg); s_bb = wave_sum(s_bb); s_fq = wave_sum(s_fq); s_be = wave_sum(s_be);
+        const int lane = tid & 63, wv = tid >> 6;
+        if (lane == 0) { red[0][wv] = s_gg; red[1][wv] = s_bb; red[2][wv] = s_fq; red[3][wv] = s_be; }
+        __syncthreads();
+        if (tid < 4) a.rows[(size_t)tid * a.O + o] = (float)((red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]));
+    }
+}
+
+// bias sample + bias log-probabilities + final scalars (single workgroup)
+__global__ __launch_bounds__(256) void gate_finalize_kernel(const lbbnn_gate_args_t a, const uint64_t* rng) {
+    __shared__ double scratch[4];
+    const int tid = threadIdx.x;
+    uint64_t seed = 0, offs = 0;
+    if (a.mode == LBBNN_MODE_SAMPLE && !a.eps_b) { seed = rng[0]; offs = rng[1]; }
+    double r0 = 0, r1 = 0, r2 = 0, r3 = 0, gb = 0, qb = 0;
+    for (int o = tid; o < a.O; o += 256) {
+        const float sb = softplus_ref(a.bias_rho[o]);
+        float b = a.bias_mu[o];
+        if (a.mode == LBBNN_MODE_SAMPLE) {
+            float e;
+            if (a.eps_b) e = a.eps_b[o];
+            else { float n[4]; philox_normal4(seed, offs, LBBNN_STREAM_EPS_B * 64u + a.layer_id, (uint64_t)(o >> 2), 0u, n); e = n[o & 3]; }
+            b = a.bias_mu[o] + sb * e;                                                                // :234
+        }
+        a.bias_out[o] = b;
+        if (a.want_lp) {
+            r0 += (double)a.rows[o]; r1 += (double)a.rows[(size_t)a.O + o];
+            r2 += (double)a.rows[2 * (size_t)a.O + o]; r3 += (double)a.rows[3 * (size_t)a.O + o];
+            const float ba = a.bias_a[o], bb = a.bias_b[o], tb = a.tau_b[o];
+            const float Cb = ba * logf(bb) + (ba - 0.5f) * tb - bb * tb - lgammaf(ba) - 0.5f * 1.8378770664093453f;
+            gb += (double)(Cb - tb * (b * b) + 0.f + 1e-8f);                                          // GaussGamma(bias, 1)
+            const float d = b - a.bias_mu[o];
+            qb += (double)(-0.9189385332046727f - logf(sb) - (d * d) / (2.f * sb * sb));              // Gaussian.log_prob :89-92
+        }
+    }
+    if (!a.want_lp) return;
+    r0 = block_sum<double, 4>(r0, scratch); r1 = block_sum<double, 4>(r1, scratch);
+    r2 = block_sum<double, 4>(r2, scratch); r3 = block_sum<double, 4>(r3, scratch);
+    gb = block_sum<double, 4>(gb, scratch); qb = block_sum<double, 4>(qb, scratch);
+    if (tid == 0) {
+        *a.log_prior = (float)(r0 + gb + r1);          // :247-249
+        *a.log_q = (float)(r2 + r3 + qb);              // :250-251
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K7
+// 32x32 tiles of theta (I,O) through LDS: coalesced reads along O, coalesced writes along I.
+__global__ __launch_bounds__(256) void vd_operands_kernel(const float* __restrict__ theta, void* e_w, void* var_w,
+                                                          int ld, int I, int O, int split) {
+    __shared__ float tile[32][33];
+    const int i0 = blockIdx.x * 32, o0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + ty + 8 * r, o = o0 + tx;
+        tile[ty + 8 * r][tx] = (i < I && o < O) ? theta[(size_t)i * O + o] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int o = o0 + ty + 8 * r, i = i0 + tx;
+        if (o < O && i < ld) {
+            const float t = tile[tx][ty + 8 * r];                // zero for i >= I: keeps the operand tail zero-filled
+            store_operand(e_w, split, O, ld, o, i, t);
+            store_operand(var_w, split, O, ld, o, i, t * t);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int lbbnn_gate_sample(const lbbnn_gate_args_t* p, const uint64_t* rng, void* stream) {
+    if (!p) return LBBNN_E_NULL;
+    const lbbnn_gate_args_t& a = *p;
+    if (!a.mu || !a.bias_mu || !a.bias_out) return LBBNN_E_NULL;
+    if (a.O <= 0 || a.I <= 0) return LBBNN_E_SHAPE;
+    if (a.mode < 0 || a.mode > 2) return LBBNN_E_FLAGS;
+    if (a.flags & ~LBBNN_F_SPLIT16) return LBBNN_E_FLAGS;
+    if (a.w_out && (a.ld < a.I || (a.ld & 31))) return LBBNN_E_ALIGN;
+    if (a.mode == LBBNN_MODE_SAMPLE && (!a.rho || !a.bias_rho)) return LBBNN_E_NULL;
+    if (a.mode != LBBNN_MODE_MEAN && !a.cgamma) return LBBNN_E_NULL;
+    if (a.mode == LBBNN_MODE_MEAN && !a.alpha_attr) return LBBNN_E_NULL;
+    if (a.mode == LBBNN_MODE_SAMPLE && (!a.eps_w || !a.eps_b) && !rng) return LBBNN_E_NOISE;
+    if (a.want_lp && (!a.rho || !a.bias_rho || !a.cgamma || !a.gamma_alpha || !a.weight_a || !a.weight_b || !a.tau_w ||
+                      !a.pa || !a.pb || !a.bias_a || !a.bias_b || !a.tau_b || !a.rows || !a.log_prior || !a.log_q))
+        return LBBNN_E_NULL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(gate_sample_kernel, dim3(a.O), dim3(256), 0, s, a, rng);
+    hipLaunchKernelGGL(gate_finalize_kernel, dim3(1), dim3(256), 0, s, a, rng);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lbbnn_vd_operands(const float* theta, void* e_w, void* var_w, int ld, int I, int O, int flags, void* stream) {
+    if (!theta || !e_w || !var_w) return LBBNN_E_NULL;
+    if (I <= 0 || O <= 0) return LBBNN_E_SHAPE;
+    if (ld < I || (ld & 31)) return LBBNN_E_ALIGN;
+    if (flags & ~LBBNN_F_SPLIT16) return LBBNN_E_FLAGS;
+    hipLaunchKernelGGL(vd_operands_kernel, dim3((ld + 31) / 32, (O + 31) / 32), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), theta, e_w, var_w, ld, I, O, (flags & LBBNN_F_SPLIT16) ? 1 : 0);
+    return (int)hipGetLastError();
+}

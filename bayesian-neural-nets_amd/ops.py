@@ -21,6 +21,8 @@ STREAM_EPS_OUT = 0
 STREAM_EPS_Z = 1
 STREAM_EPS_Z2 = 2
 STREAM_EPS_ACT = 3
+STREAM_EPS_W = 4
+STREAM_EPS_B = 5
 
 
 # GEMM arithmetic: "fp32" = exact fp32 MFMA path; "bf16x3" = split-precision path (bf16 hi/lo mean

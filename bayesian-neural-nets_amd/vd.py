@@ -1,0 +1,114 @@
+"""Gaussian variational dropout, names as in variational_dropout.py: ``BayesianLayer(n, m)`` :55-68,
+``BNN`` :72-86, ``loss_fn`` :89-106.  theta is (n, m) = (in, out), NN layout, as in the reference; the HIP
+path transposes it into the GEMM operand format on the fly (lbbnn_vd_operands) and runs the same dual-moment
+GEMM with ``var_scale = alpha`` and no bias."""
+import itertools
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _grad, _lib, ops
+
+_ids = itertools.count(48)
+
+
+class _VDFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, layer, x, theta, alpha):
+        out, zeta_src = layer._forward_hip(x, save_rng=True)
+        ctx.layer, ctx.zeta_src = layer, zeta_src
+        ctx.save_for_backward(x, theta, alpha)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, theta, alpha = ctx.saved_tensors
+        layer = ctx.layer
+        kind, val = ctx.zeta_src
+        zeta = val if kind == "explicit" else ops.philox_normal(val, ops.STREAM_EPS_OUT * 64 + layer._layer_id,
+                                                                  x.shape[0], layer.m, layer.row_offset)
+        with torch.enable_grad():
+            xs = x.detach().requires_grad_(True)
+            th = theta.detach().requires_grad_(True)
+            out = _grad.vd_torch(xs, th, alpha.detach(), zeta)
+            gx, gt = torch.autograd.grad(out, [xs, th], g)
+        return None, gx, gt, None
+
+
+class BayesianLayer(nn.Module):
+    def __init__(self, n, m):
+        super().__init__()
+        low, high = -0.1, 0.1
+        self.n, self.m = n, m
+        self.theta = nn.Parameter((low - high) * torch.rand(size=(n, m)) + high)        # :58-60
+        # :61 -- `nn.Parameter(zeros(m)) + 0.2` is a plain (non-leaf) tensor in the reference: never trained, not in
+        # state_dict.  A non-persistent buffer keeps those properties and follows .to(device).
+        self.register_buffer("alpha", torch.zeros(m) + 0.2, persistent=False)
+        self.noise = None                 # {"zeta": (B, m)} for parity tests
+        self.row_offset = 0
+        self._layer_id = next(_ids) % 64
+        self._ws = None
+
+    def _forward_hip(self, x, relu=False, save_rng=False):
+        dev = x.device
+        ld = ops.operand_ld(self.n)
+        if self._ws is None or self._ws[0].device != dev:
+            self._ws = (torch.empty((self.m, ld), dtype=torch.float32, device=dev),
+                        torch.empty((self.m, ld), dtype=torch.float32, device=dev))
+        e_w, var_w = self._ws
+        split = (ops.get_precision() == "bf16x3" and ops.split_eligible(self.n, self.m)
+                 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
+        _lib.check(_lib.lib().lbbnn_vd_operands(ops._ptr(self.theta.detach(), "theta"), e_w.data_ptr(), var_w.data_ptr(),
+                                                ld, self.n, self.m, ops.F_SPLIT16 if split else 0, ops._stream()),
+                   "lbbnn_vd_operands")
+        zeta = (self.noise or {}).get("zeta")
+        rng, st = None, None
+        if zeta is None:
+            st = ops.RngState.get(dev)
+            rng = st.t
+        src = ("explicit", zeta) if zeta is not None else ("rng", rng.clone() if save_rng else None)
+        out = ops.lrt_gemm(x, e_w, var_w, I=self.n, O=self.m, var_scale=self.alpha, eps=zeta, rng=rng,
+                           rng_stream=ops.STREAM_EPS_OUT * 64 + self._layer_id, row_offset=self.row_offset,
+                           relu=relu, split=split)
+        if st is not None:
+            st.advance(1)
+        return out, src
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("bnn_amd: forward needs a HIP device tensor (input is on %s); there is no CPU path" % x.device)
+        x = x.float()
+        if torch.is_grad_enabled() and (x.requires_grad or self.theta.requires_grad):
+            return _VDFn.apply(self, x, self.theta, self.alpha)
+        return self._forward_hip(x)[0]
+
+
+class BNN(nn.Module):
+    """variational_dropout.py:72-86 (784-1200-1200-1200-10 there; ``dims=`` added)."""
+
+    def __init__(self, dims=(28 * 28, 1200, 1200, 1200, 10)):
+        super().__init__()
+        self.dims = tuple(dims)
+        self.l1 = BayesianLayer(dims[0], dims[1])
+        self.l2 = BayesianLayer(dims[1], dims[2])
+        self.l3 = BayesianLayer(dims[2], dims[3])
+        self.l4 = BayesianLayer(dims[3], dims[4])
+
+    def forward(self, x):
+        x = x.view(-1, self.dims[0])
+        x = F.relu(self.l1(x))
+        x = F.relu(self.l2(x))
+        x = F.relu(self.l3(x))
+        return F.log_softmax(self.l4(x), dim=1)
+
+
+def loss_fn(prediction, target, model, num_batches):
+    """variational_dropout.py:89-106 (num_batches = N / batch_size was computed from the loaders there)."""
+    KL = 0
+    c1, c2, c3 = 1.16145124, -1.50204118, 0.58629921
+    for layer in model.children():
+        if isinstance(layer, BayesianLayer):
+            a = layer.alpha
+            KL = KL + (0.5 * torch.log(a) + c1 * a + c2 * a ** 2 + c3 * a ** 3).sum()
+    return KL / num_batches + F.nll_loss(prediction, target, reduction="sum")

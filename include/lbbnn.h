@@ -239,6 +239,51 @@ int lbbnn_layers_prepare(const lbbnn_layer_desc_t* layers, int n, const uint64_t
 int lbbnn_forward_finish(uint64_t* rng, uint64_t advance, const float* const* kl_layers, int n,
                          float* kl_total, void* stream);
 
+
+/* ---------------------------------------------------------------------------------------------
+ * K6  lbbnn_gate_sample -- baseline LBBNN layer (explicit latent-binary gate x Gaussian weight sample).
+ *
+ * Replaces, for BayesianLinear.forward of LBBNN-GP-MF.py:228-255, ONE fused pass over (O,I):
+ *   ws = mu + softplus(rho)*eps ; weight = cgamma*ws        Gaussian.rsample :85-87, :232-233   (mode 0)
+ *   weight = cgamma*mu (mode 1, medimean :236-238) | alpha_attr*mu (mode 2, :240-242)
+ *   bias = bias_mu + softplus(bias_rho)*eps_b  (mode 0) | bias_mu
+ * and, when want_lp, the Monte-Carlo log-probabilities (:246-251):
+ *   log_prior = GaussGamma(weight_a,weight_b).log_prob(weight,cgamma)        :140-151
+ *             + GaussGamma(bias_a,bias_b).log_prob(bias,1) + BetaBinomial(pa,pb).log_prob(cgamma)  :162-173
+ *   log_q     = Gaussian.full_log_prob(weight,cgamma) :99-101 + Bernoulli(gamma_alpha).log_prob(cgamma) :122-128
+ *             + Gaussian.log_prob(bias) :89-92
+ * The Gamma draws tau_w (1) / tau_b (O) of :141 are inputs (drawn by the host wrapper with torch).
+ * exact bits (the reference's `.exact` switches, :559-627): 1 weight_prior, 2 bias_prior, 4 gamma_prior, 8 gamma.
+ * Outputs: w_out = GEMM operand [O][ld] (fp32, or bf16 hi/lo planes with LBBNN_F_SPLIT16) for
+ *          lbbnn_lrt_gemm(LBBNN_F_MEAN_ONLY) = F.linear (:255); bias_out (O); log_prior, log_q (1 float each);
+ *          rows: workspace of 4*O floats.  eps_w (O,I) / eps_b (O) NULL => Philox (streams EPS_W / EPS_B).
+ */
+#define LBBNN_STREAM_EPS_W 4
+#define LBBNN_STREAM_EPS_B 5
+#define LBBNN_MODE_SAMPLE 0
+#define LBBNN_MODE_MEDIMEAN 1
+#define LBBNN_MODE_MEAN 2
+
+typedef struct lbbnn_gate_args {
+    const float *mu, *rho, *gamma_alpha, *cgamma, *eps_w, *alpha_attr;       /* (O,I) */
+    const float *bias_mu, *bias_rho, *eps_b, *bias_a, *bias_b, *tau_b;       /* (O)   */
+    const float *weight_a, *weight_b, *tau_w, *pa, *pb;                      /* (1)   */
+    void* w_out; float* bias_out; float* rows; float* log_prior; float* log_q;
+    int O, I, ld, mode, exact, want_lp, flags;
+    uint32_t layer_id;
+} lbbnn_gate_args_t;
+
+int lbbnn_gate_sample(const lbbnn_gate_args_t* args, const uint64_t* rng, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K7  lbbnn_vd_operands -- Gaussian variational-dropout layer (variational_dropout.py:55-68).
+ *   phi = x.theta ; delta = (x^2).(theta^2) * alpha ; out = phi + sqrt(delta)*zeta        :64-67
+ * theta is (I,O) row-major (NN layout).  This pass writes the GEMM operands theta^T and (theta^2)^T as
+ * [O][ld] (fp32 or split planes) through a tiled LDS transpose, so theta^2 is never materialised in (I,O)
+ * form and the same lbbnn_lrt_gemm runs with var_scale = alpha, bias = NULL.
+ */
+int lbbnn_vd_operands(const float* theta, void* e_w, void* var_w, int ld, int I, int O, int flags, void* stream);
+
 /* rng[1] += delta (device side, so graph replays draw fresh noise). */
 int lbbnn_rng_advance(uint64_t* rng, uint64_t delta, void* stream);
 

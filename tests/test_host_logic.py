@@ -92,3 +92,26 @@ def test_product_package_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
+
+
+def test_base_and_vd_seeded_construction_matches_reference(golden):
+    import bnn_amd
+    g = golden("base.npz")
+    for ci, (B, I, O) in enumerate([(3, 6, 4), (5, 33, 17), (8, 784, 10)]):
+        c = g.case("c%d" % ci)
+        torch.manual_seed(500 + ci)
+        layer = bnn_amd.base.BayesianLinear(I, O, 1)
+        ref = sub(c, "p.")
+        sd = layer.state_dict()
+        assert sorted(sd) == sorted(ref)
+        for k in ref:
+            assert torch.equal(sd[k], ref[k]), k
+        assert torch.equal(layer.alpha, c["alpha_init"])            # placeholder draw, LBBNN-GP-MF.py:204
+    g = golden("vd.npz")
+    for ci, (B, I, O) in enumerate([(3, 6, 4), (5, 33, 17), (8, 300, 10)]):
+        c = g.case("c%d" % ci)
+        torch.manual_seed(600 + ci)
+        layer = bnn_amd.vd.BayesianLayer(I, O)
+        assert torch.equal(layer.theta.detach(), c["theta"])
+        assert torch.equal(layer.alpha, c["alpha"])
+        assert [n for n, _ in layer.named_parameters()] == ["theta"]      # alpha is NOT a parameter there either

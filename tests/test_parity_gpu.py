@@ -580,3 +580,122 @@ def test_reference_default_network_trains(bnn, dev):
         net.eval()
         out = net(data, sample=False)
     assert out.shape == (16, 10) and torch.isfinite(out).all()
+
+
+# --------------------------------------------------------------------------- baseline LBBNN (gate x Gaussian sampling)
+@pytest.mark.parametrize("case", ["c0", "c1", "c2"])
+def test_base_layer_vs_golden(bnn, dev, golden, case):
+    c = golden("base.npz").case(case)
+    B, I, O = [int(v) for v in c["shape"]]
+    layer = _load_layer(bnn.base.BayesianLinear(I, O, 1), sub(c, "p."), dev)
+    x = c["x"].to(dev)
+    cg = c["cgamma"].to(dev)
+    with torch.no_grad():
+        layer.train()
+        layer.alpha = 1 / (1 + torch.exp(-layer.lambdal))            # as sample_elbo does (LBBNN-GP-MF.py:292-293)
+        layer.gamma.alpha = layer.alpha
+        layer.noise = {k: c[k].to(dev) for k in ("eps_w", "eps_b", "tau_w", "tau_b")}
+        out = layer(x, cg, sample=True)
+        assert rel_err(out, c["out_train"]) < TIGHT
+        assert rel_err(layer.log_prior, c["log_prior"]) < 2e-5
+        assert rel_err(layer.log_variational_posterior, c["log_q"]) < 2e-5
+        # exact=True variant (end of training, :612-627): hard gate
+        for o in (layer.weight_prior, layer.bias_prior, layer.gamma_prior, layer.gamma):
+            o.exact = True
+        hard = torch.round(cg)
+        layer.noise = {k: c["x_" + k].to(dev) for k in ("eps_w", "eps_b", "tau_w", "tau_b")}
+        out = layer(x, hard, sample=True)
+        assert rel_err(out, c["x_out_train"]) < TIGHT
+        assert rel_err(layer.log_prior, c["x_log_prior"]) < 2e-5
+        assert rel_err(layer.log_variational_posterior, c["x_log_q"]) < 2e-5
+        layer.eval()
+        layer.noise = None
+        assert rel_err(layer(x, hard, sample=False, medimean=True), c["out_medimean"]) < TIGHT
+        layer.alpha = c["alpha_attr"].to(dev)
+        assert rel_err(layer(x, hard, sample=False, medimean=False), c["out_mean"]) < TIGHT
+        assert layer.log_prior == 0
+
+
+def test_base_backward_and_sample_elbo(bnn, dev, golden):
+    c = golden("base.npz").case("c1")
+    B, I, O = [int(v) for v in c["shape"]]
+    p = sub(c, "p.")
+    layer = _load_layer(bnn.base.BayesianLinear(I, O, 1), p, dev).train()
+    noise = {k: c[k] for k in ("eps_w", "eps_b", "tau_w", "tau_b")}
+    layer.noise = {k: v.to(dev) for k, v in noise.items()}
+    with torch.no_grad():
+        layer.gamma.alpha = 1 / (1 + torch.exp(-layer.lambdal))
+    x = c["x"].to(dev).requires_grad_(True)
+    out = layer(x, c["cgamma"].to(dev), sample=True)
+    ((out ** 2).sum() + (layer.log_variational_posterior - layer.log_prior) / 600).backward()
+    pc = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    xc = c["x"].clone().requires_grad_(True)
+    o, lp, lq = orc.base_forward(xc, pc, c["cgamma"], noise, mode="sample",
+                                 gamma_alpha=orc.alpha_of(pc["lambdal"]).detach())
+    ((o ** 2).sum() + (lq - lp) / 600).backward()
+    assert rel_err(x.grad, xc.grad) < TOL
+    for name, prm in layer.named_parameters():
+        if pc[name].grad is None:
+            continue
+        assert rel_err(prm.grad, pc[name].grad) < 2e-4, name
+    # whole-network ELBO sample as the reference's train() calls it (:331-337)
+    torch.manual_seed(1)
+    net = bnn.base.BayesianNetwork((784, 64, 48, 10)).to(dev).train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    data = torch.rand(32, 1, 28, 28, device=dev); target = torch.randint(0, 10, (32,), device=dev)
+    vals = []
+    for _ in range(3):
+        net.zero_grad()
+        loss, lp, lq, nll = net.sample_elbo(data, target)
+        loss.backward(); opt.step()
+        vals.append(float(loss.detach()))
+    assert all(math.isfinite(v) for v in vals)
+
+
+# --------------------------------------------------------------------------- variational dropout
+@pytest.mark.parametrize("case", ["c0", "c1", "c2"])
+def test_vd_layer_vs_golden(bnn, dev, golden, case):
+    c = golden("vd.npz").case(case)
+    B, I, O = [int(v) for v in c["shape"]]
+    layer = bnn.vd.BayesianLayer(I, O)
+    with torch.no_grad():
+        layer.theta.copy_(c["theta"])
+    layer = layer.to(dev)
+    layer.noise = {"zeta": c["zeta"].to(dev)}
+    with torch.no_grad():
+        out = layer(c["x"].to(dev))
+    assert rel_err(out, c["out"]) < TIGHT
+    pred = torch.log_softmax(out, 1)
+    loss = bnn.vd.loss_fn(pred, c["target"].to(dev), torch.nn.Sequential(layer), float(c["num_batches"]))
+    assert rel_err(loss, c["loss"]) < 1e-5
+
+
+def test_vd_network_full_size_and_training(bnn, dev):
+    """BASELINE configs[4] shape (3072-4096-4096-10 'CIFAR-flat') forward vs fp64, in both precisions; then
+    the reference's BNN (784-1200-1200-1200-10) takes optimizer steps."""
+    torch.manual_seed(2)
+    I, O, B = 3072, 4096, 512
+    layer = bnn.vd.BayesianLayer(I, O).to(dev)
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(B, I, generator=g); zeta = torch.randn(B, O, generator=g)
+    layer.noise = {"zeta": zeta.to(dev)}
+    th = layer.theta.detach().cpu().double()
+    ref = x.double() @ th + torch.sqrt((x.double() ** 2) @ th ** 2 * 0.2) * zeta.double()
+    for prec in ("fp32", "bf16x3"):
+        bnn.set_precision(prec)
+        try:
+            with torch.no_grad():
+                out = layer(x.to(dev))
+        finally:
+            bnn.set_precision("fp32")
+        assert rel_err(out, ref) < (TIGHT if prec == "fp32" else 2e-5), prec
+    net = bnn.vd.BNN().to(dev)
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-4)
+    data = torch.rand(64, 1, 28, 28, device=dev); target = torch.randint(0, 10, (64,), device=dev)
+    vals = []
+    for _ in range(3):
+        net.zero_grad()
+        loss = bnn.vd.loss_fn(net(data), target, net, 600.0)
+        loss.backward(); opt.step()
+        vals.append(float(loss.detach()))
+    assert all(math.isfinite(v) for v in vals) and vals[-1] < vals[0]
