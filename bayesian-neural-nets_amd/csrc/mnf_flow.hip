@@ -137,19 +137,26 @@ __global__ __launch_bounds__(256) void mnf_flow_planar_lds_kernel(const FlowBatc
     const uint32_t stream = (klblk ? LBBNN_STREAM_EPS_Z2 : LBBNN_STREAM_EPS_Z) * 64u + a.layer;
     dma_wait_all();
 
-    // z0 = q0_mean + exp(q0_log_var)^.5 * eps  (LBBNN-GP-MF-MNF.py:183-185); log_q0 (:213-214, -0.5*log(pi))
+    // z0 = q0_mean + exp(q0_log_var)^.5 * eps  (LBBNN-GP-MF-MNF.py:183-185); log_q0 (:213-214, -0.5*log(pi)).
+    // A thread owns 4 consecutive elements so that one Philox call (4 normals) serves all of them.
     double lq0 = 0.0;
 #pragma unroll 1
-    for (int i = tid; i < I; i += 256) {
-        float e;
-        if (eps) e = ep[i];
-        else { float n[4]; philox_normal4(seed, offs, stream, (uint64_t)(i >> 2), 0u, n); e = n[i & 3]; }
-        const float ev = expf(lv[i]);
-        const float z0 = qm[i] + sqrtf(ev) * e;
-        z[i] = z0;
-        if (klblk) {
-            const float d = z0 - qm[i];
-            lq0 += (double)(-0.5f * 1.1447298858494002f - 0.5f * lv[i] - 0.5f * ((d * d) / ev));
+    for (int i0 = 4 * tid; i0 < I; i0 += 1024) {
+        float n[4] = {0.f, 0.f, 0.f, 0.f};
+        if (!eps) philox_normal4(seed, offs, stream, (uint64_t)(i0 >> 2), 0u, n);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + k;
+            if (i < I) {
+                const float e = eps ? ep[i] : n[k];
+                const float ev = expf(lv[i]);
+                const float z0 = qm[i] + sqrtf(ev) * e;
+                z[i] = z0;
+                if (klblk) {
+                    const float d = z0 - qm[i];
+                    lq0 += (double)(-0.5f * 1.1447298858494002f - 0.5f * lv[i] - 0.5f * ((d * d) / ev));
+                }
+            }
         }
     }
     __syncthreads();
