@@ -40,6 +40,18 @@ struct FinalizeArgs {
     float bias_mu_prior, bias_sigma_prior;
 };
 
+// Select element `idx` of a by-value kernel-argument array WITHOUT dynamic indexing: a runtime index into a
+// kernarg struct array makes hipcc copy the array to scratch memory (measured: 64 B/lane of scratch in K1);
+// a chain of uniform compares keeps every field a constant-offset scalar load.
+#define LBBNN_SELECT_LAYER(dst, arr, idx)                      \
+    do {                                                       \
+        if ((idx) == 0) dst = (arr)[0];                        \
+        else if ((idx) == 1) dst = (arr)[1];                   \
+        else if ((idx) == 2) dst = (arr)[2];                   \
+        else dst = (arr)[3];                                   \
+    } while (0)
+static_assert(LBBNN_MAX_LAYERS == 4, "LBBNN_SELECT_LAYER enumerates 4 layers");
+
 // Fill / validate helpers (return LBBNN_E_* or 0); launchers return hipGetLastError().
 LBBNN_HIDDEN int make_weight_pass_args(WeightPassArgs& a, const float* mu, const float* rho, const float* lambdal,
                                        const float* z_fwd, const float* z_kl, const float* r0_c, const float* bias_rho,

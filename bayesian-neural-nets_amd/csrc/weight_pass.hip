@@ -83,7 +83,8 @@ __global__ __launch_bounds__(256) void weight_pass_kernel(const WeightPassBatch 
     int li = 0;
 #pragma unroll
     for (int t = 0; t < LBBNN_MAX_LAYERS - 1; ++t) if (t + 1 < bt.n && (int)blockIdx.x >= bt.row_end[t]) li = t + 1;
-    const WeightPassArgs& a = bt.l[li];
+    WeightPassArgs a;
+    LBBNN_SELECT_LAYER(a, bt.l, li);        // constant-index select: no scratch copy of the argument array
     const int o = (int)blockIdx.x - (li ? bt.row_end[li - 1] : 0);
     const bool VEC = a.vec != 0;
     const int tid = threadIdx.x;
