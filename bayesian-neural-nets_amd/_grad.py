@@ -76,6 +76,53 @@ def _flow(z, spec, masks):
     return _dense(z, kind, tr, masks)
 
 
+def lrt_param_graph(P, *, stochastic, want_kl, priors):
+    """Parameter-side graph of the LRT layer: the GEMM operands and the KL as differentiable torch tensors.
+    The backward multiplies the operand gradients (computed by the HIP GEMMs) into this graph."""
+    alpha = _alpha(P["lambdal"])
+    g = {"Wm": P["weight_mu"] * alpha, "bmean": P["bias_mu"], "Wv": None, "bvar": None, "kl": None}
+    sigma = None
+    if stochastic:
+        sigma = _sigma(P["weight_rho"])
+        g["Wv"] = sigma ** 2 * alpha ** 2
+        g["bvar"] = _sigma(P["bias_rho"]) ** 2
+    if want_kl:
+        sigma = _sigma(P["weight_rho"]) if sigma is None else sigma
+        g["kl"] = _kl_bias(P["bias_mu"], P["bias_rho"], priors) + _kl_weight(P["weight_mu"], sigma, alpha, priors)
+    return g
+
+
+def mnf_param_graph(P, zf, rf, noise, *, stochastic, want_kl, priors):
+    """Parameter-side graph of the MNF layer (LBBNN-GP-MF-MNF.py:190-239 minus the two x GEMMs)."""
+    alpha = _alpha(P["lambdal"])
+    q0_std = P["q0_log_var"].exp().sqrt()
+    z_k, _ = _flow(P["q0_mean"] + q0_std * noise["eps_z"], zf, noise.get("zmask"))
+    g = {"Wm": P["weight_mu"] * alpha * z_k, "bmean": P["bias_mu"], "Wv": None, "bvar": None, "kl": None}
+    sigma = None
+    if stochastic:
+        sigma = _sigma(P["weight_rho"])
+        g["Wv"] = sigma ** 2 * alpha ** 2
+        g["bvar"] = _sigma(P["bias_rho"]) ** 2
+    if want_kl:
+        sigma = _sigma(P["weight_rho"]) if sigma is None else sigma
+        z0 = P["q0_mean"] + q0_std * noise["eps_z2"]
+        z2, log_det_q = _flow(z0, zf, noise.get("zmask2"))
+        log_q0 = (-0.5 * math.log(math.pi) - 0.5 * P["q0_log_var"]
+                  - 0.5 * ((z0 - P["q0_mean"]) ** 2 / P["q0_log_var"].exp())).sum()
+        log_q = -log_det_q + log_q0
+        W_mean = z2 * P["weight_mu"] * alpha
+        W_var = sigma ** 2 * alpha ** 2
+        act = torch.tanh(P["r0_c"] @ W_mean.T + (P["r0_c"] ** 2 @ W_var.T).sqrt() * noise["eps_act"])
+        m = act.mean()
+        mean_r, log_var_r = P["r0_b1"] * m, P["r0_b2"] * m
+        z_b, log_det_r = _flow(z2, rf, noise.get("rmask"))
+        log_rb = (-0.5 * math.log(math.pi) - 0.5 * log_var_r
+                  - 0.5 * ((z_b[-1] - mean_r) ** 2 / log_var_r.exp())).sum()
+        g["kl"] = (_kl_bias(P["bias_mu"], P["bias_rho"], priors)
+                   + _kl_weight(P["weight_mu"] * z2, sigma, alpha, priors) + log_q - (log_det_r + log_rb))
+    return g
+
+
 def lrt_torch(x, P, noise, *, stochastic, want_kl, priors, relu):
     """LBBNN-GP-MF-LRT.py:166-197 as differentiable torch ops. P: dict of tensors."""
     alpha = _alpha(P["lambdal"])

@@ -73,6 +73,9 @@ SIGNATURES = {
                                 c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "lbbnn_lrt_gemm": (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_u32, c_i64,
                              c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "lbbnn_lrt_gemm_train": (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_u32, c_i64,
+                                   c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "lbbnn_transpose_operand": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p]),
     "lbbnn_mnf_flow_planar": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p,
                                     c_p, c_u32, c_p, c_p, c_p, c_i, c_i, c_p]),
     "lbbnn_flow_dense_workspace": (c_i64, [c_i]),

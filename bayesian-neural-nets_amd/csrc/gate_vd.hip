@@ -148,7 +148,39 @@ __global__ __launch_bounds__(256) void vd_operands_kernel(const float* __restric
     }
 }
 
+// generic (R,C) -> operand [C][ld] transpose, optional square (same tiling as K7)
+__global__ __launch_bounds__(256) void transpose_operand_kernel(const float* __restrict__ src, int R, int C, int lds_src,
+                                                                void* dst, int ld, int square, int split) {
+    __shared__ float tile[32][33];
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        float v = (r < R && c < C) ? src[(size_t)r * lds_src + c] : 0.f;
+        tile[ty + 8 * k][tx] = square ? v * v : v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, r = r0 + tx;
+        if (c < C && r < ld) store_operand(dst, split, C, ld, c, r, tile[tx][ty + 8 * k]);
+    }
+}
+
 }  // namespace
+
+extern "C" int lbbnn_transpose_operand(const float* src, int R, int C, int lds_src, void* dst, int ld,
+                                       int square, int flags, void* stream) {
+    if (!src || !dst) return LBBNN_E_NULL;
+    if (R <= 0 || C <= 0 || lds_src < C) return LBBNN_E_SHAPE;
+    if (ld < R || (ld & 31)) return LBBNN_E_ALIGN;
+    if (flags & ~LBBNN_F_SPLIT16) return LBBNN_E_FLAGS;
+    hipLaunchKernelGGL(transpose_operand_kernel, dim3((ld + 31) / 32, (C + 31) / 32), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), src, R, C, lds_src, dst, ld, square ? 1 : 0,
+                       (flags & LBBNN_F_SPLIT16) ? 1 : 0);
+    return (int)hipGetLastError();
+}
 
 extern "C" int lbbnn_gate_sample(const lbbnn_gate_args_t* p, const uint64_t* rng, void* stream) {
     if (!p) return LBBNN_E_NULL;

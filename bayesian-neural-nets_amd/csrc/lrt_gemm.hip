@@ -37,6 +37,7 @@ struct GemmArgs {
     const float* bias_mean; const float* bias_var; const float* var_scale;
     const float* eps; const uint64_t* rng;
     float* out;
+    float* std_out;          // optional (B,O): sqrt(var) before ReLU, for the backward pass
     long long row_offset;
     int ldx, ld, ldo, B, I, O;
     uint32_t rng_stream;
@@ -107,11 +108,20 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& a, const EpiCtx& c, co
             philox_normal4(c.seed, c.offs, a.rng_stream, (uint64_t)(a.row_offset + b), (uint32_t)(o >> 2), e);
         }
     }
+    float sd[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         float mean = am[r] + oc.bm[r];
-        if (!MEAN_ONLY) mean += sqrtf(av[r] * oc.vs[r] + oc.bv[r]) * e[r];
+        if (!MEAN_ONLY) { sd[r] = sqrtf(av[r] * oc.vs[r] + oc.bv[r]); mean += sd[r] * e[r]; }
         res[r] = a.relu ? fmaxf(mean, 0.f) : mean;
+    }
+    if (!MEAN_ONLY && a.std_out) {
+        float* sp = a.std_out + (size_t)b * a.O + o;
+        if (c.ovec) *reinterpret_cast<float4*>(sp) = make_float4(sd[0], sd[1], sd[2], sd[3]);
+        else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (o + r < a.O) sp[r] = sd[r];
+        }
     }
 }
 
@@ -1051,10 +1061,10 @@ int launch_split(const GemmArgs& a, bool mean_only, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int lbbnn_lrt_gemm(const float* x, int ldx, const void* e_w, const void* var_w, int ld,
-                              const float* bias_mean, const float* bias_var, const float* var_scale,
-                              const float* eps, const uint64_t* rng, uint32_t rng_stream, int64_t row_offset,
-                              float* out, int ldo, int B, int I, int O, int flags, void* stream) {
+static int lrt_gemm_impl(const float* x, int ldx, const void* e_w, const void* var_w, int ld,
+                         const float* bias_mean, const float* bias_var, const float* var_scale,
+                         const float* eps, const uint64_t* rng, uint32_t rng_stream, int64_t row_offset,
+                         float* out, int ldo, float* std_out, int B, int I, int O, int flags, void* stream) {
     if (!x || !e_w || !out) return LBBNN_E_NULL;
     if (B <= 0 || I <= 0 || O <= 0 || ldx < I || ldo < O) return LBBNN_E_SHAPE;
     if (flags & ~(LBBNN_F_RELU | LBBNN_F_MEAN_ONLY | LBBNN_F_SPLIT16 | LBBNN_F_LOG_SOFTMAX)) return LBBNN_E_FLAGS;
@@ -1069,7 +1079,7 @@ extern "C" int lbbnn_lrt_gemm(const float* x, int ldx, const void* e_w, const vo
     GemmArgs a;
     a.x = x; a.e_w = static_cast<const float*>(e_w); a.var_w = static_cast<const float*>(var_w);
     a.bias_mean = bias_mean; a.bias_var = bias_var; a.var_scale = var_scale;
-    a.eps = eps; a.rng = rng; a.out = out; a.row_offset = row_offset;
+    a.eps = eps; a.rng = rng; a.out = out; a.std_out = std_out; a.row_offset = row_offset;
     a.ldx = ldx; a.ld = ld; a.ldo = ldo; a.B = B; a.I = I; a.O = O;
     a.rng_stream = rng_stream; a.relu = (flags & LBBNN_F_RELU) ? 1 : 0;
     a.log_softmax = (flags & LBBNN_F_LOG_SOFTMAX) ? 1 : 0;
@@ -1099,4 +1109,22 @@ extern "C" int lbbnn_lrt_gemm(const float* x, int ldx, const void* e_w, const vo
     const long blocks_big = (long)((O + 79) / 80) * ((B + 127) / 128);
     if (blocks_big >= 256) return launch_cfg<5, 2, 4>(a, mean_only, xvec, s);
     return launch_cfg<5, 1, 2>(a, mean_only, xvec, s);
+}
+
+extern "C" int lbbnn_lrt_gemm(const float* x, int ldx, const void* e_w, const void* var_w, int ld,
+                              const float* bias_mean, const float* bias_var, const float* var_scale,
+                              const float* eps, const uint64_t* rng, uint32_t rng_stream, int64_t row_offset,
+                              float* out, int ldo, int B, int I, int O, int flags, void* stream) {
+    return lrt_gemm_impl(x, ldx, e_w, var_w, ld, bias_mean, bias_var, var_scale, eps, rng, rng_stream, row_offset,
+                         out, ldo, nullptr, B, I, O, flags, stream);
+}
+
+extern "C" int lbbnn_lrt_gemm_train(const float* x, int ldx, const void* e_w, const void* var_w, int ld,
+                                    const float* bias_mean, const float* bias_var, const float* var_scale,
+                                    const float* eps, const uint64_t* rng, uint32_t rng_stream, int64_t row_offset,
+                                    float* out, int ldo, float* std_out, int B, int I, int O, int flags, void* stream) {
+    if ((flags & LBBNN_F_MEAN_ONLY) && std_out) return LBBNN_E_FLAGS;
+    if ((flags & LBBNN_F_LOG_SOFTMAX) && std_out) return LBBNN_E_FLAGS;
+    return lrt_gemm_impl(x, ldx, e_w, var_w, ld, bias_mean, bias_var, var_scale, eps, rng, rng_stream, row_offset,
+                         out, ldo, std_out, B, I, O, flags, stream);
 }

@@ -35,13 +35,21 @@ _layer_ids = itertools.count()
 
 
 class _BayesLinearFn(torch.autograd.Function):
-    """Forward: HIP kernels.  Backward: torch-op recompute on the GPU (see _grad.py)."""
+    """Forward: HIP kernels.  Backward (hybrid): the four large products run on the same HIP GEMM kernels
+    as the forward --
+        dX   = G_m . W_m + 2 x (.) (G_v . W_v)        G_m = g (.) relu-mask,  G_v = G_m eps / (2 std)
+        dW_m = G_m^T . x ,   dW_v = G_v^T . x^2
+    -- and only the O(O*I) parameter chain (operands -> mu, rho, lambda, z, flows) and the KL are
+    differentiated by torch autograd on the GPU (``_grad.*_param_graph``).  Measured on the headline net:
+    see DESIGN.md."""
 
     @staticmethod
     def forward(ctx, layer, x, cfg, *params):
-        out, kl, saved = layer._forward_hip(x, cfg, save_rng=True)
+        out, kl, saved = layer._forward_hip(x, cfg, save_rng=True, want_std=cfg[0])
         ctx.layer, ctx.cfg, ctx.saved = layer, cfg, saved
-        ctx.save_for_backward(x, *params)
+        std = saved.pop("std", None)
+        ctx.has_std = std is not None
+        ctx.save_for_backward(x, out, *([std] if std is not None else []), *params)
         if kl is None:
             kl = out.new_zeros(())
         return out, kl
@@ -49,20 +57,54 @@ class _BayesLinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out, g_kl):
         layer, cfg = ctx.layer, ctx.cfg
-        x, *params = ctx.saved_tensors
-        noise = layer._noise_for_backward(ctx.saved, x.shape[0])
+        stochastic, want_kl, relu = cfg
+        tens = list(ctx.saved_tensors)
+        x, out = tens[0], tens[1]
+        std = tens[2] if ctx.has_std else None
+        params = tens[3 if ctx.has_std else 2:]
+        B = x.shape[0]
+        noise = layer._noise_for_backward(ctx.saved, B)
+        g = g_out.contiguous()
+        if relu:
+            g = g * (out > 0)
+        g_v = None
+        if stochastic:
+            g_v = g * noise["eps_out"] / (2 * std)
+        # ---- parameter-side graph (small / elementwise) under autograd
         with torch.enable_grad():
-            xs = x.detach().requires_grad_(ctx.needs_input_grad[1])
             ps = [p.detach().requires_grad_(True) for p in params]
-            out_t, kl_t = layer._forward_torch(xs, ps, cfg, noise)
-            outs, gouts = [out_t], [g_out]
-            if kl_t is not None:
-                outs.append(kl_t)
-                gouts.append(g_kl)
-            wrt = ([xs] if xs.requires_grad else []) + ps
-            grads = list(torch.autograd.grad(outs, wrt, gouts, allow_unused=True))
-        gx = grads.pop(0) if xs.requires_grad else None
+            pg = layer._param_graph(ps, cfg, noise)
+        Wm = pg["Wm"].detach()
+        # ---- the four big products on the HIP GEMM kernels
+        gx = None
+        if ctx.needs_input_grad[1]:
+            gx = _hip_matmul_nt(g, ops.transpose_operand, Wm)
+            if stochastic:
+                gx = gx + 2 * x * _hip_matmul_nt(g_v, ops.transpose_operand, pg["Wv"].detach())
+        gT = g.t().contiguous()
+        dWm = _hip_matmul_nt(gT, ops.transpose_operand, x)
+        outs, gouts = [pg["Wm"], pg["bmean"]], [dWm, g.sum(0)]
+        if stochastic:
+            dWv = _hip_matmul_nt(g_v.t().contiguous(), ops.transpose_operand, x, square=True)
+            outs += [pg["Wv"], pg["bvar"]]
+            gouts += [dWv, g_v.sum(0)]
+        if want_kl and pg["kl"] is not None:
+            outs.append(pg["kl"])
+            gouts.append(g_kl)
+        grads = torch.autograd.grad(outs, ps, gouts, allow_unused=True)
         return (None, gx, None, *grads)
+
+
+def _hip_matmul_nt(a, transpose_fn, w, square=False):
+    """a (M,K) @ f(w) (K,N) with f = identity or square, through lbbnn_lrt_gemm (mean-only):
+    the operand is f(w)^T = [N][ld(K)], built by lbbnn_transpose_operand."""
+    M, K = a.shape
+    N = w.shape[1]
+    assert w.shape[0] == K
+    split = (ops.get_precision() == "bf16x3" and ops.split_eligible(K, N)
+             and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0)
+    op = transpose_fn(w.contiguous(), square=square, split=split)
+    return ops.lrt_gemm(a, op, None, I=K, O=N, mean_only=True, split=split)
 
 
 class _BayesLinearBase(nn.Module):
@@ -150,9 +192,10 @@ class _BayesLinearBase(nn.Module):
         d.q0_mean = None
         return ws, noise
 
-    def _forward_hip(self, x, cfg, advance=True, save_rng=False):
+    def _forward_hip(self, x, cfg, advance=True, save_rng=False, want_std=False):
         """One layer, sequentially on the current stream: prep kernels, GEMM, RNG advance.
-        ``save_rng`` snapshots the device RNG state so backward can re-create the in-kernel draws."""
+        ``save_rng`` snapshots the device RNG state so backward can re-create the in-kernel draws;
+        ``want_std`` also stores sqrt(var) (needed by the backward)."""
         rng, st = None, None
         saved = {"noise": self.noise}
         if self._uses_rng(cfg):
@@ -164,7 +207,10 @@ class _BayesLinearBase(nn.Module):
         self._last_masks = None
         self._prep(cfg, rng, kl_layer=kl)
         saved["masks"] = self._last_masks
-        out = self._gemm(x, cfg, rng)
+        std = torch.empty((x.shape[0], self.out_features), dtype=torch.float32, device=x.device) if want_std else None
+        out = self._gemm(x, cfg, rng, std_out=std)
+        if std is not None:
+            saved["std"] = std
         if st is not None and advance:
             st.advance(1)
         return out, kl, saved
@@ -214,14 +260,15 @@ class LRTBayesianLinear(_BayesLinearBase):
         ops.kl_finalize(ws.kl_rows, self.bias_mu, self.bias_rho, priors=self.priors, kl_layer=kl_layer,
                         kl_out=kl_total, accumulate=accumulate)
 
-    def _gemm(self, x, cfg, rng, log_softmax=False):
+    def _gemm(self, x, cfg, rng, log_softmax=False, std_out=None):
         stochastic, _, relu = cfg
         ws = self._workspace()
         eps = (self.noise or {}).get("eps_out")
         return ops.lrt_gemm(x, ws.e_w, ws.var_w, I=self.in_features, O=self.out_features,
                             bias_mean=self.bias_mu, bias_var=ws.bias_var, eps=eps, rng=rng,
                             rng_stream=ops.STREAM_EPS_OUT * 64 + self._layer_id, row_offset=self.row_offset,
-                            relu=relu, mean_only=not stochastic, log_softmax=log_softmax, split=self._split_now)
+                            relu=relu, mean_only=not stochastic, log_softmax=log_softmax, split=self._split_now,
+                            std_out=std_out)
 
     def _noise_for_backward(self, saved, B):
         if saved.get("noise") and "eps_out" in saved["noise"]:
@@ -234,6 +281,10 @@ class LRTBayesianLinear(_BayesLinearBase):
     def _forward_torch(self, x, ps, cfg, noise):
         P = dict(zip(self._names, ps))
         return _grad.lrt_torch(x, P, noise, stochastic=cfg[0], want_kl=cfg[1], priors=self.priors, relu=cfg[2])
+
+    def _param_graph(self, ps, cfg, noise):
+        P = dict(zip(self._names, ps))
+        return _grad.lrt_param_graph(P, stochastic=cfg[0], want_kl=cfg[1], priors=self.priors)
 
 
 class MNFBayesianLinear(_BayesLinearBase):
@@ -396,14 +447,14 @@ class MNFBayesianLinear(_BayesLinearBase):
                         r0_b1=self.r0_b1, r0_b2=self.r0_b2, scal=ws.scal, rng=rng,
                         layer_id=self._layer_id, kl_layer=kl_layer, kl_out=kl_total, accumulate=accumulate)
 
-    def _gemm(self, x, cfg, rng, log_softmax=False):
+    def _gemm(self, x, cfg, rng, log_softmax=False, std_out=None):
         stochastic, _, relu = cfg
         ws = self._workspace()
         return ops.lrt_gemm(x, ws.e_w, ws.var_w, I=self.in_features, O=self.out_features,
                             bias_mean=self.bias_mu, bias_var=ws.bias_var, eps=(self.noise or {}).get("eps_out"),
                             rng=rng, rng_stream=ops.STREAM_EPS_OUT * 64 + self._layer_id,
                             row_offset=self.row_offset, relu=relu, mean_only=not stochastic,
-                            log_softmax=log_softmax, split=self._split_now)
+                            log_softmax=log_softmax, split=self._split_now, std_out=std_out)
 
     def _noise_for_backward(self, saved, B):
         masks = saved.get("masks") or {}
@@ -423,7 +474,7 @@ class MNFBayesianLinear(_BayesLinearBase):
         n.update(masks)
         return n
 
-    def _forward_torch(self, x, ps, cfg, noise):
+    def _unpack_params(self, ps):
         n = len(self._names)
         P = dict(zip(self._names, ps[:n]))
         rest = list(ps[n:])
@@ -440,8 +491,17 @@ class MNFBayesianLinear(_BayesLinearBase):
                     trs.append(dict(zip(names, rest[:len(names)])))
                     rest = rest[len(names):]
                 specs.append((flow.kind, trs))
+        return P, specs
+
+    def _forward_torch(self, x, ps, cfg, noise):
+        P, specs = self._unpack_params(ps)
         return _grad.mnf_planar_torch(x, P, specs[0], specs[1], noise, stochastic=cfg[0], want_kl=cfg[1],
                                       priors=self.priors, relu=cfg[2])
+
+    def _param_graph(self, ps, cfg, noise):
+        P, specs = self._unpack_params(ps)
+        return _grad.mnf_param_graph(P, specs[0], specs[1], noise, stochastic=cfg[0], want_kl=cfg[1],
+                                     priors=self.priors)
 
 
 class _NetworkBase(nn.Module):

@@ -153,7 +153,7 @@ GEMM_EVENTS = None
 def lrt_gemm(x, e_w, var_w, *, I: int, O: int, bias_mean=None, bias_var=None, var_scale=None,
              eps=None, rng: Optional[torch.Tensor] = None, rng_stream: int = 0, row_offset: int = 0,
              relu: bool = False, mean_only: bool = False, log_softmax: bool = False,
-             split: bool = False, out: Optional[torch.Tensor] = None):
+             split: bool = False, out: Optional[torch.Tensor] = None, std_out: Optional[torch.Tensor] = None):
     """lbbnn_lrt_gemm: out = x.e_w^T + b [+ sqrt(x^2.var_w^T + bv) * eps] [ReLU]."""
     if x.dim() != 2 or x.shape[1] != I:
         raise RuntimeError("bnn_amd: input must be (B,%d), got %s" % (I, tuple(x.shape)))
@@ -170,11 +170,18 @@ def lrt_gemm(x, e_w, var_w, *, I: int, O: int, bias_mean=None, bias_var=None, va
     if GEMM_EVENTS is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    rc = _lib.lib().lbbnn_lrt_gemm(
-        _ptr_rows(x, "input"), x.stride(0), _ptr(e_w), _ptr(var_w), operand_ld(I),
-        _ptr(bias_mean), _ptr(bias_var), _ptr(var_scale), _ptr(eps, "eps"),
-        rng.data_ptr() if rng is not None else None, rng_stream, row_offset,
-        out.data_ptr(), out.stride(0), B, I, O, flags, _stream())
+    if std_out is None:
+        rc = _lib.lib().lbbnn_lrt_gemm(
+            _ptr_rows(x, "input"), x.stride(0), _ptr(e_w), _ptr(var_w), operand_ld(I),
+            _ptr(bias_mean), _ptr(bias_var), _ptr(var_scale), _ptr(eps, "eps"),
+            rng.data_ptr() if rng is not None else None, rng_stream, row_offset,
+            out.data_ptr(), out.stride(0), B, I, O, flags, _stream())
+    else:
+        rc = _lib.lib().lbbnn_lrt_gemm_train(
+            _ptr_rows(x, "input"), x.stride(0), _ptr(e_w), _ptr(var_w), operand_ld(I),
+            _ptr(bias_mean), _ptr(bias_var), _ptr(var_scale), _ptr(eps, "eps"),
+            rng.data_ptr() if rng is not None else None, rng_stream, row_offset,
+            out.data_ptr(), out.stride(0), _ptr(std_out, "std_out"), B, I, O, flags, _stream())
     _lib.check(rc, "lbbnn_lrt_gemm")
     if ev is not None:
         ev[1].record()
@@ -235,6 +242,19 @@ def kl_finalize(kl_rows, bias_mu, bias_rho, *, priors: Priors, act_mu=None, act_
         _ptr(scal), ctypes.byref(priors), rng.data_ptr() if rng is not None else None, layer_id,
         _ptr(kl_out), _ptr(kl_layer), 1 if accumulate else 0, _stream())
     _lib.check(rc, "lbbnn_kl_finalize")
+
+
+def transpose_operand(src: torch.Tensor, *, square: bool = False, split: bool = False,
+                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """lbbnn_transpose_operand: (R,C) fp32 -> GEMM operand [C][operand_ld(R)] holding src^T (squared if asked)."""
+    R, C = src.shape
+    ld = operand_ld(R)
+    if out is None:
+        out = torch.empty((C, ld), dtype=torch.float32, device=src.device)
+    rc = _lib.lib().lbbnn_transpose_operand(_ptr_rows(src, "src"), R, C, src.stride(0), out.data_ptr(), ld,
+                                            1 if square else 0, F_SPLIT16 if split else 0, _stream())
+    _lib.check(rc, "lbbnn_transpose_operand")
+    return out
 
 
 def log_softmax_rows(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:

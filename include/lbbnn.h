@@ -284,6 +284,28 @@ int lbbnn_gate_sample(const lbbnn_gate_args_t* args, const uint64_t* rng, void* 
  */
 int lbbnn_vd_operands(const float* theta, void* e_w, void* var_w, int ld, int I, int O, int flags, void* stream);
 
+
+/* ---------------------------------------------------------------------------------------------
+ * Training support (the backward of loss.backward(), LBBNN-GP-MF-LRT.py:225).
+ *
+ * lbbnn_lrt_gemm_train = lbbnn_lrt_gemm that additionally stores std_out[b,o] = sqrt(var[b,o])
+ * (pre-ReLU), which the backward needs for  dL/dvar = g * eps / (2 * std).
+ *
+ * lbbnn_transpose_operand: dst[c][r] = src[r][c] (squared when `square`) for src (R,C) with row stride
+ * lds_src, written as a GEMM operand [C][ld] (ld = lbbnn_operand_ld(R), zero tail; fp32 or, with
+ * LBBNN_F_SPLIT16, bf16 hi/lo planes).  With it every backward product is an "x . operand^T" GEMM on the
+ * same kernels as the forward:
+ *   dX  = G_m . W_m + 2 x (.) (G_v . W_v)      operands W_m^T, W_v^T          (K = O)
+ *   dW_m = G_m^T . x ,  dW_v = G_v^T . x^2     operands x^T, (x^2)^T          (K = B)
+ */
+int lbbnn_lrt_gemm_train(const float* x, int ldx, const void* e_w, const void* var_w, int ld,
+                         const float* bias_mean, const float* bias_var, const float* var_scale,
+                         const float* eps, const uint64_t* rng, uint32_t rng_stream, int64_t row_offset,
+                         float* out, int ldo, float* std_out, int B, int I, int O, int flags, void* stream);
+
+int lbbnn_transpose_operand(const float* src, int R, int C, int lds_src, void* dst, int ld,
+                            int square, int flags, void* stream);
+
 /* rng[1] += delta (device side, so graph replays draw fresh noise). */
 int lbbnn_rng_advance(uint64_t* rng, uint64_t delta, void* stream);
 
