@@ -994,10 +994,15 @@ inline size_t lds_request(size_t needed, long nblocks) {
 template <typename K>
 inline int launch_one(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s, const GemmArgs& a) {
     if (lds > 64 * 1024) {
-        // above 64 KB the dynamic-LDS limit of the function has to be raised (host-side attribute, not a stream op)
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
+        // above 64 KB the dynamic-LDS limit of the function has to be raised (host-side attribute, not a stream
+        // op); done once per kernel instantiation and size (this template is instantiated per kernel type K).
+        static size_t raised = 0;
+        if (lds > raised) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+            raised = lds;
+        }
     }
     hipLaunchKernelGGL(kernel, grid, block, lds, s, a);
     return (int)hipGetLastError();

@@ -1,0 +1,39 @@
+"""HIP-graph capture of launch-bound loops (one process per GPU; graphs instead of a tracing compiler).
+
+``make_graphed_train_step`` captures ONE full training step -- forward (HIP kernels), backward (HIP GEMMs +
+the torch parameter chain) and the optimizer update -- into a HIP graph and returns a callable that replays
+it on new data.  The eager step of the headline net issues ~760 kernel launches for 2.6 ms of GPU work and is
+host-bound at ~11.7 ms; replayed from a graph it runs at GPU speed.  Noise stays fresh across replays because
+the Philox {seed, offset} pair lives in device memory and is advanced by a kernel inside the graph.
+"""
+import torch
+
+
+def make_graphed_train_step(net, optimizer, loss_fn, example_x, example_y, warmup: int = 3):
+    """loss_fn(net, x, y) -> scalar loss.  The optimizer must be capture-safe (e.g. Adam(capturable=True)).
+    Returns step(x, y) -> loss tensor (a static buffer, overwritten by the next replay)."""
+    dev = example_x.device
+    static_x, static_y = example_x.clone(), example_y.clone()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        for _ in range(warmup):
+            optimizer.zero_grad(set_to_none=True)
+            loss_fn(net, static_x, static_y).backward()
+            optimizer.step()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    optimizer.zero_grad(set_to_none=True)
+    with torch.cuda.graph(graph):
+        static_loss = loss_fn(net, static_x, static_y)
+        static_loss.backward()
+        optimizer.step()
+
+    def step(x, y):
+        static_x.copy_(x)
+        static_y.copy_(y)
+        graph.replay()
+        return static_loss
+
+    step.graph = graph
+    return step

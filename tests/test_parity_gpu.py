@@ -699,3 +699,32 @@ def test_vd_network_full_size_and_training(bnn, dev):
         loss.backward(); opt.step()
         vals.append(float(loss.detach()))
     assert all(math.isfinite(v) for v in vals) and vals[-1] < vals[0]
+
+
+def test_graphed_training_step_subprocess():
+    """Whole training step (HIP forward + hybrid backward + Adam) captured in a HIP graph and replayed.
+    Runs in its own process: capture wants a clean autograd state."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, torch
+sys.path.insert(0, %r)
+import bnn_amd
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+net = bnn_amd.mnf.BayesianNetwork((784, 128, 64, 10), 2, z_flow_type="Planar", r_flow_type="Planar").to(dev).train()
+opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True)
+x = torch.rand(256, 1, 28, 28, device=dev); y = torch.randint(0, 10, (256,), device=dev)
+lf = lambda n, a, b: torch.nn.functional.nll_loss(n(a, sample=True), b, reduction="sum") + n.kl() / 100
+step = bnn_amd.graphs.make_graphed_train_step(net, opt, lf, x, y)
+vals = [float(step(x, y).detach().clone()) for _ in range(30)]
+torch.cuda.synchronize()
+assert all(v == v for v in vals), vals
+assert vals[-1] < vals[0], (vals[0], vals[-1])
+assert len(set(vals)) > 20
+print("GRAPH_OK", vals[0], vals[-1])
+""" % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "GRAPH_OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])

@@ -23,7 +23,8 @@ def step(backward=True):
     return loss
 
 
-for name, bw in (("forward only (autograd graph built)", False), ("forward + backward + Adam", True)):
+MODE = sys.argv[1] if len(sys.argv) > 1 else "eager"
+for name, bw in ((("forward only (autograd graph built)", False), ("forward + backward + Adam", True)) if MODE == "eager" else ()):
     for _ in range(3):
         step(bw)
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -32,3 +33,21 @@ for name, bw in (("forward only (autograd graph built)", False), ("forward + bac
         step(bw)
     torch.cuda.synchronize()
     print("%s: %.3f ms/step" % (name, (time.perf_counter() - t0) / n * 1e3))
+
+# ---- the same step captured in a HIP graph (fresh process: `train_step_time.py graph`)
+if MODE != "graph":
+    sys.exit(0)
+opt2 = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True)
+lf = lambda n, a, b: torch.nn.functional.nll_loss(n(a, sample=True), b, reduction="sum") + n.kl() / 15
+gstep = bnn_amd.graphs.make_graphed_train_step(net, opt2, lf, x, y)
+for _ in range(3):
+    gstep(x, y)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+n = 50
+losses = []
+for _ in range(n):
+    losses.append(gstep(x, y).clone())
+torch.cuda.synchronize()
+print("HIP-graph replay of forward + backward + Adam: %.3f ms/step" % ((time.perf_counter() - t0) / n * 1e3))
+ls = [float(l) for l in losses]
+print("loss first/last: %.1f -> %.1f (must decrease; distinct values => fresh noise per replay: %s)" % (ls[0], ls[-1], len(set(ls)) > 40))
