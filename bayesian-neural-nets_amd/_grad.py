@@ -123,6 +123,37 @@ def mnf_param_graph(P, zf, rf, noise, *, stochastic, want_kl, priors):
     return g
 
 
+def lrt_vector_graph(P, *, stochastic, want_kl, priors):
+    """Bias-only part of the LRT layer; the (O,I) chain is lbbnn_weight_pass_backward's."""
+    return {"z_k": None, "z2": None, "bmean": P["bias_mu"],
+            "bvar": _sigma(P["bias_rho"]) ** 2 if stochastic else None,
+            "kl": _kl_bias(P["bias_mu"], P["bias_rho"], priors) if want_kl else None}
+
+
+def mnf_vector_graph(P, zf, rf, noise, act_mu, act_var, *, stochastic, want_kl, priors):
+    """Vector-sized part of the MNF layer (LBBNN-GP-MF-MNF.py:182-187, 199-233): flows, q/r log-densities and
+    the bias terms, as functions of the vector parameters and of the auxiliary activations act_mu / act_var
+    (leaves here: their dependence on the weights is differentiated by lbbnn_weight_pass_backward)."""
+    q0_std = P["q0_log_var"].exp().sqrt()
+    z_k, _ = _flow(P["q0_mean"] + q0_std * noise["eps_z"], zf, noise.get("zmask"))
+    g = {"z_k": z_k, "z2": None, "bmean": P["bias_mu"],
+         "bvar": _sigma(P["bias_rho"]) ** 2 if stochastic else None, "kl": None}
+    if want_kl:
+        z0 = P["q0_mean"] + q0_std * noise["eps_z2"]
+        z2, log_det_q = _flow(z0, zf, noise.get("zmask2"))
+        log_q0 = (-0.5 * math.log(math.pi) - 0.5 * P["q0_log_var"]
+                  - 0.5 * ((z0 - P["q0_mean"]) ** 2 / P["q0_log_var"].exp())).sum()
+        act = torch.tanh(act_mu + act_var.sqrt() * noise["eps_act"])
+        m = act.mean()
+        mean_r, log_var_r = P["r0_b1"] * m, P["r0_b2"] * m
+        z_b, log_det_r = _flow(z2, rf, noise.get("rmask"))
+        log_rb = (-0.5 * math.log(math.pi) - 0.5 * log_var_r
+                  - 0.5 * ((z_b[-1] - mean_r) ** 2 / log_var_r.exp())).sum()
+        g["z2"] = z2
+        g["kl"] = _kl_bias(P["bias_mu"], P["bias_rho"], priors) + (-log_det_q + log_q0) - (log_det_r + log_rb)
+    return g
+
+
 def lrt_torch(x, P, noise, *, stochastic, want_kl, priors, relu):
     """LBBNN-GP-MF-LRT.py:166-197 as differentiable torch ops. P: dict of tensors."""
     alpha = _alpha(P["lambdal"])

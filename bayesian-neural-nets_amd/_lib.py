@@ -64,6 +64,14 @@ class GateArgs(ctypes.Structure):
                [(n, c_i) for n in ("O", "I", "ld", "mode", "exact", "want_lp", "flags")] + [("layer_id", c_u32)]
 
 
+class WpbArgs(ctypes.Structure):
+    """lbbnn_wpb_args_t"""
+    _fields_ = [(n, c_p) for n in ("mu", "rho", "lambdal", "dWm", "dWv", "z_fwd", "z_kl", "r0_c",
+                                   "da_mu", "da_var", "g_kl")] + [("priors", Priors)] + \
+               [(n, c_p) for n in ("dmu", "drho", "dlambdal", "dz_fwd", "dz_kl", "dr0_c", "work")] + \
+               [("O", c_i), ("I", c_i)]
+
+
 # name -> (restype, argtypes); must list every symbol include/lbbnn.h declares
 SIGNATURES = {
     "lbbnn_abi_version": (c_i, []),
@@ -76,6 +84,8 @@ SIGNATURES = {
     "lbbnn_lrt_gemm_train": (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_u32, c_i64,
                                    c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p]),
     "lbbnn_transpose_operand": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p]),
+    "lbbnn_weight_pass_backward_workspace": (c_i64, [c_i, c_i]),
+    "lbbnn_weight_pass_backward": (c_i, [ctypes.POINTER(WpbArgs), c_p]),
     "lbbnn_mnf_flow_planar": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p,
                                     c_p, c_u32, c_p, c_p, c_p, c_i, c_i, c_p]),
     "lbbnn_flow_dense_workspace": (c_i64, [c_i]),

@@ -1,0 +1,160 @@
+// K1b -- analytic backward of the fused weight pass (see include/lbbnn.h).  HBM-bound: 20 B read + 12 B
+// written per weight.  A 256-thread workgroup owns RB = 8 consecutive rows; a thread owns one column group
+// (4 columns, or 1 on the unaligned path) at a time and walks the 8 rows, so every global access is a
+// coalesced row segment and the three column sums (dz_fwd, dz_kl, dr0_c) accumulate in registers; the
+// per-row-block partials are reduced in a fixed order by a second launch (deterministic, no float atomics).
+#include <cmath>
+#include "lbbnn_device.h"
+#include "lbbnn_internal.h"
+
+namespace {
+
+using namespace lbbnn;
+constexpr int RB = 8;
+
+struct Consts { float mp, inv_sp2, log_sp, log_ap, log_1map, gk; };
+
+// gradients of one weight; returns dmu, drho, dlam and the three column-sum contributions
+__device__ __forceinline__ void elem_bwd(float mu, float rho, float lam, float gWm, float gWv, float zf, float zk, float rc,
+                                         float dam, float dav, const Consts& c, bool has_kl, bool has_act,
+                                         float& dmu, float& drho, float& dlam, float& czf, float& czk, float& crc) {
+    const float ex = __expf(-lam);
+    const float alpha = __frcp_rn(1.f + ex);
+    const float er = __expf(rho);
+    const float sigma = er < 0.04f ? er * (1.f + er * (-0.5f + er * (0.33333334f + er * (-0.25f + er * 0.2f)))) : log1pf(er);
+    const float dsig = er * __frcp_rn(1.f + er);              // d softplus / d rho = sigmoid(rho)
+    const float a2 = alpha * alpha, s2 = sigma * sigma;
+    float Gmu = gWm * alpha * zf;
+    float Gsig = gWv * 2.f * sigma * a2;
+    float Gal = gWm * mu * zf + gWv * 2.f * s2 * alpha;
+    czf = gWm * mu * alpha;
+    czk = 0.f; crc = 0.f;
+    if (has_kl) {
+        const float d = mu * zk - c.mp;
+        const float one_m = 1.f - alpha;
+        const float T = (c.log_sp - __logf(sigma)) - 0.5f + (__logf(alpha) - c.log_ap) + (s2 + d * d) * 0.5f * c.inv_sp2;
+        Gmu += c.gk * alpha * d * zk * c.inv_sp2;
+        Gsig += c.gk * alpha * (sigma * c.inv_sp2 - __frcp_rn(sigma));
+        Gal += c.gk * (T - (__logf(one_m) - c.log_1map));
+        czk = c.gk * alpha * d * mu * c.inv_sp2;
+    }
+    if (has_act) {
+        const float ma = mu * alpha;
+        Gmu += dam * rc * zk * alpha;
+        Gal += dam * rc * zk * mu + dav * rc * rc * 2.f * s2 * alpha;
+        Gsig += dav * rc * rc * 2.f * sigma * a2;
+        czk += dam * rc * ma;
+        crc = dam * zk * ma + dav * 2.f * rc * s2 * a2;
+    }
+    dmu = Gmu;
+    drho = Gsig * dsig;
+    dlam = Gal * alpha * (1.f - alpha);
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void weight_pass_bwd_kernel(const lbbnn_wpb_args_t a, int nblk, int ldw) {
+    const int rb = blockIdx.x, tid = threadIdx.x;
+    const int r0 = rb * RB, r1 = min(r0 + RB, a.O);
+    Consts c;
+    c.mp = a.priors.mu_prior;
+    c.inv_sp2 = 1.f / (a.priors.sigma_prior * a.priors.sigma_prior);
+    c.log_sp = logf(a.priors.sigma_prior); c.log_ap = logf(a.priors.alpha_prior); c.log_1map = logf(1.f - a.priors.alpha_prior);
+    const bool has_kl = a.g_kl != nullptr, has_act = a.da_mu != nullptr;
+    c.gk = has_kl ? a.g_kl[0] : 0.f;
+    float* const p_zf = a.work + (size_t)rb * 3 * ldw;
+    float* const p_zk = p_zf + ldw;
+    float* const p_rc = p_zk + ldw;
+    const int ngroups = (a.I + W - 1) / W;
+    for (int j = tid; j < ngroups; j += 256) {
+        const int i0 = j * W;
+        float zf[W], zk[W], rc[W], szf[W], szk[W], src[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            const int i = i0 + k;
+            const bool in = i < a.I;
+            zf[k] = (a.z_fwd && in) ? a.z_fwd[i] : 1.f;
+            zk[k] = (a.z_kl && in) ? a.z_kl[i] : 1.f;
+            rc[k] = (a.r0_c && in) ? a.r0_c[i] : 0.f;
+            szf[k] = szk[k] = src[k] = 0.f;
+        }
+        for (int r = r0; r < r1; ++r) {
+            const size_t off = (size_t)r * a.I + i0;
+            const float dam = has_act ? a.da_mu[r] : 0.f, dav = has_act ? a.da_var[r] : 0.f;
+            float mu[W], rho[W], lam[W], gm[W], gv[W];
+            if (W == 4) {
+                const float4 t0 = *reinterpret_cast<const float4*>(a.mu + off), t1 = *reinterpret_cast<const float4*>(a.rho + off);
+                const float4 t2 = *reinterpret_cast<const float4*>(a.lambdal + off), t3 = *reinterpret_cast<const float4*>(a.dWm + off);
+                const float4 t4 = a.dWv ? *reinterpret_cast<const float4*>(a.dWv + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+                mu[0] = t0.x; mu[1] = t0.y; mu[2] = t0.z; mu[3] = t0.w;  rho[0] = t1.x; rho[1] = t1.y; rho[2] = t1.z; rho[3] = t1.w;
+                lam[0] = t2.x; lam[1] = t2.y; lam[2] = t2.z; lam[3] = t2.w;  gm[0] = t3.x; gm[1] = t3.y; gm[2] = t3.z; gm[3] = t3.w;
+                gv[0] = t4.x; gv[1] = t4.y; gv[2] = t4.z; gv[3] = t4.w;
+            } else {
+                mu[0] = a.mu[off]; rho[0] = a.rho[off]; lam[0] = a.lambdal[off]; gm[0] = a.dWm[off]; gv[0] = a.dWv ? a.dWv[off] : 0.f;
+            }
+            float dm[W], dr[W], dl[W];
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                float czf, czk, crc;
+                elem_bwd(mu[k], rho[k], lam[k], gm[k], gv[k], zf[k], zk[k], rc[k], dam, dav, c, has_kl, has_act,
+                         dm[k], dr[k], dl[k], czf, czk, crc);
+                szf[k] += czf; szk[k] += czk; src[k] += crc;
+            }
+            if (W == 4) {
+                *reinterpret_cast<float4*>(a.dmu + off) = make_float4(dm[0], dm[1], dm[2], dm[3]);
+                *reinterpret_cast<float4*>(a.drho + off) = make_float4(dr[0], dr[1], dr[2], dr[3]);
+                *reinterpret_cast<float4*>(a.dlambdal + off) = make_float4(dl[0], dl[1], dl[2], dl[3]);
+            } else {
+                a.dmu[off] = dm[0]; a.drho[off] = dr[0]; a.dlambdal[off] = dl[0];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            const int i = i0 + k;
+            if (i < a.I) { p_zf[i] = szf[k]; p_zk[i] = szk[k]; p_rc[i] = src[k]; }
+        }
+    }
+}
+
+// column sums: out[q][i] = sum over row blocks of work[b][q][i], fixed order
+__global__ __launch_bounds__(256) void wpb_reduce_kernel(const float* __restrict__ work, int nblk, int ldw, int I,
+                                                         float* dz_fwd, float* dz_kl, float* dr0_c) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= I) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int b = 0; b < nblk; ++b) {
+        const float* p = work + (size_t)b * 3 * ldw;
+        s0 += p[i]; s1 += p[ldw + i]; s2 += p[2 * ldw + i];
+    }
+    if (dz_fwd) dz_fwd[i] = s0;
+    if (dz_kl) dz_kl[i] = s1;
+    if (dr0_c) dr0_c[i] = s2;
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" int64_t lbbnn_weight_pass_backward_workspace(int O, int I) {
+    if (O <= 0 || I <= 0) return 0;
+    return (int64_t)((O + RB - 1) / RB) * 3 * (((int64_t)I + 3) & ~3LL);
+}
+
+extern "C" int lbbnn_weight_pass_backward(const lbbnn_wpb_args_t* p, void* stream) {
+    if (!p) return LBBNN_E_NULL;
+    const lbbnn_wpb_args_t& a = *p;
+    if (!a.mu || !a.rho || !a.lambdal || !a.dWm || !a.dmu || !a.drho || !a.dlambdal || !a.work) return LBBNN_E_NULL;
+    if (a.O <= 0 || a.I <= 0) return LBBNN_E_SHAPE;
+    if ((a.da_mu == nullptr) != (a.da_var == nullptr)) return LBBNN_E_NULL;
+    if (a.da_mu && (!a.z_kl || !a.r0_c)) return LBBNN_E_NULL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nblk = (a.O + RB - 1) / RB;
+    const int ldw = (a.I + 3) & ~3;
+    const bool vec = (a.I % 4 == 0) && al16(a.mu) && al16(a.rho) && al16(a.lambdal) && al16(a.dWm) &&
+                     (!a.dWv || al16(a.dWv)) && al16(a.dmu) && al16(a.drho) && al16(a.dlambdal);
+    if (vec) hipLaunchKernelGGL(weight_pass_bwd_kernel<4>, dim3(nblk), dim3(256), 0, s, a, nblk, ldw);
+    else     hipLaunchKernelGGL(weight_pass_bwd_kernel<1>, dim3(nblk), dim3(256), 0, s, a, nblk, ldw);
+    if (a.dz_fwd || a.dz_kl || a.dr0_c)
+        hipLaunchKernelGGL(wpb_reduce_kernel, dim3((a.I + 255) / 256), dim3(256), 0, s, a.work, nblk, ldw, a.I,
+                           a.dz_fwd, a.dz_kl, a.dr0_c);
+    return (int)hipGetLastError();
+}

@@ -46,6 +46,9 @@ class _BayesLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, layer, x, cfg, *params):
         out, kl, saved = layer._forward_hip(x, cfg, save_rng=True, want_std=cfg[0])
+        if layer._mnf and cfg[1]:
+            ws = layer._workspace()                 # auxiliary activations of this call (K1 by-products)
+            saved["act_mu"], saved["act_var"] = ws.act_mu.clone(), ws.act_var.clone()
         ctx.layer, ctx.cfg, ctx.saved = layer, cfg, saved
         std = saved.pop("std", None)
         ctx.has_std = std is not None
@@ -62,6 +65,7 @@ class _BayesLinearFn(torch.autograd.Function):
         x, out = tens[0], tens[1]
         std = tens[2] if ctx.has_std else None
         params = tens[3 if ctx.has_std else 2:]
+        mu, rho, lam = params[0], params[1], params[2]
         B = x.shape[0]
         noise = layer._noise_for_backward(ctx.saved, B)
         g = g_out.contiguous()
@@ -70,29 +74,52 @@ class _BayesLinearFn(torch.autograd.Function):
         g_v = None
         if stochastic:
             g_v = g * noise["eps_out"] / (2 * std)
-        # ---- parameter-side graph (small / elementwise) under autograd
+        # ---- vector-sized graph (flows, q/r densities, bias terms) under autograd: O(I + O) work
         with torch.enable_grad():
-            ps = [p.detach().requires_grad_(True) for p in params]
-            pg = layer._param_graph(ps, cfg, noise)
-        Wm = pg["Wm"].detach()
+            vs = [p.detach().requires_grad_(True) for p in params[3:]]
+            am = av = None
+            if layer._mnf and want_kl:
+                am = ctx.saved["act_mu"].requires_grad_(True)
+                av = ctx.saved["act_var"].requires_grad_(True)
+            vg = layer._vector_graph(vs, cfg, noise, am, av)
+        z_k = vg["z_k"].detach() if vg["z_k"] is not None else None
+        z2 = vg["z2"].detach() if vg["z2"] is not None else None
+        r0_c = params[3 + layer._vec_names.index("r0_c")] if (layer._mnf and want_kl) else None
+        g_kl = g_kl.contiguous() if want_kl else None
+        da_mu = da_var = None
+        if am is not None:
+            da_mu, da_var = torch.autograd.grad(vg["kl"], [am, av], g_kl, retain_graph=True)
         # ---- the four big products on the HIP GEMM kernels
         gx = None
         if ctx.needs_input_grad[1]:
-            gx = _hip_matmul_nt(g, ops.transpose_operand, Wm)
+            ws = layer._workspace()
+            bw = ws.backward_operands()
+            ops.weight_pass(mu, rho, lam, z_fwd=z_k, priors=layer.priors, e_w=bw[0],
+                            var_w=bw[1] if stochastic else None)
+            I = layer.in_features
+            gx = _hip_matmul_nt(g, ops.transpose_operand, bw[0][:, :I])
             if stochastic:
-                gx = gx + 2 * x * _hip_matmul_nt(g_v, ops.transpose_operand, pg["Wv"].detach())
-        gT = g.t().contiguous()
-        dWm = _hip_matmul_nt(gT, ops.transpose_operand, x)
-        outs, gouts = [pg["Wm"], pg["bmean"]], [dWm, g.sum(0)]
+                gx = gx + 2 * x * _hip_matmul_nt(g_v, ops.transpose_operand, bw[1][:, :I])
+        dWm = _hip_matmul_nt(g.t().contiguous(), ops.transpose_operand, x)
+        dWv = _hip_matmul_nt(g_v.t().contiguous(), ops.transpose_operand, x, square=True) if stochastic else None
+        # ---- K1b: the whole (O,I) chain in one pass
+        dmu, drho, dlam, dz_k, dz2, dr0c = ops.weight_pass_backward(
+            mu, rho, lam, dWm, dWv, z_fwd=z_k, z_kl=z2, r0_c=r0_c, da_mu=da_mu, da_var=da_var, g_kl=g_kl,
+            priors=layer.priors)
+        outs, gouts = [vg["bmean"]], [g.sum(0)]
         if stochastic:
-            dWv = _hip_matmul_nt(g_v.t().contiguous(), ops.transpose_operand, x, square=True)
-            outs += [pg["Wv"], pg["bvar"]]
-            gouts += [dWv, g_v.sum(0)]
-        if want_kl and pg["kl"] is not None:
-            outs.append(pg["kl"])
-            gouts.append(g_kl)
-        grads = torch.autograd.grad(outs, ps, gouts, allow_unused=True)
-        return (None, gx, None, *grads)
+            outs.append(vg["bvar"]); gouts.append(g_v.sum(0))
+        if z_k is not None:
+            outs.append(vg["z_k"]); gouts.append(dz_k)
+        if want_kl and vg["kl"] is not None:
+            outs.append(vg["kl"]); gouts.append(g_kl)
+            if z2 is not None:
+                outs.append(vg["z2"]); gouts.append(dz2)
+        vgrads = list(torch.autograd.grad(outs, vs, gouts, allow_unused=True))
+        if dr0c is not None:
+            k = layer._vec_names.index("r0_c")
+            vgrads[k] = dr0c if vgrads[k] is None else vgrads[k] + dr0c
+        return (None, gx, None, dmu, drho, dlam, *vgrads)
 
 
 def _hip_matmul_nt(a, transpose_fn, w, square=False):
@@ -103,7 +130,7 @@ def _hip_matmul_nt(a, transpose_fn, w, square=False):
     assert w.shape[0] == K
     split = (ops.get_precision() == "bf16x3" and ops.split_eligible(K, N)
              and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0)
-    op = transpose_fn(w.contiguous(), square=square, split=split)
+    op = transpose_fn(w if w.stride(1) == 1 else w.contiguous(), square=square, split=split)
     return ops.lrt_gemm(a, op, None, I=K, O=N, mean_only=True, split=split)
 
 
@@ -285,6 +312,12 @@ class LRTBayesianLinear(_BayesLinearBase):
     def _param_graph(self, ps, cfg, noise):
         P = dict(zip(self._names, ps))
         return _grad.lrt_param_graph(P, stochastic=cfg[0], want_kl=cfg[1], priors=self.priors)
+
+    _vec_names = ("bias_mu", "bias_rho")
+
+    def _vector_graph(self, vs, cfg, noise, act_mu=None, act_var=None):
+        P = dict(zip(self._vec_names, vs))
+        return _grad.lrt_vector_graph(P, stochastic=cfg[0], want_kl=cfg[1], priors=self.priors)
 
 
 class MNFBayesianLinear(_BayesLinearBase):
@@ -502,6 +535,13 @@ class MNFBayesianLinear(_BayesLinearBase):
         P, specs = self._unpack_params(ps)
         return _grad.mnf_param_graph(P, specs[0], specs[1], noise, stochastic=cfg[0], want_kl=cfg[1],
                                      priors=self.priors)
+
+    _vec_names = _names[3:]
+
+    def _vector_graph(self, vs, cfg, noise, act_mu=None, act_var=None):
+        P, specs = self._unpack_params([None, None, None] + list(vs))
+        return _grad.mnf_vector_graph(P, specs[0], specs[1], noise, act_mu, act_var, stochastic=cfg[0],
+                                      want_kl=cfg[1], priors=self.priors)
 
 
 class _NetworkBase(nn.Module):

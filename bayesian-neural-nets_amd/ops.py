@@ -144,6 +144,35 @@ def weight_pass(mu, rho, lambdal, *, z_fwd=None, z_kl=None, r0_c=None, bias_rho=
     _lib.check(rc, "lbbnn_weight_pass")
 
 
+def weight_pass_backward(mu, rho, lambdal, dWm, dWv=None, *, z_fwd=None, z_kl=None, r0_c=None, da_mu=None,
+                         da_var=None, g_kl=None, priors: Priors, work: Optional[torch.Tensor] = None):
+    """lbbnn_weight_pass_backward (K1b).  Returns (dmu, drho, dlambdal, dz_fwd, dz_kl, dr0_c); the three
+    vector gradients are None when the corresponding input vector was not given."""
+    O, I = mu.shape
+    a = _lib.WpbArgs()
+    a.mu, a.rho, a.lambdal = _ptr(mu, "weight_mu"), _ptr(rho, "weight_rho"), _ptr(lambdal, "lambdal")
+    for t, name in ((dWm, "dWm"), (dWv, "dWv")):
+        if t is not None and (t.shape != mu.shape or not t.is_contiguous()):
+            raise ValueError("bnn_amd: %s must be a contiguous (O,I) tensor" % name)
+    a.dWm, a.dWv = _ptr(dWm, "dWm"), _ptr(dWv)
+    a.z_fwd, a.z_kl, a.r0_c = _ptr(z_fwd), _ptr(z_kl), _ptr(r0_c)
+    a.da_mu, a.da_var, a.g_kl = _ptr(da_mu), _ptr(da_var), _ptr(g_kl)
+    a.priors = priors
+    f = dict(dtype=torch.float32, device=mu.device)
+    dmu, drho, dlam = torch.empty_like(mu), torch.empty_like(mu), torch.empty_like(mu)
+    dz_fwd = torch.empty(I, **f) if z_fwd is not None else None
+    dz_kl = torch.empty(I, **f) if (z_kl is not None and (g_kl is not None or da_mu is not None)) else None
+    dr0_c = torch.empty(I, **f) if (r0_c is not None and da_mu is not None) else None
+    need = _lib.lib().lbbnn_weight_pass_backward_workspace(O, I)
+    if work is None or work.numel() < need:
+        work = torch.empty(need, **f)
+    a.dmu, a.drho, a.dlambdal = dmu.data_ptr(), drho.data_ptr(), dlam.data_ptr()
+    a.dz_fwd, a.dz_kl, a.dr0_c, a.work = _ptr(dz_fwd), _ptr(dz_kl), _ptr(dr0_c), work.data_ptr()
+    a.O, a.I = O, I
+    _lib.check(_lib.lib().lbbnn_weight_pass_backward(ctypes.byref(a), _stream()), "lbbnn_weight_pass_backward")
+    return dmu, drho, dlam, dz_fwd, dz_kl, dr0_c
+
+
 # ----------------------------------------------------------------------------------------- K2
 # When set to a list, every lrt_gemm launch is bracketed by HIP events recorded on the launch
 # stream and (B, I, O, start, end) is appended -- bench.py's per-kernel roofline timing.
@@ -280,9 +309,16 @@ class LayerWorkspace:
         self.kl_rows = torch.empty(O, **f)
         self.bias_var = torch.empty(O, **f)
         self.kl = torch.zeros((), **f)
+        self._bw = None
         if mnf:
             self.act_mu = torch.empty(O, **f)
             self.act_var = torch.empty(O, **f)
             self.z_fwd = torch.empty(I, **f)
             self.z_kl = torch.empty(I, **f)
             self.scal = torch.empty(8, **f)
+
+    def backward_operands(self):
+        """fp32 operand pair the backward rebuilds for dX (allocated on first use)."""
+        if self._bw is None:
+            self._bw = (torch.empty_like(self.e_w), torch.empty_like(self.var_w))
+        return self._bw

@@ -306,6 +306,31 @@ int lbbnn_lrt_gemm_train(const float* x, int ldx, const void* e_w, const void* v
 int lbbnn_transpose_operand(const float* src, int R, int C, int lds_src, void* dst, int ld,
                             int square, int flags, void* stream);
 
+/* lbbnn_weight_pass_backward (K1b): analytic backward of the fused weight pass -- one pass over (O,I).
+ * Given the operand gradients from the backward GEMMs (dWm wrt e_w = mu*alpha*z_fwd, dWv wrt var_w =
+ * sigma^2*alpha^2), the upstream KL gradient *g_kl (device scalar, NULL = none) and the gradients of the
+ * auxiliary activations da_mu / da_var (O) (wrt act_mu / act_var, already scaled by g_kl; NULL = none), writes
+ *   dmu, drho, dlambdal (O,I)              chain through alpha = sigmoid(lambda), sigma = softplus(rho)
+ *   dz_fwd (I) = sum_o dWm*mu*alpha        dz_kl (I), dr0_c (I): column sums of the KL / auxiliary terms
+ * Column sums are deterministic: per-row-block partials in `work` (lbbnn_weight_pass_backward_workspace floats)
+ * reduced in a fixed order by a second tiny launch.  Formulas: derivative of LBBNN-GP-MF-MNF.py:195-196,211-217,230-233.
+ */
+typedef struct lbbnn_wpb_args {
+    const float *mu, *rho, *lambdal, *dWm, *dWv;          /* (O,I); dWv may be NULL (posterior-mean forward) */
+    const float *z_fwd, *z_kl, *r0_c;                     /* (I) or NULL                                     */
+    const float *da_mu, *da_var;                          /* (O) or NULL                                     */
+    const float *g_kl;                                    /* device scalar or NULL                           */
+    lbbnn_priors_t priors;
+    float *dmu, *drho, *dlambdal;                         /* (O,I) outputs                                   */
+    float *dz_fwd, *dz_kl, *dr0_c;                        /* (I) outputs or NULL                             */
+    float *work;
+    int O, I;
+} lbbnn_wpb_args_t;
+
+int64_t lbbnn_weight_pass_backward_workspace(int O, int I);
+int lbbnn_weight_pass_backward(const lbbnn_wpb_args_t* args, void* stream);
+
+
 /* rng[1] += delta (device side, so graph replays draw fresh noise). */
 int lbbnn_rng_advance(uint64_t* rng, uint64_t delta, void* stream);
 

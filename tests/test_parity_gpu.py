@@ -728,3 +728,71 @@ print("GRAPH_OK", vals[0], vals[-1])
 """ % root
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "GRAPH_OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+
+
+# --------------------------------------------------------------------------- BASELINE.json configs as parity cases
+def test_baseline_config1_lrt_400_b1024_split(bnn, dev):
+    """configs[1]: LBBNN-GP-MF-LRT 784-400-400-10, batch 1024, reduced-precision matrix-core path (bf16x3 here),
+    whole network vs the fp32 oracle on the same seeded draws; and configs[0]'s shape (784-400-400-10, B=100)
+    for the baseline LBBNN is covered by test_base_* above."""
+    dims, B = (784, 400, 400, 10), 1024
+    torch.manual_seed(31)
+    net = bnn.lrt.BayesianNetwork(dims)
+    g = torch.Generator().manual_seed(32)
+    x = torch.rand(B, 784, generator=g)
+    layers = [net.l1, net.l2, net.l3]
+    P = [{k: v.detach().clone() for k, v in l.state_dict().items()} for l in layers]
+    eps = [torch.randn(B, l.out_features, generator=g) for l in layers]
+    ref_out, ref_kl = orc.lrt_network_forward(x, P, eps)
+    net = net.to(dev).train()
+    for l, e in zip(layers, eps):
+        l.noise = {"eps_out": e.to(dev)}
+    for prec, tol in (("fp32", TIGHT), ("bf16x3", 2e-5)):
+        bnn.set_precision(prec)
+        try:
+            with torch.no_grad():
+                out = net(x.to(dev), sample=True)
+                kl = net.kl()
+        finally:
+            bnn.set_precision("fp32")
+        assert rel_err(out, ref_out) < tol, prec
+        assert rel_err(kl, ref_kl) < TIGHT
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("O,I,mnf", [(37, 53, True), (64, 128, True), (130, 1200, True), (48, 64, False)])
+def test_weight_pass_backward_kernel(bnn, dev, O, I, mnf):
+    """K1b (lbbnn_weight_pass_backward) against fp64 autograd of the same chain: e_w, var_w, weight KL and the
+    auxiliary activations act_mu / act_var as functions of (mu, rho, lambda, z_fwd, z_kl, r0_c)."""
+    from bnn_amd import ops
+    g = torch.Generator().manual_seed(O * 1000 + I)
+    pr = bnn.Priors()
+    mu = (torch.rand(O, I, generator=g) - 0.5) * 0.4
+    rho = -5 + torch.rand(O, I, generator=g) * 3
+    lam = torch.randn(O, I, generator=g) * 2
+    dWm, dWv = torch.randn(O, I, generator=g), torch.randn(O, I, generator=g)
+    zf, zk, rc = 1 + 0.1 * torch.randn(I, generator=g), 1 + 0.1 * torch.randn(I, generator=g), 0.1 * torch.randn(I, generator=g)
+    dam, dav = torch.randn(O, generator=g), torch.randn(O, generator=g)
+    gk = torch.tensor(1 / 600.)
+    leaves = [t.double().requires_grad_(True) for t in (mu, rho, lam, zf, zk, rc)]
+    m, r, l, f, k, c = leaves
+    alpha, sigma = torch.sigmoid(l), torch.log1p(torch.exp(r))
+    k_eff = k if mnf else torch.ones_like(k)
+    Wv = sigma ** 2 * alpha ** 2
+    klw = (alpha * (math.log(pr.sigma_prior) - sigma.log() - 0.5 + (alpha / pr.alpha_prior).log()
+                    + (sigma ** 2 + (m * k_eff - pr.mu_prior) ** 2) / (2 * pr.sigma_prior ** 2))
+           + (1 - alpha) * ((1 - alpha) / (1 - pr.alpha_prior)).log()).sum()
+    obj = (dWm.double() * (m * alpha * (f if mnf else 1))).sum() + (dWv.double() * Wv).sum() + gk.double() * klw
+    if mnf:
+        obj = obj + (dam.double() * (c @ (k * m * alpha).T)).sum() + (dav.double() * (c ** 2 @ Wv.T)).sum()
+    ref = torch.autograd.grad(obj, leaves, allow_unused=True)
+    d = lambda t: t.to(dev)
+    got = ops.weight_pass_backward(d(mu), d(rho), d(lam), d(dWm), d(dWv), z_fwd=d(zf) if mnf else None,
+                                   z_kl=d(zk) if mnf else None, r0_c=d(rc) if mnf else None,
+                                   da_mu=d(dam) if mnf else None, da_var=d(dav) if mnf else None, g_kl=d(gk), priors=pr)
+    names = ["dmu", "drho", "dlambdal", "dz_fwd", "dz_kl", "dr0_c"]
+    for n, a, b in zip(names, got, ref):
+        if a is None:
+            assert not mnf
+            continue
+        assert rel_err(a.cpu().double(), b) < 2e-5, n
