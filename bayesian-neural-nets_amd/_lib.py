@@ -72,6 +72,20 @@ class WpbArgs(ctypes.Structure):
                [("O", c_i), ("I", c_i)]
 
 
+class PlanarGrad(ctypes.Structure):
+    """lbbnn_planar_grad_t"""
+    _fields_ = [("u", c_p * MAX_FLOW_T), ("w", c_p * MAX_FLOW_T), ("b", c_p * MAX_FLOW_T)]
+
+
+class FlowBwdArgs(ctypes.Structure):
+    """lbbnn_flow_bwd_args_t"""
+    _fields_ = [(n, c_p) for n in ("q0_mean", "q0_log_var", "eps_fwd", "eps_kl", "r0_b1", "r0_b2", "aux",
+                                   "dz_fwd", "dz_kl", "g_kl", "bias_mu", "bias_rho", "g_sum", "gv_sum")] + \
+               [("z_flow", PlanarFlow), ("r_flow", PlanarFlow), ("priors", Priors)] + \
+               [(n, c_p) for n in ("d_q0_mean", "d_q0_log_var", "d_r0_b1", "d_r0_b2", "d_bias_mu", "d_bias_rho")] + \
+               [("d_z_flow", PlanarGrad), ("d_r_flow", PlanarGrad), ("work", c_p), ("O", c_i), ("I", c_i)]
+
+
 # name -> (restype, argtypes); must list every symbol include/lbbnn.h declares
 SIGNATURES = {
     "lbbnn_abi_version": (c_i, []),
@@ -86,6 +100,9 @@ SIGNATURES = {
     "lbbnn_transpose_operand": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p]),
     "lbbnn_weight_pass_backward_workspace": (c_i64, [c_i, c_i]),
     "lbbnn_weight_pass_backward": (c_i, [ctypes.POINTER(WpbArgs), c_p]),
+    "lbbnn_mnf_aux_backward": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
+    "lbbnn_mnf_flow_backward_workspace": (c_i64, [c_i, c_i, c_i]),
+    "lbbnn_mnf_flow_planar_backward": (c_i, [ctypes.POINTER(FlowBwdArgs), c_p]),
     "lbbnn_mnf_flow_planar": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p,
                                     c_p, c_u32, c_p, c_p, c_p, c_i, c_i, c_p]),
     "lbbnn_flow_dense_workspace": (c_i64, [c_i]),

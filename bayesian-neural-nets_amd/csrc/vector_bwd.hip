@@ -1,0 +1,229 @@
+// Vector-sized backward of an MNF layer with planar flows (see include/lbbnn.h): two single-workgroup kernels.
+// Both are latency-bound chains of block reductions over I (or O) elements; every thread owns the indices
+// i = tid + k*1024 of each vector, so the per-index state in `work` is private to its thread and only the
+// block sums (fixed-order, double accumulation) cross threads.
+#include <cmath>
+#include "lbbnn_device.h"
+#include "lbbnn_internal.h"
+
+namespace {
+
+using namespace lbbnn;
+constexpr int NT = 1024, NWV = NT / 64;
+
+__device__ __forceinline__ void bsum3(double& a, double& b, double& c, double* scratch) {
+    a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) { scratch[w] = a; scratch[NWV + w] = b; scratch[2 * NWV + w] = c; }
+    __syncthreads();
+    double sa = 0, sb = 0, sc = 0;
+#pragma unroll
+    for (int i = 0; i < NWV; ++i) { sa += scratch[i]; sb += scratch[NWV + i]; sc += scratch[2 * NWV + i]; }
+    a = sa; b = sb; c = sc;
+}
+
+__global__ __launch_bounds__(NT) void mnf_aux_backward_kernel(const float* __restrict__ act_mu, const float* __restrict__ act_var,
+                                                              const float* __restrict__ eps_act, const float* __restrict__ b1,
+                                                              const float* __restrict__ b2, const float* zb_last, const float* g_kl,
+                                                              int O, int I, float* da_mu, float* da_var, float* aux) {
+    __shared__ double scratch[3 * NWV];
+    const int tid = threadIdx.x;
+    double s_act = 0, z0 = 0, z1 = 0;
+    for (int o = tid; o < O; o += NT) s_act += (double)tanhf(act_mu[o] + sqrtf(act_var[o]) * eps_act[o]);
+    bsum3(s_act, z0, z1, scratch);
+    const float m = (float)(s_act / (double)O);
+    const float zb = zb_last[0];
+    double S = 0;
+    for (int i = tid; i < I; i += NT) {
+        const float e = expf(-b2[i] * m), dlt = zb - b1[i] * m;
+        S += (double)(-0.5f * b2[i] + dlt * b1[i] * e + 0.5f * dlt * dlt * b2[i] * e);
+    }
+    bsum3(S, z0, z1, scratch);
+    const float cm = g_kl[0] * (float)(-S) / (float)O;          // kl = ... - log_rb  =>  dkl/dm = -S
+    for (int o = tid; o < O; o += NT) {
+        const float sd = sqrtf(act_var[o]);
+        const float a = tanhf(act_mu[o] + sd * eps_act[o]);
+        const float d = cm * (1.f - a * a);
+        da_mu[o] = d;
+        da_var[o] = d * eps_act[o] / (2.f * sd);
+    }
+    if (tid == 0) aux[0] = m;
+}
+
+__global__ __launch_bounds__(NT) void mnf_flow_planar_backward_kernel(const lbbnn_flow_bwd_args_t a) {
+    __shared__ double scratch[3 * NWV];
+    __shared__ float thF[LBBNN_MAX_FLOW_T], thK[LBBNN_MAX_FLOW_T], uwZ[LBBNN_MAX_FLOW_T], thR[LBBNN_MAX_FLOW_T], uwR[LBBNN_MAX_FLOW_T];
+    __shared__ float s_zb;
+    const int tid = threadIdx.x, I = a.I, O = a.O;
+    const int Tz = a.z_flow.T, Tr = a.r_flow.T;
+    const bool has_kl = a.g_kl != nullptr;
+    const float G = has_kl ? a.g_kl[0] : 0.f;
+    // work layout: ZF[0..Tz], ZK[0..Tz], R[1..Tr] (R[0] aliases ZK[Tz]), DK, DF
+    float* const ZF = a.work;
+    float* const ZK = ZF + (size_t)(Tz + 1) * I;
+    float* const RR = ZK + (size_t)(Tz + 1) * I;
+    float* const DK = RR + (size_t)Tr * I;
+    float* const DF = DK + I;
+    auto Rv = [&](int t) { return t == 0 ? ZK + (size_t)Tz * I : RR + (size_t)(t - 1) * I; };
+
+    // ---- bias terms (LBBNN-GP-MF-MNF.py:197-198, 234-236)
+    for (int o = tid; o < O; o += NT) {
+        const float er = expf(a.bias_rho[o]);
+        const float sb = log1pf(er), dsig = er / (1.f + er);
+        float gm = a.g_sum[o], gs = a.gv_sum ? a.gv_sum[o] * 2.f * sb : 0.f;
+        if (has_kl) {
+            const float inv = 1.f / (a.priors.bias_sigma_prior * a.priors.bias_sigma_prior);
+            gm += G * (a.bias_mu[o] - a.priors.bias_mu_prior) * inv;
+            gs += G * (sb * inv - 1.f / sb);
+        }
+        a.d_bias_mu[o] = gm;
+        a.d_bias_rho[o] = gs * dsig;
+    }
+    // ---- forward: z0 draws, z flow on both draws
+    for (int i = tid; i < I; i += NT) {
+        const float sd = expf(0.5f * a.q0_log_var[i]);
+        ZF[i] = a.q0_mean[i] + sd * a.eps_fwd[i];
+        if (has_kl) ZK[i] = a.q0_mean[i] + sd * a.eps_kl[i];
+    }
+    for (int t = 0; t < Tz; ++t) {
+        const float *u = a.z_flow.u[t], *w = a.z_flow.w[t];
+        const float* zf = ZF + (size_t)t * I;
+        const float* zk = ZK + (size_t)t * I;
+        double sf = 0, sk = 0, uw = 0;
+        for (int i = tid; i < I; i += NT) {
+            sf += (double)(w[i] * zf[i]);
+            if (has_kl) sk += (double)(w[i] * zk[i]);
+            uw += (double)(u[i] * w[i]);
+        }
+        bsum3(sf, sk, uw, scratch);
+        const float b = a.z_flow.b[t][0];
+        const float tf = tanhf((float)sf + b), tk = tanhf((float)sk + b);
+        if (tid == 0) { thF[t] = tf; thK[t] = tk; uwZ[t] = (float)uw; }
+        for (int i = tid; i < I; i += NT) {
+            ZF[(size_t)(t + 1) * I + i] = zf[i] + u[i] * tf;
+            if (has_kl) ZK[(size_t)(t + 1) * I + i] = zk[i] + u[i] * tk;
+        }
+    }
+    if (has_kl) {
+        // ---- forward: r flow on z2 = ZK[Tz]
+        for (int t = 0; t < Tr; ++t) {
+            const float *u = a.r_flow.u[t], *w = a.r_flow.w[t];
+            const float* z = Rv(t);
+            float* zn = Rv(t + 1);
+            double sr = 0, uw = 0, z0 = 0;
+            for (int i = tid; i < I; i += NT) { sr += (double)(w[i] * z[i]); uw += (double)(u[i] * w[i]); }
+            bsum3(sr, uw, z0, scratch);
+            const float th = tanhf((float)sr + a.r_flow.b[t][0]);
+            if (tid == 0) { thR[t] = th; uwR[t] = (float)uw; }
+            for (int i = tid; i < I; i += NT) zn[i] = z[i] + u[i] * th;
+        }
+        if (tid == ((I - 1) % NT)) s_zb = Rv(Tr)[I - 1];          // owner of the last element (quirk 2)
+        __syncthreads();
+        const float zb = s_zb, m = a.aux[0];
+        // ---- log_rb: gradients of r0_b1 / r0_b2 and of zb
+        double Szb = 0, z0 = 0, z1 = 0;
+        for (int i = tid; i < I; i += NT) {
+            const float e = expf(-a.r0_b2[i] * m), dlt = zb - a.r0_b1[i] * m;
+            a.d_r0_b1[i] = -G * dlt * m * e;
+            a.d_r0_b2[i] = -G * (-0.5f * m + 0.5f * dlt * dlt * m * e);
+            Szb += (double)(dlt * e);
+            DK[i] = 0.f;
+        }
+        bsum3(Szb, z0, z1, scratch);
+        if (tid == ((I - 1) % NT)) DK[I - 1] = G * (float)Szb;    // -G * dlog_rb/dzb
+        // ---- r flow backward (multiplier on log_det_r is -G)
+        for (int t = Tr - 1; t >= 0; --t) {
+            const float *u = a.r_flow.u[t], *w = a.r_flow.w[t];
+            const float* z = Rv(t);
+            double d1 = 0; z0 = 0; z1 = 0;
+            for (int i = tid; i < I; i += NT) d1 += (double)(DK[i] * u[i]);
+            bsum3(d1, z0, z1, scratch);
+            const float th = thR[t], psi = 1.f - th * th, uw = uwR[t], D = 1.f + psi * uw;
+            const float dth = (float)d1 + (-G) * (-2.f * th * uw) / D;
+            const float din = dth * psi, c = (-G) * psi / D;
+            float *du = a.d_r_flow.u[t], *dw = a.d_r_flow.w[t];
+            for (int i = tid; i < I; i += NT) {
+                const float dz = DK[i];
+                du[i] = dz * th + c * w[i];
+                dw[i] = din * z[i] + c * u[i];
+                DK[i] = dz + din * w[i];
+            }
+            if (tid == 0) a.d_r_flow.b[t][0] = din;
+        }
+        for (int i = tid; i < I; i += NT) DK[i] += a.dz_kl ? a.dz_kl[i] : 0.f;
+    } else {
+        for (int i = tid; i < I; i += NT) {
+            a.d_r0_b1[i] = 0.f; a.d_r0_b2[i] = 0.f; DK[i] = 0.f;
+        }
+        for (int t = 0; t < Tr; ++t) {
+            for (int i = tid; i < I; i += NT) { a.d_r_flow.u[t][i] = 0.f; a.d_r_flow.w[t][i] = 0.f; }
+            if (tid == 0) a.d_r_flow.b[t][0] = 0.f;
+        }
+    }
+    for (int i = tid; i < I; i += NT) DF[i] = a.dz_fwd ? a.dz_fwd[i] : 0.f;
+    __syncthreads();                                  // thF/thK/uwZ written by thread 0
+    // ---- z flow backward on both draws (multiplier on log_det_q is -G; the forward draw's log-det is unused)
+    for (int t = Tz - 1; t >= 0; --t) {
+        const float *u = a.z_flow.u[t], *w = a.z_flow.w[t];
+        const float* zf = ZF + (size_t)t * I;
+        const float* zk = ZK + (size_t)t * I;
+        double dk = 0, df = 0, z0 = 0;
+        for (int i = tid; i < I; i += NT) { dk += (double)(DK[i] * u[i]); df += (double)(DF[i] * u[i]); }
+        bsum3(dk, df, z0, scratch);
+        const float uw = uwZ[t];
+        const float tk = thK[t], psik = 1.f - tk * tk, Dk = 1.f + psik * uw;
+        const float dthk = (float)dk + (-G) * (-2.f * tk * uw) / Dk;
+        const float dink = has_kl ? dthk * psik : 0.f, ck = has_kl ? (-G) * psik / Dk : 0.f;
+        const float tf = thF[t], dinf = (float)df * (1.f - tf * tf);
+        float *du = a.d_z_flow.u[t], *dw = a.d_z_flow.w[t];
+        for (int i = tid; i < I; i += NT) {
+            const float dzk = DK[i], dzf = DF[i];
+            du[i] = dzk * tk + ck * w[i] + dzf * tf;
+            dw[i] = dink * (has_kl ? zk[i] : 0.f) + ck * u[i] + dinf * zf[i];
+            DK[i] = dzk + dink * w[i];
+            DF[i] = dzf + dinf * w[i];
+        }
+        if (tid == 0) a.d_z_flow.b[t][0] = dink + dinf;
+    }
+    // ---- q0 (LBBNN-GP-MF-MNF.py:183-185, 201-205): dlog_q0/dlog_var = -1/2 exactly, dlog_q0/dmean = 0
+    for (int i = tid; i < I; i += NT) {
+        const float sd = expf(0.5f * a.q0_log_var[i]);
+        const float ek = has_kl ? a.eps_kl[i] : 0.f;
+        a.d_q0_mean[i] = DK[i] + DF[i];
+        a.d_q0_log_var[i] = 0.5f * sd * (DK[i] * ek + DF[i] * a.eps_fwd[i]) - 0.5f * G;
+    }
+}
+
+}  // namespace
+
+extern "C" int lbbnn_mnf_aux_backward(const float* act_mu, const float* act_var, const float* eps_act, const float* r0_b1,
+                                      const float* r0_b2, const float* zb_last, const float* g_kl, int O, int I,
+                                      float* da_mu, float* da_var, float* aux, void* stream) {
+    if (!act_mu || !act_var || !eps_act || !r0_b1 || !r0_b2 || !zb_last || !g_kl || !da_mu || !da_var || !aux) return LBBNN_E_NULL;
+    if (O <= 0 || I <= 0) return LBBNN_E_SHAPE;
+    hipLaunchKernelGGL(mnf_aux_backward_kernel, dim3(1), dim3(NT), 0, static_cast<hipStream_t>(stream), act_mu, act_var, eps_act,
+                       r0_b1, r0_b2, zb_last, g_kl, O, I, da_mu, da_var, aux);
+    return (int)hipGetLastError();
+}
+
+extern "C" int64_t lbbnn_mnf_flow_backward_workspace(int I, int Tz, int Tr) {
+    if (I <= 0 || Tz < 0 || Tr < 0) return 0;
+    return (int64_t)I * (2 * (Tz + 1) + Tr + 2);
+}
+
+extern "C" int lbbnn_mnf_flow_planar_backward(const lbbnn_flow_bwd_args_t* p, void* stream) {
+    if (!p) return LBBNN_E_NULL;
+    const lbbnn_flow_bwd_args_t& a = *p;
+    if (!a.q0_mean || !a.q0_log_var || !a.eps_fwd || !a.bias_mu || !a.bias_rho || !a.g_sum || !a.work ||
+        !a.d_q0_mean || !a.d_q0_log_var || !a.d_r0_b1 || !a.d_r0_b2 || !a.d_bias_mu || !a.d_bias_rho) return LBBNN_E_NULL;
+    if (a.g_kl && (!a.eps_kl || !a.r0_b1 || !a.r0_b2 || !a.aux)) return LBBNN_E_NULL;
+    if (a.O <= 0 || a.I <= 0) return LBBNN_E_SHAPE;
+    if (a.z_flow.T < 0 || a.z_flow.T > LBBNN_MAX_FLOW_T || a.r_flow.T < 0 || a.r_flow.T > LBBNN_MAX_FLOW_T) return LBBNN_E_SHAPE;
+    for (int t = 0; t < a.z_flow.T; ++t)
+        if (!a.z_flow.u[t] || !a.z_flow.w[t] || !a.z_flow.b[t] || !a.d_z_flow.u[t] || !a.d_z_flow.w[t] || !a.d_z_flow.b[t]) return LBBNN_E_NULL;
+    for (int t = 0; t < a.r_flow.T; ++t)
+        if (!a.r_flow.u[t] || !a.r_flow.w[t] || !a.r_flow.b[t] || !a.d_r_flow.u[t] || !a.d_r_flow.w[t] || !a.d_r_flow.b[t]) return LBBNN_E_NULL;
+    hipLaunchKernelGGL(mnf_flow_planar_backward_kernel, dim3(1), dim3(NT), 0, static_cast<hipStream_t>(stream), a);
+    return (int)hipGetLastError();
+}

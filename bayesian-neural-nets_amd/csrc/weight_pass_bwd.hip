@@ -115,19 +115,28 @@ __global__ __launch_bounds__(256) void weight_pass_bwd_kernel(const lbbnn_wpb_ar
     }
 }
 
-// column sums: out[q][i] = sum over row blocks of work[b][q][i], fixed order
-__global__ __launch_bounds__(256) void wpb_reduce_kernel(const float* __restrict__ work, int nblk, int ldw, int I,
-                                                         float* dz_fwd, float* dz_kl, float* dr0_c) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= I) return;
+// column sums: out[q][i] = sum over row blocks of work[b][q][i].  A workgroup owns 64 columns; its 16 waves
+// each sum every 16th row block (coalesced 256-B rows), then one wave adds the 16 partials in a fixed order.
+__global__ __launch_bounds__(1024) void wpb_reduce_kernel(const float* __restrict__ work, int nblk, int ldw, int I,
+                                                          float* dz_fwd, float* dz_kl, float* dr0_c) {
+    __shared__ float part[3][16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    for (int b = 0; b < nblk; ++b) {
-        const float* p = work + (size_t)b * 3 * ldw;
-        s0 += p[i]; s1 += p[ldw + i]; s2 += p[2 * ldw + i];
+    if (i < I)
+        for (int b = w; b < nblk; b += 16) {
+            const float* p = work + (size_t)b * 3 * ldw;
+            s0 += p[i]; s1 += p[ldw + i]; s2 += p[2 * ldw + i];
+        }
+    part[0][w][lane] = s0; part[1][w][lane] = s1; part[2][w][lane] = s2;
+    __syncthreads();
+    if (w < 3 && i < I) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += part[w][k][lane];
+        float* out = w == 0 ? dz_fwd : (w == 1 ? dz_kl : dr0_c);
+        if (out) out[i] = s;
     }
-    if (dz_fwd) dz_fwd[i] = s0;
-    if (dz_kl) dz_kl[i] = s1;
-    if (dr0_c) dr0_c[i] = s2;
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -154,7 +163,7 @@ extern "C" int lbbnn_weight_pass_backward(const lbbnn_wpb_args_t* p, void* strea
     if (vec) hipLaunchKernelGGL(weight_pass_bwd_kernel<4>, dim3(nblk), dim3(256), 0, s, a, nblk, ldw);
     else     hipLaunchKernelGGL(weight_pass_bwd_kernel<1>, dim3(nblk), dim3(256), 0, s, a, nblk, ldw);
     if (a.dz_fwd || a.dz_kl || a.dr0_c)
-        hipLaunchKernelGGL(wpb_reduce_kernel, dim3((a.I + 255) / 256), dim3(256), 0, s, a.work, nblk, ldw, a.I,
+        hipLaunchKernelGGL(wpb_reduce_kernel, dim3((a.I + 63) / 64), dim3(1024), 0, s, a.work, nblk, ldw, a.I,
                            a.dz_fwd, a.dz_kl, a.dr0_c);
     return (int)hipGetLastError();
 }

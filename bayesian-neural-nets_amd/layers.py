@@ -46,9 +46,12 @@ class _BayesLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, layer, x, cfg, *params):
         out, kl, saved = layer._forward_hip(x, cfg, save_rng=True, want_std=cfg[0])
-        if layer._mnf and cfg[1]:
-            ws = layer._workspace()                 # auxiliary activations of this call (K1 by-products)
-            saved["act_mu"], saved["act_var"] = ws.act_mu.clone(), ws.act_var.clone()
+        if layer._mnf:
+            ws = layer._workspace()                 # by-products of this call's K3 / K1 (the workspace is reused)
+            saved["z_fwd"] = ws.z_fwd.clone()
+            if cfg[1]:
+                saved["act_mu"], saved["act_var"] = ws.act_mu.clone(), ws.act_var.clone()
+                saved["z_kl"], saved["scal"] = ws.z_kl.clone(), ws.scal.clone()
         ctx.layer, ctx.cfg, ctx.saved = layer, cfg, saved
         std = saved.pop("std", None)
         ctx.has_std = std is not None
@@ -74,21 +77,32 @@ class _BayesLinearFn(torch.autograd.Function):
         g_v = None
         if stochastic:
             g_v = g * noise["eps_out"] / (2 * std)
-        # ---- vector-sized graph (flows, q/r densities, bias terms) under autograd: O(I + O) work
-        with torch.enable_grad():
-            vs = [p.detach().requires_grad_(True) for p in params[3:]]
-            am = av = None
-            if layer._mnf and want_kl:
-                am = ctx.saved["act_mu"].requires_grad_(True)
-                av = ctx.saved["act_var"].requires_grad_(True)
-            vg = layer._vector_graph(vs, cfg, noise, am, av)
-        z_k = vg["z_k"].detach() if vg["z_k"] is not None else None
-        z2 = vg["z2"].detach() if vg["z2"] is not None else None
-        r0_c = params[3 + layer._vec_names.index("r0_c")] if (layer._mnf and want_kl) else None
+        planar = layer._mnf and layer._check_flows() == "planar"
         g_kl = g_kl.contiguous() if want_kl else None
-        da_mu = da_var = None
-        if am is not None:
-            da_mu, da_var = torch.autograd.grad(vg["kl"], [am, av], g_kl, retain_graph=True)
+        da_mu = da_var = aux = r0_c = vg = None
+        if planar:
+            # ---- all-HIP chain: V1 (aux activations) -> GEMMs -> K1b -> V2 (flows, q0, r0_b, bias)
+            P = dict(zip(layer._vec_names, params[3:3 + len(layer._vec_names)]))
+            z_k = ctx.saved["z_fwd"]
+            z2 = ctx.saved["z_kl"] if want_kl else None
+            if want_kl:
+                r0_c = P["r0_c"]
+                da_mu, da_var, aux = ops.mnf_aux_backward(ctx.saved["act_mu"], ctx.saved["act_var"], noise["eps_act"],
+                                                          P["r0_b1"], P["r0_b2"], ctx.saved["scal"][3:4], g_kl)
+        else:
+            # ---- vector-sized graph (flows, q/r densities, bias terms) under autograd: O(I + O) work
+            with torch.enable_grad():
+                vs = [p.detach().requires_grad_(True) for p in params[3:]]
+                am = av = None
+                if layer._mnf and want_kl:
+                    am = ctx.saved["act_mu"].requires_grad_(True)
+                    av = ctx.saved["act_var"].requires_grad_(True)
+                vg = layer._vector_graph(vs, cfg, noise, am, av)
+            z_k = vg["z_k"].detach() if vg["z_k"] is not None else None
+            z2 = vg["z2"].detach() if vg["z2"] is not None else None
+            if am is not None:
+                r0_c = params[3 + layer._vec_names.index("r0_c")]
+                da_mu, da_var = torch.autograd.grad(vg["kl"], [am, av], g_kl, retain_graph=True)
         # ---- the four big products on the HIP GEMM kernels
         gx = None
         if ctx.needs_input_grad[1]:
@@ -106,9 +120,24 @@ class _BayesLinearFn(torch.autograd.Function):
         dmu, drho, dlam, dz_k, dz2, dr0c = ops.weight_pass_backward(
             mu, rho, lam, dWm, dWv, z_fwd=z_k, z_kl=z2, r0_c=r0_c, da_mu=da_mu, da_var=da_var, g_kl=g_kl,
             priors=layer.priors)
-        outs, gouts = [vg["bmean"]], [g.sum(0)]
+        g_sum = g.sum(0)
+        gv_sum = g_v.sum(0) if stochastic else None
+        if planar:
+            zp, rp = layer._planar_params_from(params)
+            G = ops.mnf_flow_planar_backward(
+                P["q0_mean"], P["q0_log_var"], zp, rp, eps_fwd=noise["eps_z"].contiguous(),
+                eps_kl=noise["eps_z2"].contiguous() if want_kl else None, r0_b1=P["r0_b1"], r0_b2=P["r0_b2"], aux=aux,
+                dz_fwd=dz_k, dz_kl=dz2, g_kl=g_kl, bias_mu=P["bias_mu"], bias_rho=P["bias_rho"], g_sum=g_sum,
+                gv_sum=gv_sum, priors=layer.priors)
+            G["r0_c"] = dr0c if dr0c is not None else torch.zeros_like(P["q0_mean"])
+            vgrads = [G[n] for n in layer._vec_names]
+            for key in ("z_flow", "r_flow"):
+                for g3 in G[key]:
+                    vgrads += list(g3)
+            return (None, gx, None, dmu, drho, dlam, *vgrads)
+        outs, gouts = [vg["bmean"]], [g_sum]
         if stochastic:
-            outs.append(vg["bvar"]); gouts.append(g_v.sum(0))
+            outs.append(vg["bvar"]); gouts.append(gv_sum)
         if z_k is not None:
             outs.append(vg["z_k"]); gouts.append(dz_k)
         if want_kl and vg["kl"] is not None:
@@ -537,6 +566,14 @@ class MNFBayesianLinear(_BayesLinearBase):
                                      priors=self.priors)
 
     _vec_names = _names[3:]
+
+    def _planar_params_from(self, params):
+        """(u, w, bias) triples of the z and r flows out of the saved parameter list (order of _param_list)."""
+        rest = list(params[len(self._names):])
+        Tz, Tr = len(self.z_flow.transforms), len(self.r_flow.transforms)
+        zp = [tuple(rest[3 * t:3 * t + 3]) for t in range(Tz)]
+        rp = [tuple(rest[3 * (Tz + t):3 * (Tz + t) + 3]) for t in range(Tr)]
+        return zp, rp
 
     def _vector_graph(self, vs, cfg, noise, act_mu=None, act_var=None):
         P, specs = self._unpack_params([None, None, None] + list(vs))

@@ -241,6 +241,50 @@ def mnf_flow_planar(q0_mean, q0_log_var, z_params, r_params, *, eps_fwd=None, ep
     _lib.check(rc, "lbbnn_mnf_flow_planar")
 
 
+def mnf_aux_backward(act_mu, act_var, eps_act, r0_b1, r0_b2, zb_last, g_kl):
+    """lbbnn_mnf_aux_backward -> (da_mu, da_var, aux); zb_last: 1-element view of the forward's scal[3]."""
+    O, I = act_mu.shape[0], r0_b1.shape[0]
+    da_mu, da_var = torch.empty_like(act_mu), torch.empty_like(act_mu)
+    aux = torch.empty(4, dtype=torch.float32, device=act_mu.device)
+    rc = _lib.lib().lbbnn_mnf_aux_backward(_ptr(act_mu, "act_mu"), _ptr(act_var, "act_var"), _ptr(eps_act, "eps_act"),
+                                           _ptr(r0_b1, "r0_b1"), _ptr(r0_b2, "r0_b2"), zb_last.data_ptr(), _ptr(g_kl, "g_kl"),
+                                           O, I, da_mu.data_ptr(), da_var.data_ptr(), aux.data_ptr(), _stream())
+    _lib.check(rc, "lbbnn_mnf_aux_backward")
+    return da_mu, da_var, aux
+
+
+def mnf_flow_planar_backward(q0_mean, q0_log_var, z_params, r_params, *, eps_fwd, eps_kl=None, r0_b1=None, r0_b2=None,
+                             aux=None, dz_fwd=None, dz_kl=None, g_kl=None, bias_mu, bias_rho, g_sum, gv_sum=None,
+                             priors: Priors):
+    """lbbnn_mnf_flow_planar_backward.  Returns a dict: q0_mean, q0_log_var, r0_b1, r0_b2, bias_mu, bias_rho and
+    z_flow / r_flow = lists of (du, dw, dbias) per transform."""
+    I, O = q0_mean.shape[0], bias_mu.shape[0]
+    a = _lib.FlowBwdArgs()
+    for name, t in (("q0_mean", q0_mean), ("q0_log_var", q0_log_var), ("eps_fwd", eps_fwd), ("eps_kl", eps_kl),
+                    ("r0_b1", r0_b1), ("r0_b2", r0_b2), ("aux", aux), ("dz_fwd", dz_fwd), ("dz_kl", dz_kl),
+                    ("g_kl", g_kl), ("bias_mu", bias_mu), ("bias_rho", bias_rho), ("g_sum", g_sum), ("gv_sum", gv_sum)):
+        setattr(a, name, _ptr(t, name))
+    a.priors = priors
+    f = dict(dtype=torch.float32, device=q0_mean.device)
+    out = {n: torch.empty(I, **f) for n in ("q0_mean", "q0_log_var", "r0_b1", "r0_b2")}
+    out["bias_mu"], out["bias_rho"] = torch.empty(O, **f), torch.empty(O, **f)
+    for n in ("q0_mean", "q0_log_var", "r0_b1", "r0_b2", "bias_mu", "bias_rho"):
+        setattr(a, "d_" + n, out[n].data_ptr())
+    for key, params, fl, gr in (("z_flow", z_params, a.z_flow, a.d_z_flow), ("r_flow", r_params, a.r_flow, a.d_r_flow)):
+        fl.T = len(params)
+        grads = []
+        for t, (u, w, b) in enumerate(params):
+            fl.u[t], fl.w[t], fl.b[t] = _ptr(u, "flow u"), _ptr(w, "flow w"), _ptr(b, "flow bias")
+            g3 = (torch.empty_like(u), torch.empty_like(w), torch.empty_like(b))
+            gr.u[t], gr.w[t], gr.b[t] = g3[0].data_ptr(), g3[1].data_ptr(), g3[2].data_ptr()
+            grads.append(g3)
+        out[key] = grads
+    work = torch.empty(_lib.lib().lbbnn_mnf_flow_backward_workspace(I, len(z_params), len(r_params)), **f)
+    a.work, a.O, a.I = work.data_ptr(), O, I
+    _lib.check(_lib.lib().lbbnn_mnf_flow_planar_backward(ctypes.byref(a), _stream()), "lbbnn_mnf_flow_planar_backward")
+    return out
+
+
 # ----------------------------------------------------------------------------------------- K4
 def mnf_flow_dense(q0_mean, q0_log_var, z_descs, Tz, r_descs, Tr, *, eps_fwd=None, eps_kl=None,
                    rng: Optional[torch.Tensor] = None, layer_id: int = 0, z_fwd, z_kl=None, scal=None, work=None,

@@ -343,6 +343,48 @@ int lbbnn_philox_normal(const uint64_t* rng, uint32_t rng_stream, int64_t row_ba
 /* log_softmax over the last dim of a (B,O<=64) matrix, in place allowed (…LRT.py:210). */
 int lbbnn_log_softmax_rows(const float* in, int ldi, float* out, int ldo, int B, int O, void* stream);
 
+/* Vector-sized backward of one MNF layer with planar flows -- two single-workgroup launches around K1b:
+ *
+ * lbbnn_mnf_aux_backward: gradient of the KL wrt the auxiliary activations (LBBNN-GP-MF-MNF.py:211-233).
+ *   m = mean_o tanh(act_mu + sqrt(act_var)*eps_act);  kl has -log_rb(m; r0_b1, r0_b2, zb_last);
+ *   da_mu = g_kl * dkl/dm / O * (1 - act^2),  da_var = da_mu * eps_act / (2 sqrt(act_var));  aux[0] = m.
+ *   zb_last = device pointer to scal[3] of the forward.
+ *
+ * lbbnn_mnf_flow_planar_backward: given dz_fwd / dz_kl (I) from K1b, the upstream g_kl and the column sums of
+ *   the output gradients g_sum = sum_b G_m, gv_sum = sum_b G_v (O; gv_sum NULL for a posterior-mean forward), re-runs
+ *   the z flow (both draws) and the r flow forward keeping every intermediate z, then walks them backwards
+ *   (flows2.py:168-179 planar step; LBBNN-GP-MF-MNF.py:182-187,199-208,224-233) and writes the gradients of
+ *   q0_mean, q0_log_var, r0_b1, r0_b2, every flow's u/w/bias, bias_mu and bias_rho.  g_kl NULL = no KL branch
+ *   (r-flow / r0_b gradients are then zero-filled).  work: lbbnn_mnf_flow_backward_workspace(I, Tz, Tr) floats.
+ */
+typedef struct lbbnn_planar_grad {
+    float* u[LBBNN_MAX_FLOW_T];
+    float* w[LBBNN_MAX_FLOW_T];
+    float* b[LBBNN_MAX_FLOW_T];
+} lbbnn_planar_grad_t;
+
+typedef struct lbbnn_flow_bwd_args {
+    const float *q0_mean, *q0_log_var, *eps_fwd, *eps_kl;   /* (I) */
+    const float *r0_b1, *r0_b2;                              /* (I) */
+    const float *aux;                                        /* aux[0] = m from lbbnn_mnf_aux_backward      */
+    const float *dz_fwd, *dz_kl;                             /* (I) upstream, either may be NULL (= 0)       */
+    const float *g_kl;                                       /* device scalar or NULL                        */
+    const float *bias_mu, *bias_rho, *g_sum, *gv_sum;        /* (O)                                          */
+    lbbnn_planar_flow_t z_flow, r_flow;
+    lbbnn_priors_t priors;
+    float *d_q0_mean, *d_q0_log_var, *d_r0_b1, *d_r0_b2;     /* (I) outputs                                  */
+    float *d_bias_mu, *d_bias_rho;                           /* (O) outputs                                  */
+    lbbnn_planar_grad_t d_z_flow, d_r_flow;
+    float *work;
+    int O, I;
+} lbbnn_flow_bwd_args_t;
+
+int lbbnn_mnf_aux_backward(const float* act_mu, const float* act_var, const float* eps_act, const float* r0_b1,
+                           const float* r0_b2, const float* zb_last, const float* g_kl, int O, int I,
+                           float* da_mu, float* da_var, float* aux, void* stream);
+int64_t lbbnn_mnf_flow_backward_workspace(int I, int Tz, int Tr);
+int lbbnn_mnf_flow_planar_backward(const lbbnn_flow_bwd_args_t* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -796,3 +796,72 @@ def test_weight_pass_backward_kernel(bnn, dev, O, I, mnf):
             assert not mnf
             continue
         assert rel_err(a.cpu().double(), b) < 2e-5, n
+
+
+def _mnf_planar_case(bnn, dev, B, I, O, T, seed, flow_scale=8.0):
+    torch.manual_seed(seed)
+    layer = bnn.mnf.BayesianLinear(I, O, T, z_flow_type="Planar", r_flow_type="Planar")
+    with torch.no_grad():                       # make the flows matter: u, w ~ U(+-0.08) instead of +-0.01
+        for fl in (layer.z_flow, layer.r_flow):
+            for tr in fl.transforms:
+                tr.u.mul_(flow_scale); tr.w.mul_(flow_scale); tr.bias.mul_(flow_scale)
+        layer.q0_mean.add_(1.0)
+        layer.weight_mu.mul_(10)
+    g = torch.Generator().manual_seed(seed + 1)
+    noise = {"eps_z": torch.randn(B, I, generator=g), "eps_out": torch.randn(B, O, generator=g),
+             "eps_z2": torch.randn(1, I, generator=g), "eps_act": torch.randn(O, generator=g)}
+    x = torch.rand(B, I, generator=g)
+    p = {k: v.detach().clone() for k, v in layer.state_dict().items()}
+    return layer.to(dev), p, noise, x
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,I,O,T,train", [(64, 1200, 130, 3, True), (16, 53, 37, 2, True), (32, 1200, 64, 2, False),
+                                           (8, 2500, 20, 1, True)])
+def test_planar_backward_all_hip_vs_oracle_autograd(bnn, dev, B, I, O, T, train):
+    """V1 + K1b + V2 + GEMMs (no torch autograd inside the layer) against autograd of the oracle in fp64."""
+    layer, p, noise, x = _mnf_planar_case(bnn, dev, B, I, O, T, seed=B + I + O)
+    layer.train(train)
+    layer.noise = {k: v.to(dev) for k, v in noise.items() if train or k in ("eps_z", "eps_out")}
+    xg = x.to(dev).requires_grad_(True)
+    out = layer(xg, sample=True)
+    wgt = torch.randn(B, O, generator=torch.Generator().manual_seed(5)).to(dev)
+    loss = (out * wgt).sum() + (layer.kl / 60 if train else 0)
+    loss.backward()
+    pc = {k: v.double().requires_grad_(True) for k, v in p.items()}
+    xc = x.double().requires_grad_(True)
+    zf = orc.flow_from_state("z_flow", "Planar", pc, T)
+    rf = orc.flow_from_state("r_flow", "Planar", pc, T)
+    n64 = {k: v.double() for k, v in noise.items()}
+    o, kl, _ = orc.mnf_forward(xc, pc, zf, rf, n64, stochastic=True, compute_kl=train)
+    ((o * wgt.cpu().double()).sum() + (kl / 60 if train else 0)).backward()
+    assert rel_err(out.detach().cpu().double(), o.detach()) < TOL
+    assert rel_err(xg.grad.cpu().double(), xc.grad) < TOL
+    for name, prm in layer.named_parameters():
+        ref = pc[name].grad
+        if ref is None or float(ref.abs().max()) == 0.0:
+            assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, name
+            continue
+        assert rel_err(prm.grad.cpu().double(), ref) < 5e-5, name
+
+
+@pytest.mark.gpu
+def test_lrt_backward_vs_oracle_autograd(bnn, dev):
+    B, I, O = 48, 200, 72
+    torch.manual_seed(3)
+    layer = bnn.lrt.BayesianLinear(I, O)
+    p = {k: v.detach().clone() for k, v in layer.state_dict().items()}
+    layer = layer.to(dev).train()
+    g = torch.Generator().manual_seed(4)
+    eps, x = torch.randn(B, O, generator=g), torch.rand(B, I, generator=g)
+    layer.noise = {"eps_out": eps.to(dev)}
+    xg = x.to(dev).requires_grad_(True)
+    out = layer(xg)
+    ((out ** 2).sum() + layer.kl / 60).backward()
+    pc = {k: v.double().requires_grad_(True) for k, v in p.items()}
+    xc = x.double().requires_grad_(True)
+    o, kl, _ = orc.lrt_forward(xc, pc, eps.double())
+    ((o ** 2).sum() + kl / 60).backward()
+    assert rel_err(xg.grad.cpu().double(), xc.grad) < TOL
+    for name, prm in layer.named_parameters():
+        assert rel_err(prm.grad.cpu().double(), pc[name].grad) < 5e-5, name
