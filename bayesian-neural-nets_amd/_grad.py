@@ -69,10 +69,38 @@ def _dense(z, kind, tr, masks):
     return z, logdet
 
 
+def _vector(z, tr):
+    """Radial / Householder / Sylvester / planar steps on a 1-D z (flows2.py:48-135), typed by parameter names."""
+    logdet = z.new_zeros(())
+    for t in tr:
+        if "v" in t:
+            v = t["v"]
+            z = z - 2 * v * torch.dot(v, z) / (v ** 2).sum()
+        elif "z_0" in t:
+            alpha = torch.nn.functional.softplus(t["log_alpha"])
+            r = torch.sqrt(((z - t["z_0"]) ** 2).sum())
+            H1 = t["beta"] / (alpha + r)
+            H2 = -t["beta"] * r * (alpha + r) ** (-2)
+            logdet = logdet + ((z.shape[0] - 1) * torch.log(1 + H1) + torch.log(1 + H1 + H2)).sum()
+            z = z + H1 + H2
+        elif "A" in t:
+            lin = t["B"] @ z + t["b"]
+            h = torch.tanh(lin)
+            z = z + t["A"] @ h
+            mat = torch.eye(lin.shape[0], dtype=z.dtype, device=z.device) + torch.diag(1 - h ** 2) @ (t["B"] @ t["A"])
+            logdet = logdet + torch.log(torch.det(mat))
+        else:
+            z, ld = _planar(z, [(t["u"], t["w"], t["bias"])])
+            logdet = logdet + ld
+    return z, logdet
+
+
 def _flow(z, spec, masks):
     kind, tr = spec
     if kind == "Planar":
         return _planar(z, tr)
+    if kind in ("Radial", "Householder", "Sylvester", "mixed"):
+        return _vector(z, tr)
     return _dense(z, kind, tr, masks)
 
 

@@ -72,6 +72,16 @@ class WpbArgs(ctypes.Structure):
                [("O", c_i), ("I", c_i)]
 
 
+class FlowStep(ctypes.Structure):
+    """lbbnn_flow_step_t"""
+    _fields_ = [("p0", c_p), ("p1", c_p), ("p2", c_p), ("type", c_i), ("M", c_i)]
+
+
+class FlowChain(ctypes.Structure):
+    """lbbnn_flow_chain_t"""
+    _fields_ = [("step", FlowStep * MAX_FLOW_T), ("n", c_i)]
+
+
 class PlanarGrad(ctypes.Structure):
     """lbbnn_planar_grad_t"""
     _fields_ = [("u", c_p * MAX_FLOW_T), ("w", c_p * MAX_FLOW_T), ("b", c_p * MAX_FLOW_T)]
@@ -100,6 +110,7 @@ SIGNATURES = {
     "lbbnn_transpose_operand": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p]),
     "lbbnn_weight_pass_backward_workspace": (c_i64, [c_i, c_i]),
     "lbbnn_weight_pass_backward": (c_i, [ctypes.POINTER(WpbArgs), c_p]),
+    "lbbnn_flow_chain": (c_i, [ctypes.POINTER(FlowChain), c_p, c_p, c_p, c_p, c_p, c_u32, c_i, c_p, c_p, c_p, c_p, c_p]),
     "lbbnn_mnf_aux_backward": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
     "lbbnn_mnf_flow_backward_workspace": (c_i64, [c_i, c_i, c_i]),
     "lbbnn_mnf_flow_planar_backward": (c_i, [ctypes.POINTER(FlowBwdArgs), c_p]),

@@ -57,7 +57,39 @@ class MNF(nn.Module):
         self.k = nn.Linear(hidden, dim)
 
 
-_KINDS = {"Planar": PlanarTransform, "RNVP": RNVP, "MNF": MNF}
+class RadialTransform(nn.Module):
+    """Parameters of one radial transform (flows2.py:48-69): z_0 (dim,), log_alpha (1,), beta (1,)."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.z_0 = nn.Parameter(parameter_init(-0.1, 0.1, dim))
+        self.log_alpha = nn.Parameter(parameter_init(-4, 5, 1))
+        self.beta = nn.Parameter(parameter_init(-0.1, 0.1, 1))
+        self.d = dim
+
+
+class SylvesterTransform(nn.Module):
+    """Parameters of one Sylvester transform, M = 5 (flows2.py:98-120): A (dim,M), B (M,dim), b (M,)."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.M = 5
+        self.A = nn.Parameter(parameter_init(-0.01, 0.01, (dim, self.M)))
+        self.B = nn.Parameter(parameter_init(-0.01, 0.01, (self.M, dim)))
+        self.b = nn.Parameter(parameter_init(-0.01, 0.01, self.M))
+
+
+class HouseholderTransform(nn.Module):
+    """Parameters of one Householder transform (flows2.py:122-135): v (dim,)."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.v = nn.Parameter(parameter_init(-0.01, 0.01, dim))
+
+
+_KINDS = {"Planar": PlanarTransform, "RNVP": RNVP, "MNF": MNF, "Radial": RadialTransform,
+          "Sylvester": SylvesterTransform, "Householder": HouseholderTransform}
+VECTOR_KINDS = ("Planar", "Radial", "Sylvester", "Householder", "mixed")     # 1-D flows: lbbnn_flow_chain
 
 
 class PropagateFlow(nn.Module):
@@ -65,13 +97,31 @@ class PropagateFlow(nn.Module):
 
     def __init__(self, transform, dim, num_transforms):
         super().__init__()
-        if transform not in _KINDS:
-            raise NotImplementedError(
-                "flow type %r: only %s have HIP kernels in this build (Radial/Householder/Sylvester/mixed "
-                "are 'next' rows of SURVEY.md 8f)" % (transform, sorted(_KINDS)))
+        if transform != "mixed" and transform not in _KINDS:
+            raise NotImplementedError("flow type %r (the reference only prints 'Transform not implemented', "
+                                      "flows2.py:39-40); known: %s" % (transform, sorted(_KINDS) + ["mixed"]))
         self.kind = transform
         self.dim = dim
-        self.transforms = nn.ModuleList([_KINDS[transform](dim) for _ in range(num_transforms)])
+        if transform == "mixed":               # 5 x (Householder, Planar), num_transforms ignored (flows2.py:31-37)
+            self.transforms = nn.ModuleList([cls(dim) for _ in range(5) for cls in (HouseholderTransform, PlanarTransform)])
+        else:
+            self.transforms = nn.ModuleList([_KINDS[transform](dim) for _ in range(num_transforms)])
+
+    def chain_steps(self):
+        """(type, M, p0, p1, p2) per transform for lbbnn_flow_chain (1-D flow kinds only)."""
+        steps = []
+        for t in self.transforms:
+            if isinstance(t, PlanarTransform):
+                steps.append((ops.FLOW_PLANAR, 0, t.u, t.w, t.bias))
+            elif isinstance(t, RadialTransform):
+                steps.append((ops.FLOW_RADIAL, 0, t.z_0, t.log_alpha, t.beta))
+            elif isinstance(t, HouseholderTransform):
+                steps.append((ops.FLOW_HOUSEHOLDER, 0, t.v, None, None))
+            elif isinstance(t, SylvesterTransform):
+                steps.append((ops.FLOW_SYLVESTER, t.M, t.A, t.B, t.b))
+            else:
+                raise NotImplementedError("%s is not a 1-D flow" % type(t).__name__)
+        return steps
 
     def planar_params(self):
         return [(t.u, t.w, t.bias) for t in self.transforms]
@@ -106,17 +156,15 @@ class PropagateFlow(nn.Module):
         return arr, T, keep
 
     def forward(self, z):
-        """Stand-alone flow on a 1-D z (what ``r_flow(z2)`` does at LBBNN-GP-MF-MNF.py:222)."""
-        if self.kind != "Planar":
-            raise NotImplementedError("stand-alone %s flow forward" % self.kind)
+        """Stand-alone flow on a 1-D z (what ``r_flow(z2)`` does at LBBNN-GP-MF-MNF.py:222): one
+        lbbnn_flow_chain launch.  A 2-D z is taken row-wise and only its LAST row is computed (the row
+        ``sample_z`` keeps, LBBNN-GP-MF-MNF.py:187).  Returns (z (dim,), logdet (1,)); no autograd."""
+        if self.kind not in VECTOR_KINDS:
+            raise NotImplementedError("stand-alone %s flow forward: dense flows run inside the MNF layer "
+                                      "(lbbnn_mnf_flow_dense)" % self.kind)
+        if not z.is_cuda:
+            raise RuntimeError("bnn_amd: PropagateFlow.forward needs a HIP device tensor; there is no CPU path")
         if z.dim() != 1:
             z = z.reshape(-1, self.dim)[-1]
-        # the fused kernel computes z_flow(q0_mean + exp(lv)^.5 * eps): lv -> -inf, eps = 0 gives flow(z)
-        lv = torch.full_like(z, -1e30)
-        eps = torch.zeros_like(z)
-        out = torch.empty_like(z)
-        scal = torch.empty(8, dtype=torch.float32, device=z.device)
         with torch.no_grad():
-            ops.mnf_flow_planar(z.detach().contiguous(), lv, self.planar_params(), [], eps_fwd=eps,
-                                z_fwd=out, scal=scal, want_kl=False)
-        return out, scal[4]
+            return ops.flow_chain(self.chain_steps(), I=self.dim, z_in=z.detach().float().contiguous())

@@ -375,12 +375,35 @@ class MNFBayesianLinear(_BayesLinearBase):
         return ps
 
     def _check_flows(self):
-        """'planar' (K3) or 'dense' (K4: RNVP / MNF-type coupling flows); mixing the two families is not built."""
-        zp, rp = self.z_flow.kind == "Planar", self.r_flow.kind == "Planar"
-        if zp != rp:
-            raise NotImplementedError("bnn_amd: z_flow=%s with r_flow=%s: planar and dense flows cannot be mixed in "
-                                      "one layer in this build" % (self.z_flow.kind, self.r_flow.kind))
-        return "planar" if zp else "dense"
+        """'planar' (K3, fused/batched path), 'chain' (any 1-D flow kinds: lbbnn_flow_chain) or 'dense' (K4: RNVP /
+        MNF-type coupling flows); a 1-D flow cannot be paired with a dense one in this build."""
+        from .flows import VECTOR_KINDS
+        zk, rk = self.z_flow.kind, self.r_flow.kind
+        if zk == "Planar" and rk == "Planar":
+            return "planar"
+        if zk in VECTOR_KINDS and rk in VECTOR_KINDS:
+            return "chain"
+        if zk in ("RNVP", "MNF") and rk in ("RNVP", "MNF"):
+            return "dense"
+        raise NotImplementedError("bnn_amd: z_flow=%s with r_flow=%s: 1-D and dense flows cannot be mixed in one layer "
+                                  "in this build" % (zk, rk))
+
+    def _chain_flows(self, rng, eps_z, eps_z2, want_kl):
+        """z draws + flows of a layer whose flows are 1-D chains: up to three lbbnn_flow_chain launches filling the
+        same workspace slots as K3 (z_fwd, z_kl, scal[0..4]).  Row-wise restatement: only the kept row of the
+        B-row forward draw is computed (for Radial the reference's norm runs over all B rows -- documented deviation)."""
+        ws = self._workspace()
+        L, I = self._layer_id, self.in_features
+        zs = self.z_flow.chain_steps()
+        ops.flow_chain(zs, I=I, q0_mean=self.q0_mean, q0_log_var=self.q0_log_var, eps=eps_z, rng=rng,
+                       rng_stream=ops.STREAM_EPS_Z * 64 + L, z_out=ws.z_fwd, logdet=ws.scal[4:5])
+        if want_kl:
+            ops.flow_chain(zs, I=I, q0_mean=self.q0_mean, q0_log_var=self.q0_log_var, eps=eps_z2, rng=rng,
+                           rng_stream=ops.STREAM_EPS_Z2 * 64 + L, z_out=ws.z_kl, logdet=ws.scal[0:1], log_q0=ws.scal[1:2])
+            if getattr(ws, "chain_tmp", None) is None:
+                ws.chain_tmp = torch.empty(I, dtype=torch.float32, device=self.q0_mean.device)
+            ops.flow_chain(self.r_flow.chain_steps(), I=I, z_in=ws.z_kl, z_out=ws.chain_tmp, logdet=ws.scal[2:3],
+                           z_last=ws.scal[3:4])
 
     def _masks(self, cfg, B):
         """Bernoulli(0.5) masks of the dense flows (flows2.py:209,234): from layer.noise or drawn on the device."""
@@ -408,9 +431,12 @@ class MNFBayesianLinear(_BayesLinearBase):
 
     def _prep_flows_only(self, rng):
         ws = self._workspace()
-        if self._check_flows() == "planar":
+        family = self._check_flows()
+        if family == "planar":
             ops.mnf_flow_planar(self.q0_mean, self.q0_log_var, self.z_flow.planar_params(), [], rng=rng,
                                 layer_id=self._layer_id, z_fwd=ws.z_fwd, scal=ws.scal, want_kl=False)
+        elif family == "chain":
+            self._chain_flows(rng, None, None, False)
         else:
             masks = self._masks((True, False, False), 0)
             zd, Tz, keep = self.z_flow.dense_descs(masks["zmask"], None)
@@ -480,6 +506,8 @@ class MNFBayesianLinear(_BayesLinearBase):
                                 self.r_flow.planar_params(), eps_fwd=eps_z, eps_kl=eps_z2,
                                 rng=rng, layer_id=self._layer_id, z_fwd=ws.z_fwd, z_kl=ws.z_kl, scal=ws.scal,
                                 want_kl=want_kl)
+        elif family == "chain":
+            self._chain_flows(rng, eps_z, eps_z2, want_kl)
         else:
             masks = self._masks(cfg, 0)
             self._last_masks = masks

@@ -241,6 +241,34 @@ def mnf_flow_planar(q0_mean, q0_log_var, z_params, r_params, *, eps_fwd=None, ep
     _lib.check(rc, "lbbnn_mnf_flow_planar")
 
 
+FLOW_PLANAR, FLOW_RADIAL, FLOW_HOUSEHOLDER, FLOW_SYLVESTER = 0, 1, 2, 3
+
+
+def flow_chain(steps, *, I: int, z_in=None, q0_mean=None, q0_log_var=None, eps=None, rng=None, rng_stream: int = 0,
+               z_out: Optional[torch.Tensor] = None, logdet=None, log_q0=None, z_last=None):
+    """lbbnn_flow_chain.  steps: list of (type, M, p0, p1, p2) (tensors or None).  Returns (z_out, logdet)."""
+    if len(steps) > _lib.MAX_FLOW_T:
+        raise ValueError("bnn_amd: at most %d transforms per flow" % _lib.MAX_FLOW_T)
+    ch = _lib.FlowChain()
+    ch.n = len(steps)
+    for k, (ty, M, p0, p1, p2) in enumerate(steps):
+        st = ch.step[k]
+        st.type, st.M = ty, M
+        st.p0, st.p1, st.p2 = _ptr(p0, "flow parameter"), _ptr(p1, "flow parameter"), _ptr(p2, "flow parameter")
+    ref = z_in if z_in is not None else q0_mean
+    if z_out is None:
+        z_out = torch.empty(I, dtype=torch.float32, device=ref.device)
+    if logdet is None:
+        logdet = torch.empty(1, dtype=torch.float32, device=ref.device)
+    rc = _lib.lib().lbbnn_flow_chain(ctypes.byref(ch), _ptr(z_in, "z"), _ptr(q0_mean), _ptr(q0_log_var), _ptr(eps),
+                                     rng.data_ptr() if rng is not None else None, rng_stream, I,
+                                     z_out.data_ptr(), logdet.data_ptr(),
+                                     log_q0.data_ptr() if log_q0 is not None else None,
+                                     z_last.data_ptr() if z_last is not None else None, _stream())
+    _lib.check(rc, "lbbnn_flow_chain")
+    return z_out, logdet
+
+
 def mnf_aux_backward(act_mu, act_var, eps_act, r0_b1, r0_b2, zb_last, g_kl):
     """lbbnn_mnf_aux_backward -> (da_mu, da_var, aux); zb_last: 1-element view of the forward's scal[3]."""
     O, I = act_mu.shape[0], r0_b1.shape[0]

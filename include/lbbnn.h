@@ -385,6 +385,38 @@ int lbbnn_mnf_aux_backward(const float* act_mu, const float* act_var, const floa
 int64_t lbbnn_mnf_flow_backward_workspace(int I, int Tz, int Tr);
 int lbbnn_mnf_flow_planar_backward(const lbbnn_flow_bwd_args_t* args, void* stream);
 
+/* lbbnn_flow_chain -- a chain of 1-D (vector) flow transforms on one z (I): planar, radial, Householder,
+ * Sylvester (flows2.py:72-95, 48-69, 122-135, 98-120) in any order ('mixed' = 5 x (Householder, Planar),
+ * flows2.py:31-37).  One single-workgroup launch; fixed-order double-precision block reductions.
+ *   z = z_in                                   if z_in != NULL
+ *     = q0_mean + exp(q0_log_var)^.5 * eps     otherwise (eps (I) or NULL => Philox stream rng_stream, counter i/4);
+ *       log_q0 (if != NULL) = sum(-0.5*log(pi) - 0.5*log_var - 0.5*eps^2-form of LBBNN-GP-MF-MNF.py:213-214)
+ *   for each step: z = f(z); logdet += f.log_det()
+ * Outputs: z_out (I) (also the working vector; may alias z_in), logdet (1), z_last (1) = z_out[I-1].
+ * Step parameters: PLANAR p0=u p1=w p2=bias(1); RADIAL p0=z_0 (I) p1=log_alpha(1) p2=beta(1) -- as written the norm is
+ * over the whole vector and H1+H2 is added to every element; HOUSEHOLDER p0=v; SYLVESTER p0=A (I x M row-major)
+ * p1=B (M x I) p2=b (M), M <= LBBNN_MAX_SYLVESTER_M, log det by LU with partial pivoting (NaN if det < 0, as torch).
+ */
+#define LBBNN_FLOW_PLANAR 0
+#define LBBNN_FLOW_RADIAL 1
+#define LBBNN_FLOW_HOUSEHOLDER 2
+#define LBBNN_FLOW_SYLVESTER 3
+#define LBBNN_MAX_SYLVESTER_M 8
+
+typedef struct lbbnn_flow_step {
+    const float *p0, *p1, *p2;
+    int type, M;
+} lbbnn_flow_step_t;
+
+typedef struct lbbnn_flow_chain {
+    lbbnn_flow_step_t step[LBBNN_MAX_FLOW_T];
+    int n;
+} lbbnn_flow_chain_t;
+
+int lbbnn_flow_chain(const lbbnn_flow_chain_t* chain, const float* z_in, const float* q0_mean,
+                     const float* q0_log_var, const float* eps, const uint64_t* rng, uint32_t rng_stream, int I,
+                     float* z_out, float* logdet, float* log_q0, float* z_last, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -155,6 +155,54 @@ def planar_step_1d(z: Tensor, u: Tensor, w: Tensor, b: Tensor) -> Tuple[Tensor, 
     return z_new, logdet
 
 
+# --------------------------------------------------------------------------- F4: radial / Householder / Sylvester
+def radial_step_1d(z: Tensor, t: Dict[str, Tensor]) -> Tuple[Tensor, Tensor]:
+    """RadialTransform on a 1-D z (flows2.py:57-69): the norm runs over the whole vector (``dim=[]``),
+    H1/H2 are (1,)-shaped and are ADDED to every element (as written)."""
+    alpha = torch.nn.functional.softplus(t["log_alpha"])              # :58 nn.Softplus()
+    diff = z - t["z_0"]
+    r = torch.sqrt((diff ** 2).sum())                                 # :61
+    H1 = t["beta"] / (alpha + r)                                      # :62
+    H2 = -t["beta"] * r * (alpha + r) ** (-2)                         # :63
+    d = z.shape[-1]
+    logdet = (d - 1) * torch.log(1 + H1) + torch.log(1 + H1 + H2)     # :68
+    return z + H1 + H2, logdet
+
+
+def householder_step_1d(z: Tensor, t: Dict[str, Tensor]) -> Tuple[Tensor, Tensor]:
+    """HouseholderTransform (flows2.py:128-135); log_det is the integer 0."""
+    v = t["v"]
+    return z - 2 * v * torch.dot(v, z) / (v ** 2).sum(), z.new_zeros(1)
+
+
+def sylvester_step_1d(z: Tensor, t: Dict[str, Tensor]) -> Tuple[Tensor, Tensor]:
+    """SylvesterTransform, M = 5 (flows2.py:112-120): z + A tanh(Bz + b); log det(I + diag(h'(Bz+b)) B A)."""
+    lin = t["B"] @ z + t["b"]
+    z_new = z + t["A"] @ torch.tanh(lin)
+    M = t["b"].shape[0]
+    mat = torch.eye(M, dtype=z.dtype) + torch.diag(1 - torch.tanh(lin) ** 2) @ (t["B"] @ t["A"])
+    return z_new, torch.log(torch.det(mat)).reshape(1)
+
+
+def vector_step_1d(z: Tensor, t: Dict[str, Tensor]) -> Tuple[Tensor, Tensor]:
+    """One 1-D transform, type read off the parameter names (so 'mixed' chains work: flows2.py:31-37)."""
+    if "v" in t:
+        return householder_step_1d(z, t)
+    if "z_0" in t:
+        return radial_step_1d(z, t)
+    if "A" in t:
+        return sylvester_step_1d(z, t)
+    return planar_step_1d(z, t["u"], t["w"], t["bias"])
+
+
+def vector_flow_1d(z: Tensor, tr: Sequence[Dict[str, Tensor]]) -> Tuple[Tensor, Tensor]:
+    logdet = z.new_zeros(1)
+    for t in tr:
+        z, ld = vector_step_1d(z, t)
+        logdet = logdet + ld
+    return z, logdet
+
+
 def planar_flow_1d(z: Tensor, tr: Sequence[Dict[str, Tensor]]) -> Tuple[Tensor, Tensor]:
     """PropagateFlow('Planar').forward on 1-D z (flows2.py:41-46). logdet has shape (1,)."""
     logdet = 0
@@ -239,7 +287,7 @@ def mnfflow_flow(z: Tensor, tr: Sequence[Dict[str, Tensor]], masks: Sequence[Ten
 @dataclass
 class Flow:
     """A PropagateFlow (flows2.py:14-46): type name + per-transform parameter dicts."""
-    kind: str                                   # 'Planar' | 'RNVP' | 'MNF'
+    kind: str                                   # 'Planar' | 'RNVP' | 'MNF' | 'Radial' | 'Householder' | 'Sylvester' | 'mixed'
     transforms: List[Dict[str, Tensor]] = field(default_factory=list)
 
     def run(self, z: Tensor, masks: Optional[Sequence[Tensor]] = None):
@@ -251,6 +299,12 @@ class Flow:
             return rnvp_flow(z, self.transforms, masks)
         if self.kind == "MNF":
             return mnfflow_flow(z, self.transforms, masks)
+        if self.kind in ("Radial", "Householder", "Sylvester", "mixed"):
+            if z.dim() == 1:
+                return vector_flow_1d(z, self.transforms)
+            # row-wise restatement: the 1-D transform applied to every row
+            outs = [vector_flow_1d(row, self.transforms) for row in z]
+            return torch.stack([o[0] for o in outs]), torch.stack([o[1] for o in outs])
         raise ValueError(f"flow kind {self.kind!r} not in the oracle")
 
 

@@ -353,6 +353,31 @@ def gen_flows():
     print("flows.npz", sum(v.nbytes for v in store.values()) // 1024, "KB raw")
 
 
+# ----------------------------------------------------------------------------- remaining 1-D flow types
+def gen_flows_misc():
+    """Radial / Householder / Sylvester / 'mixed' (flows2.py:48-69, 98-135, 31-37) on a 1-D z, as PropagateFlow runs
+    them.  Each shape twice: reference init, and parameters scaled x12 so that the transforms visibly move z."""
+    store = {}
+    for kind in ("Radial", "Householder", "Sylvester", "mixed"):
+        for ci, (I, T) in enumerate([(6, 2), (33, 3), (784, 2), (1200, 1)]):
+            for scale in (1.0, 12.0):
+                torch.manual_seed(700 + ci)
+                flow = flows2.PropagateFlow(kind, I, T)
+                with torch.no_grad():
+                    for prm in flow.parameters():
+                        prm.mul_(scale)
+                z = (0.1 if scale == 1.0 else 1.0) * torch.randn(I)
+                with torch.no_grad():
+                    zt, ld = flow(z)
+                ld = torch.as_tensor(ld, dtype=torch.float32).reshape(-1)
+                case = "%s%d%s" % (kind.lower(), ci, "" if scale == 1.0 else "s")
+                put(store, case, z=z, z_out=zt, logdet=ld, shape=np.array([I, len(flow.transforms)]))
+                for k, v in sd(flow).items():
+                    put(store, case, **{"p." + k: v})
+    np.savez_compressed(os.path.join(HERE, "flows_misc.npz"), **store)
+    print("flows_misc.npz", sum(v.nbytes for v in store.values()) // 1024, "KB raw")
+
+
 # ----------------------------------------------------------------------------- base LBBNN layer
 def gen_base():
     ns = load_classes("LBBNN-GP-MF.py", ("Gaussian", "Bernoulli", "GaussGamma", "BetaBinomial", "BayesianLinear"),
@@ -434,5 +459,6 @@ if __name__ == "__main__":
     gen_lrt()
     gen_mnf()
     gen_flows()
+    gen_flows_misc()
     gen_base()
     gen_vd()

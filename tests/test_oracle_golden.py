@@ -171,3 +171,18 @@ def test_fp64_truth_close(golden):
     assert out.dtype == torch.float64
     assert rel_err(out, c["out_train"]) < 1e-5
     assert rel_err(kl, c["kl"]) < 1e-5
+
+
+@pytest.mark.parametrize("kind", ["radial", "householder", "sylvester", "mixed"])
+def test_remaining_flow_types_vs_reference(golden, kind):
+    """Radial / Householder / Sylvester / mixed restatements against flows2.PropagateFlow outputs (1-D z)."""
+    g = golden("flows_misc.npz")
+    for ci in range(4):
+        for suffix in ("", "s"):
+            c = g.case("%s%d%s" % (kind, ci, suffix))
+            I, T = [int(v) for v in c["shape"]]
+            name = {"radial": "Radial", "householder": "Householder", "sylvester": "Sylvester", "mixed": "mixed"}[kind]
+            flow = orc.flow_from_state("p", name, {"p." + k: v for k, v in sub(c, "p.").items()}, T)
+            z, ld = flow.run(c["z"])
+            assert torch.allclose(z, c["z_out"], rtol=1e-5, atol=1e-6), (kind, ci, suffix)
+            assert torch.allclose(ld.reshape(-1), c["logdet"].reshape(-1), rtol=2e-4, atol=2e-6), (kind, ci, suffix, ld, c["logdet"])

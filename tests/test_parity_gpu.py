@@ -370,7 +370,7 @@ def test_error_paths(bnn, dev):
         l = bnn.mnf.BayesianLinear(8, 4, 2, z_flow_type="Planar", r_flow_type="RNVP").to(dev)   # mixed families
         l(x)
     with pytest.raises(NotImplementedError):
-        bnn.flows.PropagateFlow("Sylvester", 8, 2)
+        bnn.flows.PropagateFlow("NoSuchFlow", 8, 2)
 
 
 # --------------------------------------------------------------------------- scheduling variants
@@ -865,3 +865,69 @@ def test_lrt_backward_vs_oracle_autograd(bnn, dev):
     assert rel_err(xg.grad.cpu().double(), xc.grad) < TOL
     for name, prm in layer.named_parameters():
         assert rel_err(prm.grad.cpu().double(), pc[name].grad) < 5e-5, name
+
+
+# --------------------------------------------------------------------------- remaining 1-D flow types (8f-4)
+_KIND = {"radial": "Radial", "householder": "Householder", "sylvester": "Sylvester", "mixed": "mixed"}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["radial", "householder", "sylvester", "mixed"])
+def test_flow_chain_vs_reference_golden(bnn, dev, golden, kind):
+    """lbbnn_flow_chain against flows2.PropagateFlow outputs (tests/golden/flows_misc.npz), 1-D z."""
+    g = golden("flows_misc.npz")
+    for ci in range(4):
+        for suffix in ("", "s"):
+            c = g.case("%s%d%s" % (kind, ci, suffix))
+            I, T = [int(v) for v in c["shape"]]
+            flow = bnn.flows.PropagateFlow(_KIND[kind], I, T)
+            flow.load_state_dict(sub(c, "p."))
+            flow = flow.to(dev)
+            z, ld = flow(c["z"].to(dev))
+            assert rel_err(z, c["z_out"]) < TIGHT, (kind, ci, suffix)
+            ref = float(c["logdet"].reshape(-1)[0])
+            assert abs(float(ld) - ref) <= 2e-4 * abs(ref) + 2e-6, (kind, ci, suffix, float(ld), ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("zk,rk", [("Radial", "Radial"), ("Householder", "Sylvester"), ("mixed", "Planar"),
+                                   ("Sylvester", "Householder")])
+def test_mnf_layer_with_1d_flow_chains_vs_oracle(bnn, dev, zk, rk):
+    """MNF layer whose flows are 1-D chains (row-wise restatement): forward, KL and backward against the oracle
+    (fp64 autograd).  The reference itself only runs Radial here (and reduces its norm over all B rows)."""
+    B, I, O, T = 24, 96, 40, 2
+    torch.manual_seed(11)
+    layer = bnn.mnf.BayesianLinear(I, O, T, z_flow_type=zk, r_flow_type=rk)
+    with torch.no_grad():
+        for fl in (layer.z_flow, layer.r_flow):
+            for prm in fl.parameters():
+                prm.mul_(8.0)
+        layer.q0_mean.add_(1.0)
+        layer.weight_mu.mul_(10)
+    g = torch.Generator().manual_seed(12)
+    noise = {"eps_z": torch.randn(B, I, generator=g), "eps_out": torch.randn(B, O, generator=g),
+             "eps_z2": torch.randn(1, I, generator=g), "eps_act": torch.randn(O, generator=g)}
+    x = torch.rand(B, I, generator=g)
+    p = {k: v.detach().clone() for k, v in layer.state_dict().items()}
+    layer = layer.to(dev).train()
+    layer.noise = {k: v.to(dev) for k, v in noise.items()}
+    xg = x.to(dev).requires_grad_(True)
+    out = layer(xg, sample=True)
+    (out.pow(2).sum() + layer.kl / 60).backward()
+    pc = {k: v.double().requires_grad_(True) for k, v in p.items()}
+    xc = x.double().requires_grad_(True)
+    zf = orc.flow_from_state("z_flow", zk, pc, len(layer.z_flow.transforms))
+    rf = orc.flow_from_state("r_flow", rk, pc, len(layer.r_flow.transforms))
+    n64 = {k: v.double() for k, v in noise.items()}
+    n64["eps_z"] = n64["eps_z"][-1:]            # row-wise: only the kept row matters
+    o, kl, _ = orc.mnf_forward(xc, pc, zf, rf, n64)
+    (o.pow(2).sum() + kl / 60).backward()
+    assert rel_err(out.detach().cpu().double(), o.detach()) < TOL
+    assert abs(float(layer.kl) - float(kl)) / abs(float(kl)) < TOL
+    assert rel_err(xg.grad.cpu().double(), xc.grad) < TOL
+    for name, prm in layer.named_parameters():
+        ref = pc[name].grad
+        if ref is None or float(ref.abs().max()) == 0.0:
+            assert prm.grad is None or float(prm.grad.abs().max()) < 1e-12, name
+            continue
+        assert rel_err(prm.grad.cpu().double(), ref) < 2e-4, name
