@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liblbbnn_hip.so")
+# LBBNN_LIB_PATH: developer hook for the ablation builds of tools/lab (must exist; still no fallback)
+LIB_PATH = os.environ.get("LBBNN_LIB_PATH") or os.path.join(_HERE, "csrc", "liblbbnn_hip.so")
 
 c_p = ctypes.c_void_p
 c_i = ctypes.c_int

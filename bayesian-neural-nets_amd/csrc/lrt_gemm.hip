@@ -622,9 +622,13 @@ __global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_bf16x3_kernel(const GemmA
     for (int c = 0; c < nsteps; ++c) {
         read_frags(smc + (c & 1) * BUFB);
         __builtin_amdgcn_sched_barrier(0);
+#ifndef LAB_NO_DMA          // tools/lab ablation builds only; never defined in the product library
         if (c + 1 < nsteps) dma_step(c + 1, smc + ((c & 1) ^ 1) * BUFB);
+#endif
         __builtin_amdgcn_sched_barrier(0);
+#ifndef LAB_NO_MFMA
         mfmas();
+#endif
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
     }

@@ -931,3 +931,21 @@ def test_mnf_layer_with_1d_flow_chains_vs_oracle(bnn, dev, zk, rk):
             assert prm.grad is None or float(prm.grad.abs().max()) < 1e-12, name
             continue
         assert rel_err(prm.grad.cpu().double(), ref) < 2e-4, name
+
+
+@pytest.mark.gpu
+def test_ensemble_eval_helper(bnn, dev):
+    """evaluate.ensemble_eval: shapes, distinct stochastic members, deterministic posterior-mean member equal to
+    the oracle's mean-path forward, density in (0,1)."""
+    torch.manual_seed(2)
+    net = bnn.lrt.BayesianNetwork((784, 64, 48, 10)).to(dev)
+    data = torch.rand(100, 1, 28, 28, device=dev)
+    target = torch.randint(0, 10, (100,), device=dev)
+    r = bnn.evaluate.ensemble_eval(net, data, target, samples=4)
+    assert r["outputs"].shape == (4, 100, 10)
+    assert not torch.equal(r["outputs"][0], r["outputs"][1])
+    assert 0 <= r["correct_ensemble"] <= 100 and 0 <= r["correct_posterior_mean"] <= 100
+    assert float(r["density"].min()) > 0.3 and float(r["density"].max()) < 0.9      # alpha = sigmoid(U(0,1))
+    P = [{k: v.detach().cpu() for k, v in l.state_dict().items()} for l in (net.l1, net.l2, net.l3)]
+    ref, _ = orc.lrt_network_forward(data.cpu(), P, [None] * 3, stochastic=False, compute_kl=False)
+    assert torch.equal(ref.argmax(1), r["pred_posterior_mean"].cpu()) or rel_err(net(data).cpu(), ref) < TOL
