@@ -9,13 +9,36 @@ namespace lbbnn {
 constexpr int kWave = 64;   // CDNA wavefront
 
 // ------------------------------------------------------------------------------------------ reductions
-// Fixed-order butterfly over the 64 lanes of a wave: every lane ends with the full sum, and the
-// order of additions is independent of scheduling, so results are bitwise reproducible.
+// Fixed-order sum over the 64 lanes of a wave; every lane ends with the full sum and the order of additions is
+// independent of scheduling, so results are bitwise reproducible.  Within a row of 16 lanes the four butterfly steps
+// are DPP register moves (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: no LDS crossbar round trip, which is
+// what __shfl_xor / ds_bpermute costs -- ~100 cycles per dependent step on these latency-bound single-workgroup
+// chains); the four row sums are then combined from v_readlane (lanes 0, 16, 32, 48) as (r0 + r1) + (r2 + r3).
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float v) { return __builtin_bit_cast(float, dpp_mov<CTRL>(__builtin_bit_cast(int, v))); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_get(double v) {
+    const uint64_t b = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = (uint32_t)dpp_mov<CTRL>((int)(uint32_t)b), hi = (uint32_t)dpp_mov<CTRL>((int)(uint32_t)(b >> 32));
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ float lane_get(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+__device__ __forceinline__ double lane_get(double v, int l) {
+    const uint64_t b = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, l), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), l);
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
-    return v;
+    v += dpp_get<0xB1>(v);      // quad_perm [1,0,3,2]   lane ^ 1
+    v += dpp_get<0x4E>(v);      // quad_perm [2,3,0,1]   lane ^ 2
+    v += dpp_get<0x141>(v);     // row_half_mirror       quad <-> neighbouring quad
+    v += dpp_get<0x140>(v);     // row_mirror            half row <-> other half: every lane holds its row's sum
+    return (lane_get(v, 0) + lane_get(v, 16)) + (lane_get(v, 32) + lane_get(v, 48));
 }
 
 // Block-wide sum for blockDim.x = NW*64 threads; `scratch` holds NW values of T in LDS.
@@ -53,6 +76,17 @@ __device__ __forceinline__ void dma_wait_all() {
     __syncthreads();
 }
 __host__ __device__ __forceinline__ int pad64(int n) { return (n + 63) & ~63; }
+
+// ------------------------------------------------------------------------------------------ kernel arguments as memory
+// A by-value kernel-argument struct indexed with a RUNTIME index (bt.l[blockIdx.y], a.zf.u[t]) is copied to scratch
+// memory by hipcc (measured: 872 B/lane in the flow kernel, every pointer fetch then a private-memory round trip on a
+// latency-bound chain).  Reading the same bytes through the kernarg segment pointer keeps them scalar loads with a
+// computed offset.  T must be the type of the kernel's FIRST parameter.
+#define LBBNN_CONST_AS __attribute__((address_space(4)))
+template <typename T>
+__device__ __forceinline__ const LBBNN_CONST_AS T* kernarg_as() {
+    return (const LBBNN_CONST_AS T*)__builtin_amdgcn_kernarg_segment_ptr();
+}
 
 // ------------------------------------------------------------------------------------------ elementwise
 // softplus exactly as the reference spells it: log1p(exp(rho)) (LBBNN-GP-MF-LRT.py:81-82).

@@ -109,11 +109,12 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* scratch
 }
 
 __global__ __launch_bounds__(256) void mnf_flow_planar_lds_kernel(const FlowBatch bt) {
-    const FlowArgs& a = bt.l[blockIdx.y];
+    const LBBNN_CONST_AS FlowArgs& a = kernarg_as<FlowBatch>()->l[blockIdx.y];   // == bt.l[blockIdx.y], no scratch copy
     const bool klblk = blockIdx.x == 1;
     if (klblk && !a.want_kl) return;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ double scratch[8];
+    __shared__ float s_bias[2 * LBBNN_MAX_FLOW_T];
     const int I = a.I, P = pad64(I), tid = threadIdx.x;
     const float* eps = klblk ? a.eps_kl : a.eps_fwd;
     const int Tz = a.zf.T, Tr = klblk ? a.rf.T : 0;
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(256) void mnf_flow_planar_lds_kernel(const FlowBatc
         const float* w = t < Tz ? a.zf.w[t] : a.rf.w[t - Tz];
         dma_stage(uw + (2 * t) * P, u, I);
         dma_stage(uw + (2 * t + 1) * P, w, I);
+        if (tid == 0) s_bias[t] = (t < Tz ? a.zf.b[t] : a.rf.b[t - Tz])[0];     // fetched with the vectors, not on the chain
     }
     uint64_t seed = 0, offs = 0;
     if (!eps) { seed = a.rng[0]; offs = a.rng[1]; }
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(256) void mnf_flow_planar_lds_kernel(const FlowBatc
     for (int t = 0; t < Tz + Tr; ++t) {
         const float* u = uw + (2 * t) * P;
         const float* w = uw + (2 * t + 1) * P;
-        const float bias = (t < Tz ? a.zf.b[t] : a.rf.b[t - Tz])[0];
+        const float bias = s_bias[t];
         double s_wz = 0.0, s_uw = 0.0;
 #pragma unroll 1
         for (int i = tid; i < I; i += 256) { s_wz += (double)(w[i] * z[i]); s_uw += (double)(u[i] * w[i]); }
@@ -199,6 +201,135 @@ __global__ __launch_bounds__(256) void mnf_flow_planar_lds_kernel(const FlowBatc
         a.scal[1] = (float)lq0;
         a.scal[2] = ld_r;
         a.scal[3] = z[I - 1];                                            // z_b[-1]: last ELEMENT (:224)
+    }
+}
+
+// ---- short chains (Tz + Tr <= 4, the reference's num_transforms = 2 included): ONE reduction instead of one per
+// transform.  A planar step only moves z along u:  z_t = z_0 + sum_{s<t} th_s u_s,  so
+//     w_t . z_t = w_t . z_0 + sum_{s<t} th_s (w_t . u_s)
+// and every dot product the whole chain needs -- w_t.z_0, w_t.u_s (s < t), u_t.w_t -- depends on the inputs only.
+// They are accumulated in one sweep and reduced in ONE block reduction (<= 14 values + log_q0); the th_t / log-det
+// chain is then scalar arithmetic, and z is written in one more sweep (terms added in transform order, so z is
+// bit-identical to the step-by-step form; the r flow needs no sweep at all: only its log-dets and z_b[-1] are used).
+constexpr int kFastT = 4;
+
+constexpr int kFastThreads = 512, kFastWaves = kFastThreads / 64;
+
+__global__ __launch_bounds__(kFastThreads) void mnf_flow_planar_fast_kernel(const FlowBatch bt) {
+    const LBBNN_CONST_AS FlowArgs& a = kernarg_as<FlowBatch>()->l[blockIdx.y];   // == bt.l[blockIdx.y]
+    const bool klblk = blockIdx.x == 1;
+    if (klblk && !a.want_kl) return;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int NV = 2 * kFastT + kFastT * (kFastT - 1) / 2 + 1;      // 15 reduced values
+    __shared__ double red[NV][kFastWaves];
+    __shared__ float s_bias[kFastT];
+    const int I = a.I, P = pad64(I), tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#ifdef LAB_STAMPS            // tools/lab diagnostic build only: phase times (10 ns units) into the unused scal[5..7]
+    const uint64_t lab_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    const float* eps = klblk ? a.eps_kl : a.eps_fwd;
+    const int Tz = a.zf.T, Tr = klblk ? a.rf.T : 0, NT = Tz + Tr;
+    float* z = sm;  float* qm = sm + P;  float* lv = sm + 2 * P;  float* ep = sm + 3 * P;  float* uw = sm + 4 * P;
+    dma_stage(qm, a.q0_mean, I);
+    dma_stage(lv, a.q0_log_var, I);
+    if (eps) dma_stage(ep, eps, I);
+#pragma unroll 1
+    for (int t = 0; t < NT; ++t) {
+        dma_stage(uw + (2 * t) * P, t < Tz ? a.zf.u[t] : a.rf.u[t - Tz], I);
+        dma_stage(uw + (2 * t + 1) * P, t < Tz ? a.zf.w[t] : a.rf.w[t - Tz], I);
+        if (tid == 0) s_bias[t] = (t < Tz ? a.zf.b[t] : a.rf.b[t - Tz])[0];
+    }
+    uint64_t seed = 0, offs = 0;
+    if (!eps) { seed = a.rng[0]; offs = a.rng[1]; }
+    const uint32_t stream = (klblk ? LBBNN_STREAM_EPS_Z2 : LBBNN_STREAM_EPS_Z) * 64u + a.layer;
+    dma_wait_all();
+#ifdef LAB_STAMPS
+    if (klblk && tid == 0) a.scal[5] = (float)(__builtin_amdgcn_s_memrealtime() - lab_t0);
+#endif
+
+    // one sweep: z0 (LBBNN-GP-MF-MNF.py:183-185), log_q0 (:213-214) and every dot product of the chain
+    double acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] = 0.0;
+#pragma unroll 1
+    for (int i = tid; i < I; i += kFastThreads) {      // one element per thread: the Philox call (4 normals) is recomputed
+        float e;                                       // by the 4 threads sharing it -- parallel, so free on this chain
+        if (eps) e = ep[i];
+        else { float n[4]; philox_normal4(seed, offs, stream, (uint64_t)(i >> 2), 0u, n); e = n[i & 3]; }
+        const float ev = expf(lv[i]);
+        const float z0 = qm[i] + sqrtf(ev) * e;
+        z[i] = z0;
+        if (klblk) {
+            const float d = z0 - qm[i];
+            acc[NV - 1] += (double)(-0.5f * 1.1447298858494002f - 0.5f * lv[i] - 0.5f * ((d * d) / ev));
+        }
+        float u[kFastT], w[kFastT];
+#pragma unroll
+        for (int t = 0; t < kFastT; ++t) { u[t] = t < NT ? uw[(2 * t) * P + i] : 0.f; w[t] = t < NT ? uw[(2 * t + 1) * P + i] : 0.f; }
+        int q = 2 * kFastT;
+#pragma unroll
+        for (int t = 0; t < kFastT; ++t) {
+            acc[t] += (double)(w[t] * z0);
+            acc[kFastT + t] += (double)(u[t] * w[t]);
+#pragma unroll
+            for (int s2 = 0; s2 < t; ++s2) acc[q++] += (double)(w[t] * u[s2]);
+        }
+    }
+#ifdef LAB_STAMPS
+    if (klblk && tid == 0) a.scal[6] = (float)(__builtin_amdgcn_s_memrealtime() - lab_t0);
+#endif
+    // fixed-order reduction of the NV values: wave sums, then the per-wave partials through LDS in wave order
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] = wave_sum(acc[k]);
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) red[k][wv] = acc[k];
+    __syncthreads();                                              // also publishes z0 and s_bias
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double t2 = 0.0;
+#pragma unroll
+        for (int w2 = 0; w2 < kFastWaves; ++w2) t2 += red[k][w2];
+        acc[k] = t2;
+    }
+
+    // scalar chain (flows2.py:87-95), every thread redundantly
+    float th[kFastT], ld_q = 0.f, ld_r = 0.f;
+    {
+        int q = 2 * kFastT;
+#pragma unroll
+        for (int t = 0; t < kFastT; ++t) {
+            double inner = acc[t];
+#pragma unroll
+            for (int s2 = 0; s2 < t; ++s2) inner += (double)th[s2] * acc[q++];
+            th[t] = 0.f;
+            if (t < NT) {
+                th[t] = tanhf((float)inner + s_bias[t]);
+                const float ld = logf(fabsf(1.f + (1.f - th[t] * th[t]) * (float)acc[kFastT + t]));
+                if (t < Tz) ld_q += ld; else ld_r += ld;
+            }
+        }
+    }
+    // z after the z flow (the layer's z_k / z2); the r-flow steps only add to the scalar z_b[-1]
+    float* zo = klblk ? a.z_kl : a.z_fwd;
+#pragma unroll 1
+    for (int i = tid; i < I; i += kFastThreads) {
+        float v = z[i];
+#pragma unroll
+        for (int t = 0; t < kFastT; ++t) if (t < Tz) v += uw[(2 * t) * P + i] * th[t];
+        zo[i] = v;
+        if (klblk && i == I - 1) {
+#pragma unroll
+            for (int t = 0; t < kFastT; ++t) if (t >= Tz && t < NT) v += uw[(2 * t) * P + i] * th[t];
+            a.scal[3] = v;                                                   // z_b[-1]: last ELEMENT (:224)
+        }
+    }
+#ifdef LAB_STAMPS
+    if (klblk && tid == 0) a.scal[7] = (float)(__builtin_amdgcn_s_memrealtime() - lab_t0);
+#endif
+    if (tid == 0) {
+        if (!klblk) { if (a.scal) a.scal[4] = ld_q; }
+        else { a.scal[0] = ld_q; a.scal[1] = (float)acc[NV - 1]; a.scal[2] = ld_r; }
     }
 }
 
@@ -251,7 +382,7 @@ __global__ __launch_bounds__(256) void kl_finalize_kernel(const FinalizeBatch bt
 // K5, compact form: the eight input vectors are prefetched into LDS by LDS-DMA (all loads issued, one
 // wait), then reduced from LDS.  Used when they fit; otherwise kl_finalize_kernel above reads from global.
 __global__ __launch_bounds__(256) void kl_finalize_lds_kernel(const FinalizeBatch bt) {
-    const FinalizeArgs& a = bt.l[blockIdx.x];
+    const LBBNN_CONST_AS FinalizeArgs& a = kernarg_as<FinalizeBatch>()->l[blockIdx.x];
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ double scratch[8];
     const bool mnf = a.scal != nullptr;
@@ -390,8 +521,14 @@ int launch_flow_planar(const FlowArgs* a, int n, hipStream_t s) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnf_flow_planar_lds_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
             if (e != hipSuccess) return (int)e;
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnf_flow_planar_fast_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+            if (e != hipSuccess) return (int)e;
         }
-        hipLaunchKernelGGL(mnf_flow_planar_lds_kernel, grid, block, need, s, bt);
+        bool fast = true;
+        for (int i = 0; i < n; ++i) fast = fast && (a[i].zf.T + (a[i].want_kl ? a[i].rf.T : 0) <= kFastT);
+        if (fast) hipLaunchKernelGGL(mnf_flow_planar_fast_kernel, grid, dim3(kFastThreads), need, s, bt);
+        else      hipLaunchKernelGGL(mnf_flow_planar_lds_kernel, grid, block, need, s, bt);
     } else {
         hipLaunchKernelGGL(mnf_flow_planar_kernel, grid, block, (size_t)maxI * sizeof(float), s, bt);
     }

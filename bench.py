@@ -53,6 +53,21 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic(precision):
+    """HBM-side bytes per launch of the dominant GEMM from the committed rocprofv3 PMC pass (FETCH_SIZE x2 gfx950
+    correction + WRITE_SIZE; counters cannot be read from inside the process) -- None if no pass is committed for
+    this precision."""
+    path = os.path.join(ROOT, "profiles", "r01_e_pmc_gemm_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        if d.get("precision") == precision:
+            return d["hbm_bytes_per_launch"], d["source"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None, None
+
+
 def host_cores():
     """Host cores this job may actually use: the cgroup CPU quota when there is one (the GPU box
     gives a 1-GPU job a share of the host), else the affinity mask."""
@@ -201,11 +216,13 @@ def main():
             ach = flops / (avg_ms * 1e-3) / 1e12
             split = args.precision == "bf16x3"
             peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
+            traffic, traffic_src = pmc_traffic(args.precision)
             res["roofline"] = {"bound": "mfma",
                                "kernel": ("lrt_gemm_bf16x3_kernel<5,2,4>" if split else "lrt_gemm_f32_dma_kernel<5,2,4>")
                                          + " (dual-moment GEMM, 80x128 tile)",
                                "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                               "frac": ach / peak, "traffic": None,
+                               "frac": ach / peak, "traffic": traffic, "traffic_unit": "HBM-side bytes per launch",
+                               "traffic_source": traffic_src,
                                "executed_mfma_tflops": ach * (3.0 if split else 1.0),
                                "note": "achieved = ALGORITHMIC 4*B*I*O flop per launch / HIP-event time; the bf16x3 path "
                                        "executes 3 bf16 products per algorithmic product" if split else
