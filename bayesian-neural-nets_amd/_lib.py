@@ -73,6 +73,12 @@ class WpbArgs(ctypes.Structure):
                [("O", c_i), ("I", c_i)]
 
 
+class OutGradArgs(ctypes.Structure):
+    """lbbnn_outgrad_args_t"""
+    _fields_ = [(n, c_p) for n in ("g_out", "out", "std", "eps", "rng", "gm", "gv", "gmT", "gvT", "g_sum", "gv_sum", "work")] + \
+               [("row_offset", c_i64), ("rng_stream", c_u32)] + [(n, c_i) for n in ("B", "O", "ldg", "ldo", "relu")]
+
+
 class FlowStep(ctypes.Structure):
     """lbbnn_flow_step_t"""
     _fields_ = [("p0", c_p), ("p1", c_p), ("p2", c_p), ("type", c_i), ("M", c_i)]
@@ -111,6 +117,8 @@ SIGNATURES = {
     "lbbnn_transpose_operand": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p]),
     "lbbnn_weight_pass_backward_workspace": (c_i64, [c_i, c_i]),
     "lbbnn_weight_pass_backward": (c_i, [ctypes.POINTER(WpbArgs), c_p]),
+    "lbbnn_output_grad_workspace": (c_i64, [c_i, c_i]),
+    "lbbnn_output_grad": (c_i, [ctypes.POINTER(OutGradArgs), c_p]),
     "lbbnn_flow_chain": (c_i, [ctypes.POINTER(FlowChain), c_p, c_p, c_p, c_p, c_p, c_u32, c_i, c_p, c_p, c_p, c_p, c_p]),
     "lbbnn_mnf_aux_backward": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
     "lbbnn_mnf_flow_backward_workspace": (c_i64, [c_i, c_i, c_i]),

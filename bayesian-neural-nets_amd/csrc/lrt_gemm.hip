@@ -1074,6 +1074,7 @@ static int lrt_gemm_impl(const float* x, int ldx, const void* e_w, const void* v
                          const float* bias_mean, const float* bias_var, const float* var_scale,
                          const float* eps, const uint64_t* rng, uint32_t rng_stream, int64_t row_offset,
                          float* out, int ldo, float* std_out, int B, int I, int O, int flags, void* stream) {
+    if (B == 0 && I > 0 && O > 0) return 0;        // empty batch (torch.mm of 0 rows, LBBNN-GP-MF-LRT.py:172): nothing to do
     if (!x || !e_w || !out) return LBBNN_E_NULL;
     if (B <= 0 || I <= 0 || O <= 0 || ldx < I || ldo < O) return LBBNN_E_SHAPE;
     if (flags & ~(LBBNN_F_RELU | LBBNN_F_MEAN_ONLY | LBBNN_F_SPLIT16 | LBBNN_F_LOG_SOFTMAX)) return LBBNN_E_FLAGS;

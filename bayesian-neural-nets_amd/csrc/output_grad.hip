@@ -1,0 +1,121 @@
+// lbbnn_output_grad: the (B,O) elementwise head of the backward pass, fused (see include/lbbnn.h).  HBM-bound:
+// reads g_out, out, std (12 B/elt; eps is re-created from Philox), writes G_m, G_v and their transposes (16 B/elt).
+// A 256-thread workgroup owns a 64(b) x 64(o) tile: float4 row-major reads/writes, the transposes through two
+// padded LDS tiles, and the tile's column sums as per-tile partials that a second launch adds in a fixed order.
+#include "lbbnn_device.h"
+#include "lbbnn_internal.h"
+
+namespace {
+
+using namespace lbbnn;
+constexpr int TS = 64;
+
+__global__ __launch_bounds__(256) void output_grad_kernel(const lbbnn_outgrad_args_t a, int nbt) {
+    __shared__ float tm[TS][TS + 1], tv[TS][TS + 1];
+    const int b0 = blockIdx.y * TS, o0 = blockIdx.x * TS, tid = threadIdx.x;
+    const bool stoch = a.std != nullptr;
+    uint64_t seed = 0, offs = 0;
+    if (stoch && !a.eps) { seed = a.rng[0]; offs = a.rng[1]; }
+    const bool vec = ((a.O & 3) == 0) && ((a.ldg & 3) == 0) && ((a.ldo & 3) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(a.g_out) & 15u) == 0) && (!a.out || (reinterpret_cast<uintptr_t>(a.out) & 15u) == 0) &&
+                     (!stoch || (reinterpret_cast<uintptr_t>(a.std) & 15u) == 0) && (!a.eps || (reinterpret_cast<uintptr_t>(a.eps) & 15u) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(a.gm) & 15u) == 0) && (!stoch || (reinterpret_cast<uintptr_t>(a.gv) & 15u) == 0);
+    // ---- row-major pass: thread -> (row r = idx / 16, 4 consecutive o)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int idx = tid + 256 * k, r = idx >> 4, c = (idx & 15) * 4;
+        const int b = b0 + r, o = o0 + c;
+        float gm[4] = {0.f, 0.f, 0.f, 0.f}, gv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (b < a.B && o < a.O) {
+            float g[4], y[4] = {1.f, 1.f, 1.f, 1.f}, sd[4] = {1.f, 1.f, 1.f, 1.f}, e[4] = {0.f, 0.f, 0.f, 0.f};
+            const size_t ig = (size_t)b * a.ldg + o, io = (size_t)b * a.ldo + o;
+            if (vec) {
+                const float4 t = *reinterpret_cast<const float4*>(a.g_out + ig);
+                g[0] = t.x; g[1] = t.y; g[2] = t.z; g[3] = t.w;
+                if (a.relu) { const float4 u = *reinterpret_cast<const float4*>(a.out + io); y[0] = u.x; y[1] = u.y; y[2] = u.z; y[3] = u.w; }
+                if (stoch) { const float4 u = *reinterpret_cast<const float4*>(a.std + io); sd[0] = u.x; sd[1] = u.y; sd[2] = u.z; sd[3] = u.w; }
+                if (stoch && a.eps) { const float4 u = *reinterpret_cast<const float4*>(a.eps + (size_t)b * a.O + o); e[0] = u.x; e[1] = u.y; e[2] = u.z; e[3] = u.w; }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool in = o + q < a.O;
+                    g[q] = in ? a.g_out[ig + q] : 0.f;
+                    if (a.relu) y[q] = in ? a.out[io + q] : 0.f;
+                    if (stoch) sd[q] = in ? a.std[io + q] : 1.f;
+                    if (stoch && a.eps) e[q] = in ? a.eps[(size_t)b * a.O + o + q] : 0.f;
+                }
+            }
+            if (stoch && !a.eps) philox_normal4(seed, offs, a.rng_stream, (uint64_t)(a.row_offset + b), (uint32_t)(o >> 2), e);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                gm[q] = (a.relu && !(y[q] > 0.f)) ? 0.f : g[q];
+                if (stoch) gv[q] = gm[q] * e[q] / (2.f * sd[q]);
+                if (o + q >= a.O) { gm[q] = 0.f; gv[q] = 0.f; }
+            }
+            const size_t id = (size_t)b * a.O + o;
+            if (vec) {
+                *reinterpret_cast<float4*>(a.gm + id) = make_float4(gm[0], gm[1], gm[2], gm[3]);
+                if (stoch) *reinterpret_cast<float4*>(a.gv + id) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (o + q < a.O) { a.gm[id + q] = gm[q]; if (stoch) a.gv[id + q] = gv[q]; }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { tm[r][c + q] = gm[q]; tv[r][c + q] = gv[q]; }
+    }
+    __syncthreads();
+    // ---- transposed pass: thread -> (column oc = idx / 64, row br = idx % 64): 256-B contiguous rows of G^T
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int idx = tid + 256 * k, oc = idx >> 6, br = idx & 63;
+        const int o = o0 + oc, b = b0 + br;
+        if (o < a.O && b < a.B) {
+            a.gmT[(size_t)o * a.B + b] = tm[br][oc];
+            if (stoch) a.gvT[(size_t)o * a.B + b] = tv[br][oc];
+        }
+    }
+    // ---- column sums of the tile (rows past B hold zeros)
+    if (tid < 2 * TS) {
+        const int oc = tid & 63, which = tid >> 6;
+        if (which == 0 || stoch) {
+            float s = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < TS; ++r) s += which ? tv[r][oc] : tm[r][oc];
+            const int o = o0 + oc;
+            if (o < a.O) a.work[((size_t)which * nbt + blockIdx.y) * a.O + o] = s;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void output_grad_sum_kernel(const float* __restrict__ work, int nbt, int O, float* g_sum, float* gv_sum) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= O) return;
+    float s = 0.f, v = 0.f;
+    for (int t = 0; t < nbt; ++t) { s += work[(size_t)t * O + o]; if (gv_sum) v += work[((size_t)nbt + t) * O + o]; }
+    g_sum[o] = s;
+    if (gv_sum) gv_sum[o] = v;
+}
+
+}  // namespace
+
+extern "C" int64_t lbbnn_output_grad_workspace(int B, int O) {
+    if (B <= 0 || O <= 0) return 0;
+    return 2LL * ((B + TS - 1) / TS) * O;
+}
+
+extern "C" int lbbnn_output_grad(const lbbnn_outgrad_args_t* p, void* stream) {
+    if (!p) return LBBNN_E_NULL;
+    const lbbnn_outgrad_args_t& a = *p;
+    if (!a.g_out || !a.gm || !a.gmT || !a.g_sum || !a.work) return LBBNN_E_NULL;
+    if (a.relu && !a.out) return LBBNN_E_NULL;
+    if (a.std && (!a.gv || !a.gvT || !a.gv_sum)) return LBBNN_E_NULL;
+    if (a.std && !a.eps && !a.rng) return LBBNN_E_NOISE;
+    if (a.B <= 0 || a.O <= 0 || a.ldg < a.O || ((a.relu || a.std) && a.ldo < a.O)) return LBBNN_E_SHAPE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nbt = (a.B + TS - 1) / TS;
+    hipLaunchKernelGGL(output_grad_kernel, dim3((a.O + TS - 1) / TS, nbt), dim3(256), 0, s, a, nbt);
+    hipLaunchKernelGGL(output_grad_sum_kernel, dim3((a.O + 255) / 256), dim3(256), 0, s, a.work, nbt, a.O, a.g_sum,
+                       a.std ? a.gv_sum : nullptr);
+    return (int)hipGetLastError();
+}

@@ -70,13 +70,14 @@ class _BayesLinearFn(torch.autograd.Function):
         params = tens[3 if ctx.has_std else 2:]
         mu, rho, lam = params[0], params[1], params[2]
         B = x.shape[0]
-        noise = layer._noise_for_backward(ctx.saved, B)
-        g = g_out.contiguous()
-        if relu:
-            g = g * (out > 0)
-        g_v = None
-        if stochastic:
-            g_v = g * noise["eps_out"] / (2 * std)
+        # ---- (B,O) head: mask, G_v, transposes and column sums in one HIP pass; eps_out is re-created from the
+        # forward's Philox state inside the kernel unless explicit draws were given
+        explicit = ctx.saved.get("noise") or {}
+        g, g_v, gT, g_vT, g_sum, gv_sum = ops.output_grad(
+            g_out, out=out if relu else None, std=std if stochastic else None, eps=explicit.get("eps_out"),
+            rng=ctx.saved.get("rng"), rng_stream=ops.STREAM_EPS_OUT * 64 + layer._layer_id, row_offset=layer.row_offset,
+            relu=relu)
+        noise = layer._noise_for_backward(ctx.saved, B, need_out=False)
         planar = layer._mnf and layer._check_flows() == "planar"
         g_kl = g_kl.contiguous() if want_kl else None
         da_mu = da_var = aux = r0_c = vg = None
@@ -114,14 +115,12 @@ class _BayesLinearFn(torch.autograd.Function):
             gx = _hip_matmul_nt(g, ops.transpose_operand, bw[0][:, :I])
             if stochastic:
                 gx = gx + 2 * x * _hip_matmul_nt(g_v, ops.transpose_operand, bw[1][:, :I])
-        dWm = _hip_matmul_nt(g.t().contiguous(), ops.transpose_operand, x)
-        dWv = _hip_matmul_nt(g_v.t().contiguous(), ops.transpose_operand, x, square=True) if stochastic else None
+        dWm = _hip_matmul_nt(gT, ops.transpose_operand, x)
+        dWv = _hip_matmul_nt(g_vT, ops.transpose_operand, x, square=True) if stochastic else None
         # ---- K1b: the whole (O,I) chain in one pass
         dmu, drho, dlam, dz_k, dz2, dr0c = ops.weight_pass_backward(
             mu, rho, lam, dWm, dWv, z_fwd=z_k, z_kl=z2, r0_c=r0_c, da_mu=da_mu, da_var=da_var, g_kl=g_kl,
             priors=layer.priors)
-        g_sum = g.sum(0)
-        gv_sum = g_v.sum(0) if stochastic else None
         if planar:
             zp, rp = layer._planar_params_from(params)
             G = ops.mnf_flow_planar_backward(
@@ -326,10 +325,10 @@ class LRTBayesianLinear(_BayesLinearBase):
                             relu=relu, mean_only=not stochastic, log_softmax=log_softmax, split=self._split_now,
                             std_out=std_out)
 
-    def _noise_for_backward(self, saved, B):
+    def _noise_for_backward(self, saved, B, need_out=True):
         if saved.get("noise") and "eps_out" in saved["noise"]:
             return saved["noise"]
-        if saved.get("rng") is None:
+        if saved.get("rng") is None or not need_out:
             return {}
         return {"eps_out": ops.philox_normal(saved["rng"], ops.STREAM_EPS_OUT * 64 + self._layer_id,
                                              B, self.out_features, self.row_offset)}
@@ -546,7 +545,7 @@ class MNFBayesianLinear(_BayesLinearBase):
                             row_offset=self.row_offset, relu=relu, mean_only=not stochastic,
                             log_softmax=log_softmax, split=self._split_now, std_out=std_out)
 
-    def _noise_for_backward(self, saved, B):
+    def _noise_for_backward(self, saved, B, need_out=True):
         masks = saved.get("masks") or {}
         if saved.get("noise"):
             n = dict(saved["noise"])
@@ -557,10 +556,11 @@ class MNFBayesianLinear(_BayesLinearBase):
             n.update(masks)
             return n
         r, L, I, O = saved["rng"], self._layer_id, self.in_features, self.out_features
-        n = {"eps_out": ops.philox_normal(r, ops.STREAM_EPS_OUT * 64 + L, B, O, self.row_offset),
-             "eps_z": ops.philox_normal(r, ops.STREAM_EPS_Z * 64 + L, 0, I),
+        n = {"eps_z": ops.philox_normal(r, ops.STREAM_EPS_Z * 64 + L, 0, I),
              "eps_z2": ops.philox_normal(r, ops.STREAM_EPS_Z2 * 64 + L, 0, I),
              "eps_act": ops.philox_normal(r, ops.STREAM_EPS_ACT * 64 + L, 0, O)}
+        if need_out:
+            n["eps_out"] = ops.philox_normal(r, ops.STREAM_EPS_OUT * 64 + L, B, O, self.row_offset)
         n.update(masks)
         return n
 

@@ -144,6 +144,42 @@ def weight_pass(mu, rho, lambdal, *, z_fwd=None, z_kl=None, r0_c=None, bias_rho=
     _lib.check(rc, "lbbnn_weight_pass")
 
 
+def output_grad(g_out, *, out=None, std=None, eps=None, rng=None, rng_stream: int = 0, row_offset: int = 0,
+                relu: bool = False):
+    """lbbnn_output_grad.  Returns (gm, gv, gmT, gvT, g_sum, gv_sum); the gv* are None for a posterior-mean forward."""
+    B, O = g_out.shape
+    f = dict(dtype=torch.float32, device=g_out.device)
+    if g_out.stride(1) != 1:
+        g_out = g_out.contiguous()
+    stoch = std is not None
+    gm, gmT, g_sum = torch.empty((B, O), **f), torch.empty((O, B), **f), torch.empty(O, **f)
+    gv = gvT = gv_sum = None
+    if stoch:
+        gv, gvT, gv_sum = torch.empty((B, O), **f), torch.empty((O, B), **f), torch.empty(O, **f)
+    if B == 0:
+        g_sum.zero_()
+        if stoch:
+            gv_sum.zero_()
+        return gm, gv, gmT, gvT, g_sum, gv_sum
+    a = _lib.OutGradArgs()
+    a.g_out = _ptr_rows(g_out, "g_out")
+    a.out = _ptr_rows(out, "out") if (relu and out is not None) else None
+    a.std = _ptr_rows(std, "std") if stoch else None
+    ldo = out.stride(0) if (relu and out is not None) else (std.stride(0) if stoch else O)
+    if relu and stoch and out.stride(0) != std.stride(0):
+        raise ValueError("bnn_amd: out and std must share a row stride")
+    a.eps = _ptr(eps, "eps") if (stoch and eps is not None) else None
+    a.rng = rng.data_ptr() if rng is not None else None
+    work = torch.empty(_lib.lib().lbbnn_output_grad_workspace(B, O), **f)
+    a.gm, a.gmT, a.g_sum, a.work = gm.data_ptr(), gmT.data_ptr(), g_sum.data_ptr(), work.data_ptr()
+    if stoch:
+        a.gv, a.gvT, a.gv_sum = gv.data_ptr(), gvT.data_ptr(), gv_sum.data_ptr()
+    a.row_offset, a.rng_stream = row_offset, rng_stream
+    a.B, a.O, a.ldg, a.ldo, a.relu = B, O, g_out.stride(0), ldo, 1 if relu else 0
+    _lib.check(_lib.lib().lbbnn_output_grad(ctypes.byref(a), _stream()), "lbbnn_output_grad")
+    return gm, gv, gmT, gvT, g_sum, gv_sum
+
+
 def weight_pass_backward(mu, rho, lambdal, dWm, dWv=None, *, z_fwd=None, z_kl=None, r0_c=None, da_mu=None,
                          da_var=None, g_kl=None, priors: Priors, work: Optional[torch.Tensor] = None):
     """lbbnn_weight_pass_backward (K1b).  Returns (dmu, drho, dlambdal, dz_fwd, dz_kl, dr0_c); the three
@@ -193,6 +229,8 @@ def lrt_gemm(x, e_w, var_w, *, I: int, O: int, bias_mean=None, bias_var=None, va
         raise RuntimeError("bnn_amd: eps must be (%d,%d), got %s" % (B, O, tuple(eps.shape)))
     flags = ((F_RELU if relu else 0) | (F_MEAN_ONLY if mean_only else 0) | (F_LOG_SOFTMAX if log_softmax else 0)
              | (F_SPLIT16 if split else 0))
+    if B == 0:                     # empty batch: (0,O) activations, as torch.mm gives; the KL side is unaffected
+        return out
     if x.stride(1) != 1 or (x.stride(0) < I):
         x = x.contiguous()
     ev = None

@@ -106,6 +106,7 @@ int lbbnn_weight_pass(const float* mu, const float* rho, const float* lambdal,
  * x (B,I) with row stride ldx floats; e_w/var_w operands from lbbnn_weight_pass (leading dim ld);
  * bias_mean/bias_var/var_scale (O) or NULL (0 / 0 / 1); eps (B,O) or NULL => Philox from `rng`
  * with counter = (row_offset + b, o/4), stream id `rng_stream`; out (B,O) row stride ldo.
+  * B == 0 (empty batch) is a successful no-op.
  */
 int lbbnn_lrt_gemm(const float* x, int ldx, const void* e_w, const void* var_w, int ld,
                    const float* bias_mean, const float* bias_var, const float* var_scale,
@@ -416,6 +417,27 @@ typedef struct lbbnn_flow_chain {
 int lbbnn_flow_chain(const lbbnn_flow_chain_t* chain, const float* z_in, const float* q0_mean,
                      const float* q0_log_var, const float* eps, const uint64_t* rng, uint32_t rng_stream, int I,
                      float* z_out, float* logdet, float* log_q0, float* z_last, void* stream);
+
+/* lbbnn_output_grad -- the (B,O) elementwise head of the layer backward in one pass (LBBNN-GP-MF-LRT.py:172-175 read
+ * backwards):   G_m = g_out (.) [out > 0 if relu],   G_v = G_m * eps / (2 std)     (std = sqrt(var_b) of the forward)
+ * written both row-major (B,O) -- the A operands of dX = G_m.W_m + 2x(.)(G_v.W_v) -- and transposed (O,B) -- the A
+ * operands of dW_m = G_m^T.x, dW_v = G_v^T.x^2 -- plus the column sums g_sum = sum_b G_m, gv_sum = sum_b G_v (the
+ * bias gradients).  eps (B,O) explicit, or NULL => re-created in-kernel from the Philox state the forward used
+ * (stream rng_stream, counter (row_offset + b, o/4)).  std == NULL => posterior-mean forward: only G_m / G_m^T / g_sum.
+ * Column sums are deterministic (per-64-row partials in work, fixed-order second launch).
+ */
+typedef struct lbbnn_outgrad_args {
+    const float *g_out, *out, *std, *eps;     /* (B,O), row strides ldg / ldo / ldo / O; out may be NULL when !relu   */
+    const uint64_t* rng;
+    float *gm, *gv, *gmT, *gvT;               /* (B,O) dense, (O,B) dense                                              */
+    float *g_sum, *gv_sum, *work;             /* (O), (O), lbbnn_output_grad_workspace floats                          */
+    int64_t row_offset;
+    uint32_t rng_stream;
+    int B, O, ldg, ldo, relu;
+} lbbnn_outgrad_args_t;
+
+int64_t lbbnn_output_grad_workspace(int B, int O);
+int lbbnn_output_grad(const lbbnn_outgrad_args_t* args, void* stream);
 
 #ifdef __cplusplus
 }

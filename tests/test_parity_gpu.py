@@ -949,3 +949,65 @@ def test_ensemble_eval_helper(bnn, dev):
     P = [{k: v.detach().cpu() for k, v in l.state_dict().items()} for l in (net.l1, net.l2, net.l3)]
     ref, _ = orc.lrt_network_forward(data.cpu(), P, [None] * 3, stochastic=False, compute_kl=False)
     assert torch.equal(ref.argmax(1), r["pred_posterior_mean"].cpu()) or rel_err(net(data).cpu(), ref) < TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,I,O", [(0, 33, 17), (1, 1, 1), (3, 5, 1), (2, 1, 7), (5, 16383, 3), (1, 2049, 130)])
+def test_edge_shapes_vs_oracle(bnn, dev, B, I, O):
+    """Empty batch, single row / column / feature, the largest flow dimension: LRT and MNF layers against the oracle
+    (in-kernel noise re-created with lbbnn_philox_normal)."""
+    from bnn_amd import ops
+    torch.manual_seed(B * 7 + I + O)
+    for kind in ("lrt", "mnf"):
+        if kind == "lrt":
+            l = bnn.lrt.BayesianLinear(I, O)
+        else:
+            l = bnn.mnf.BayesianLinear(I, O, 2, z_flow_type="Planar", r_flow_type="Planar")
+        p = {k: v.detach().clone() for k, v in l.state_dict().items()}
+        l = l.to(dev).train()
+        g = torch.Generator().manual_seed(1)
+        x = torch.rand(B, I, generator=g)
+        noise = {"eps_z": torch.randn(1, I, generator=g), "eps_out": torch.randn(B, O, generator=g),
+                 "eps_z2": torch.randn(1, I, generator=g), "eps_act": torch.randn(O, generator=g)}
+        l.noise = {k: v.to(dev) for k, v in noise.items()} if kind == "mnf" else {"eps_out": noise["eps_out"].to(dev)}
+        with torch.no_grad():
+            out = l(x.to(dev), sample=True)
+        assert tuple(out.shape) == (B, O)
+        if kind == "lrt":
+            ref, kl, _ = orc.lrt_forward(x, p, noise["eps_out"])
+        else:
+            zf = orc.flow_from_state("z_flow", "Planar", p, 2)
+            rf = orc.flow_from_state("r_flow", "Planar", p, 2)
+            ref, kl, _ = orc.mnf_forward(x, p, zf, rf, noise)
+        if B:
+            assert rel_err(out.cpu(), ref) < TOL, kind
+        assert abs(float(l.kl) - float(kl)) <= TOL * abs(float(kl)), kind
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,O", [(5, 3), (70, 33), (64, 64), (130, 1200), (257, 132)])
+@pytest.mark.parametrize("relu,stoch,explicit", [(True, True, True), (True, True, False), (False, True, False), (True, False, True)])
+def test_output_grad_kernel(bnn, dev, B, O, relu, stoch, explicit):
+    """lbbnn_output_grad against the torch formulas: G_m, G_v, both transposes, both column sums; eps explicit or
+    re-created in-kernel from the Philox state (checked against lbbnn_philox_normal)."""
+    from bnn_amd import ops
+    g = torch.Generator().manual_seed(B * 31 + O)
+    g_out = torch.randn(B, O, generator=g).to(dev)
+    out = torch.randn(B, O, generator=g).to(dev)
+    std = (0.1 + torch.rand(B, O, generator=g)).to(dev)
+    st = ops.RngState.get(dev)
+    rng = st.t.clone()
+    stream, row_off = ops.STREAM_EPS_OUT * 64 + 5, 1000
+    eps = torch.randn(B, O, generator=g).to(dev) if explicit else ops.philox_normal(rng, stream, B, O, row_off)
+    gm, gv, gmT, gvT, gs, gvs = ops.output_grad(g_out, out=out if relu else None, std=std if stoch else None,
+                                                eps=eps if explicit else None, rng=rng, rng_stream=stream,
+                                                row_offset=row_off, relu=relu)
+    ref_m = g_out * (out > 0) if relu else g_out
+    assert torch.equal(gm, ref_m) and torch.equal(gmT, ref_m.t())
+    assert rel_err(gs.cpu().double(), ref_m.double().sum(0).cpu()) < 1e-6
+    if stoch:
+        ref_v = ref_m * eps / (2 * std)
+        assert rel_err(gv, ref_v) < 1e-6 and torch.equal(gvT, gv.t())
+        assert rel_err(gvs.cpu().double(), gv.double().sum(0).cpu()) < 1e-6
+    else:
+        assert gv is None and gvT is None and gvs is None
