@@ -73,6 +73,15 @@ class WpbArgs(ctypes.Structure):
                [("O", c_i), ("I", c_i)]
 
 
+ADAM_MAX_TENSORS = 80
+
+
+class AdamList(ctypes.Structure):
+    """lbbnn_adam_list_t"""
+    _fields_ = [("p", c_p * ADAM_MAX_TENSORS), ("g", c_p * ADAM_MAX_TENSORS), ("m", c_p * ADAM_MAX_TENSORS),
+                ("v", c_p * ADAM_MAX_TENSORS), ("numel", c_i64 * ADAM_MAX_TENSORS), ("n", c_i)]
+
+
 class OutGradArgs(ctypes.Structure):
     """lbbnn_outgrad_args_t"""
     _fields_ = [(n, c_p) for n in ("g_out", "out", "std", "eps", "rng", "gm", "gv", "gmT", "gvT", "g_sum", "gv_sum", "work")] + \
@@ -117,6 +126,8 @@ SIGNATURES = {
     "lbbnn_transpose_operand": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p]),
     "lbbnn_weight_pass_backward_workspace": (c_i64, [c_i, c_i]),
     "lbbnn_weight_pass_backward": (c_i, [ctypes.POINTER(WpbArgs), c_p]),
+    "lbbnn_adam_step": (c_i, [ctypes.POINTER(AdamList), ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                              ctypes.c_float, c_p, c_i, c_p]),
     "lbbnn_output_grad_workspace": (c_i64, [c_i, c_i]),
     "lbbnn_output_grad": (c_i, [ctypes.POINTER(OutGradArgs), c_p]),
     "lbbnn_flow_chain": (c_i, [ctypes.POINTER(FlowChain), c_p, c_p, c_p, c_p, c_p, c_u32, c_i, c_p, c_p, c_p, c_p, c_p]),

@@ -1,0 +1,70 @@
+"""``Adam`` with ``torch.optim.Adam``'s constructor and update rule (the optimizer of the reference's training scripts:
+``optim.Adam(net.parameters(), lr=...)``, LBBNN-GP-MF-LRT.py:358, LBBNN-GP-MF-MNF.py:421; per-parameter groups in
+LBBNN-GP-MF.py:520-554), executed as ONE multi-tensor HIP launch per parameter group (``lbbnn_adam_step``) instead of
+torch's ~115 small kernels for the 66 parameter tensors of the headline net.  The step counter lives on the device, so
+``step()`` is HIP-graph capturable as it is (no ``capturable=`` switch needed).
+
+Not supported (raise): ``amsgrad``, ``maximize``, sparse gradients, non-fp32 or CPU parameters.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+class Adam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, *,
+                 maximize=False, capturable=True):
+        if amsgrad or maximize:
+            raise NotImplementedError("bnn_amd.optim.Adam: amsgrad / maximize are not implemented")
+        if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
+            raise ValueError("bnn_amd.optim.Adam: invalid hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    def _group_state(self, group):
+        st = self.state
+        for p in group["params"]:
+            if p not in st or "exp_avg" not in st[p]:
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError("bnn_amd.optim.Adam needs contiguous float32 parameters on a HIP device")
+                st[p]["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st[p]["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        if "step_dev" not in group:
+            ref = group["params"][0]
+            group["step_dev"] = torch.zeros(1, dtype=torch.float32, device=ref.device)
+        return group["step_dev"]
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            if not group["params"]:
+                continue
+            step = self._group_state(group)
+            ps = [p for p in group["params"] if p.grad is not None]
+            stream = torch.cuda.current_stream(step.device).cuda_stream
+            b1, b2 = group["betas"]
+            keep = []
+            chunks = [ps[i:i + _lib.ADAM_MAX_TENSORS] for i in range(0, len(ps), _lib.ADAM_MAX_TENSORS)] or [[]]
+            for ci, chunk in enumerate(chunks):
+                lst = _lib.AdamList()
+                lst.n = len(chunk)
+                for k, p in enumerate(chunk):
+                    g = p.grad
+                    if g.is_sparse:
+                        raise RuntimeError("bnn_amd.optim.Adam does not support sparse gradients")
+                    if not g.is_contiguous() or g.dtype != torch.float32:
+                        g = g.contiguous().float()
+                        keep.append(g)
+                    s = self.state[p]
+                    lst.p[k], lst.g[k] = p.data_ptr(), g.data_ptr()
+                    lst.m[k], lst.v[k], lst.numel[k] = s["exp_avg"].data_ptr(), s["exp_avg_sq"].data_ptr(), p.numel()
+                rc = _lib.lib().lbbnn_adam_step(ctypes.byref(lst), group["lr"], b1, b2, group["eps"], group["weight_decay"],
+                                                step.data_ptr(), 1 if ci == len(chunks) - 1 else 0, stream)
+                _lib.check(rc, "lbbnn_adam_step")
+            del keep
+        return loss

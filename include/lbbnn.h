@@ -439,6 +439,26 @@ typedef struct lbbnn_outgrad_args {
 int64_t lbbnn_output_grad_workspace(int B, int O);
 int lbbnn_output_grad(const lbbnn_outgrad_args_t* args, void* stream);
 
+/* lbbnn_adam_step -- torch.optim.Adam's update (the optimizer of the reference's training scripts,
+ * LBBNN-GP-MF-LRT.py:358, LBBNN-GP-MF-MNF.py:421) for a LIST of parameter tensors in one launch:
+ *   g' = g + weight_decay * p;  m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2;  t = *step + 1
+ *   p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+ * *step is a device-side float counter, read by every workgroup; advance != 0 adds 1 to it in a second one-thread
+ * launch (set it on the last list of an optimizer step), so the whole step is HIP-graph capturable.
+ */
+#define LBBNN_ADAM_MAX_TENSORS 80
+typedef struct lbbnn_adam_list {
+    float* p[LBBNN_ADAM_MAX_TENSORS];
+    const float* g[LBBNN_ADAM_MAX_TENSORS];
+    float* m[LBBNN_ADAM_MAX_TENSORS];
+    float* v[LBBNN_ADAM_MAX_TENSORS];
+    int64_t numel[LBBNN_ADAM_MAX_TENSORS];
+    int n;
+} lbbnn_adam_list_t;
+
+int lbbnn_adam_step(const lbbnn_adam_list_t* list, float lr, float beta1, float beta2, float eps, float weight_decay,
+                    float* step, int advance, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,7 +9,8 @@ dev = torch.device("cuda:0")
 bnn_amd.set_precision(os.environ.get("PREC", "bf16x3"))
 torch.manual_seed(0)
 net = bnn_amd.mnf.BayesianNetwork((784, 1200, 1200, 10), 2, z_flow_type="Planar", r_flow_type="Planar").to(dev).train()
-opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+FUSED = os.environ.get("FUSED_ADAM", "1") == "1"
+opt = (bnn_amd.optim.Adam if FUSED else torch.optim.Adam)(net.parameters(), lr=1e-3)
 x = torch.rand(4096, 1, 28, 28, device=dev); y = torch.randint(0, 10, (4096,), device=dev)
 
 
@@ -37,7 +38,7 @@ for name, bw in ((("forward only (autograd graph built)", False), ("forward + ba
 # ---- the same step captured in a HIP graph (fresh process: `train_step_time.py graph`)
 if MODE != "graph":
     sys.exit(0)
-opt2 = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True)
+opt2 = bnn_amd.optim.Adam(net.parameters(), lr=1e-3) if FUSED else torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True)
 lf = lambda n, a, b: torch.nn.functional.nll_loss(n(a, sample=True), b, reduction="sum") + n.kl() / 15
 gstep = bnn_amd.graphs.make_graphed_train_step(net, opt2, lf, x, y)
 for _ in range(3):
