@@ -128,6 +128,7 @@ SIGNATURES = {
     "lbbnn_weight_pass_backward": (c_i, [ctypes.POINTER(WpbArgs), c_p]),
     "lbbnn_adam_step": (c_i, [ctypes.POINTER(AdamList), ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                               ctypes.c_float, c_p, c_i, c_p]),
+    "lbbnn_dx_combine": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "lbbnn_output_grad_workspace": (c_i64, [c_i, c_i]),
     "lbbnn_output_grad": (c_i, [ctypes.POINTER(OutGradArgs), c_p]),
     "lbbnn_flow_chain": (c_i, [ctypes.POINTER(FlowChain), c_p, c_p, c_p, c_p, c_p, c_u32, c_i, c_p, c_p, c_p, c_p, c_p]),

@@ -88,13 +88,31 @@ __global__ __launch_bounds__(256) void output_grad_kernel(const lbbnn_outgrad_ar
     }
 }
 
-__global__ __launch_bounds__(256) void output_grad_sum_kernel(const float* __restrict__ work, int nbt, int O, float* g_sum, float* gv_sum) {
-    const int o = blockIdx.x * 256 + threadIdx.x;
-    if (o >= O) return;
+// g_sum[o] = sum over row tiles of the partials; a workgroup owns 64 columns, its 16 waves each add every 16th
+// tile (coalesced 256-B rows), then the 16 partials are added in a fixed order.
+__global__ __launch_bounds__(1024) void output_grad_sum_kernel(const float* __restrict__ work, int nbt, int O, float* g_sum, float* gv_sum) {
+    __shared__ float part[2][16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int o = blockIdx.x * 64 + lane;
     float s = 0.f, v = 0.f;
-    for (int t = 0; t < nbt; ++t) { s += work[(size_t)t * O + o]; if (gv_sum) v += work[((size_t)nbt + t) * O + o]; }
-    g_sum[o] = s;
-    if (gv_sum) gv_sum[o] = v;
+    if (o < O)
+        for (int t = w; t < nbt; t += 16) { s += work[(size_t)t * O + o]; if (gv_sum) v += work[((size_t)nbt + t) * O + o]; }
+    part[0][w][lane] = s; part[1][w][lane] = v;
+    __syncthreads();
+    if (w < 2 && o < O && (w == 0 || gv_sum)) {
+        float t2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t2 += part[w][k][lane];
+        (w == 0 ? g_sum : gv_sum)[o] = t2;
+    }
+}
+
+// dX = G_m.W_m + 2 x (.) (G_v.W_v):  gx += 2 * x * gxv   (one pass instead of three elementwise launches)
+__global__ __launch_bounds__(256) void dx_combine_kernel(float* __restrict__ gx, const float* __restrict__ gxv,
+                                                         const float* __restrict__ x, int ldx, int B, int I) {
+    const int b = blockIdx.y;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < I; i += gridDim.x * 256)
+        gx[(size_t)b * I + i] += 2.f * x[(size_t)b * ldx + i] * gxv[(size_t)b * I + i];
 }
 
 }  // namespace
@@ -115,7 +133,15 @@ extern "C" int lbbnn_output_grad(const lbbnn_outgrad_args_t* p, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int nbt = (a.B + TS - 1) / TS;
     hipLaunchKernelGGL(output_grad_kernel, dim3((a.O + TS - 1) / TS, nbt), dim3(256), 0, s, a, nbt);
-    hipLaunchKernelGGL(output_grad_sum_kernel, dim3((a.O + 255) / 256), dim3(256), 0, s, a.work, nbt, a.O, a.g_sum,
+    hipLaunchKernelGGL(output_grad_sum_kernel, dim3((a.O + 63) / 64), dim3(1024), 0, s, a.work, nbt, a.O, a.g_sum,
                        a.std ? a.gv_sum : nullptr);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lbbnn_dx_combine(float* gx, const float* gxv, const float* x, int ldx, int B, int I, void* stream) {
+    if (!gx || !gxv || !x) return LBBNN_E_NULL;
+    if (B <= 0 || I <= 0 || ldx < I) return LBBNN_E_SHAPE;
+    hipLaunchKernelGGL(dx_combine_kernel, dim3((I + 1023) / 1024, B), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       gx, gxv, x, ldx, B, I);
     return (int)hipGetLastError();
 }

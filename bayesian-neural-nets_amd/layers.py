@@ -45,13 +45,17 @@ class _BayesLinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, layer, x, cfg, *params):
+        if layer._mnf:
+            # the backward needs this call's K3 / K1 by-products: give the call fresh output vectors instead of
+            # copying them out of the (reused) workspace afterwards
+            ws = layer._workspace()
+            for name in ("z_fwd", "z_kl", "scal", "act_mu", "act_var"):
+                setattr(ws, name, torch.empty_like(getattr(ws, name)))
         out, kl, saved = layer._forward_hip(x, cfg, save_rng=True, want_std=cfg[0])
         if layer._mnf:
-            ws = layer._workspace()                 # by-products of this call's K3 / K1 (the workspace is reused)
-            saved["z_fwd"] = ws.z_fwd.clone()
+            saved["z_fwd"] = ws.z_fwd
             if cfg[1]:
-                saved["act_mu"], saved["act_var"] = ws.act_mu.clone(), ws.act_var.clone()
-                saved["z_kl"], saved["scal"] = ws.z_kl.clone(), ws.scal.clone()
+                saved["act_mu"], saved["act_var"], saved["z_kl"], saved["scal"] = ws.act_mu, ws.act_var, ws.z_kl, ws.scal
         ctx.layer, ctx.cfg, ctx.saved = layer, cfg, saved
         std = saved.pop("std", None)
         ctx.has_std = std is not None
@@ -96,8 +100,8 @@ class _BayesLinearFn(torch.autograd.Function):
                 vs = [p.detach().requires_grad_(True) for p in params[3:]]
                 am = av = None
                 if layer._mnf and want_kl:
-                    am = ctx.saved["act_mu"].requires_grad_(True)
-                    av = ctx.saved["act_var"].requires_grad_(True)
+                    am = ctx.saved["act_mu"].detach().requires_grad_(True)
+                    av = ctx.saved["act_var"].detach().requires_grad_(True)
                 vg = layer._vector_graph(vs, cfg, noise, am, av)
             z_k = vg["z_k"].detach() if vg["z_k"] is not None else None
             z2 = vg["z2"].detach() if vg["z2"] is not None else None
@@ -114,7 +118,7 @@ class _BayesLinearFn(torch.autograd.Function):
             I = layer.in_features
             gx = _hip_matmul_nt(g, ops.transpose_operand, bw[0][:, :I])
             if stochastic:
-                gx = gx + 2 * x * _hip_matmul_nt(g_v, ops.transpose_operand, bw[1][:, :I])
+                gx = ops.dx_combine(gx, _hip_matmul_nt(g_v, ops.transpose_operand, bw[1][:, :I]), x)
         dWm = _hip_matmul_nt(gT, ops.transpose_operand, x)
         dWv = _hip_matmul_nt(g_vT, ops.transpose_operand, x, square=True) if stochastic else None
         # ---- K1b: the whole (O,I) chain in one pass

@@ -180,6 +180,14 @@ def output_grad(g_out, *, out=None, std=None, eps=None, rng=None, rng_stream: in
     return gm, gv, gmT, gvT, g_sum, gv_sum
 
 
+def dx_combine(gx, gxv, x):
+    """lbbnn_dx_combine: gx += 2 * x * gxv in place (gx, gxv dense (B,I); x may have a row stride)."""
+    B, I = gx.shape
+    rc = _lib.lib().lbbnn_dx_combine(_ptr(gx, "gx"), _ptr(gxv, "gxv"), _ptr_rows(x, "x"), x.stride(0), B, I, _stream())
+    _lib.check(rc, "lbbnn_dx_combine")
+    return gx
+
+
 def weight_pass_backward(mu, rho, lambdal, dWm, dWv=None, *, z_fwd=None, z_kl=None, r0_c=None, da_mu=None,
                          da_var=None, g_kl=None, priors: Priors, work: Optional[torch.Tensor] = None):
     """lbbnn_weight_pass_backward (K1b).  Returns (dmu, drho, dlambdal, dz_fwd, dz_kl, dr0_c); the three

@@ -438,6 +438,9 @@ typedef struct lbbnn_outgrad_args {
 
 int64_t lbbnn_output_grad_workspace(int B, int O);
 int lbbnn_output_grad(const lbbnn_outgrad_args_t* args, void* stream);
+/* gx (B,I dense) += 2 * x (B,I; row stride ldx) * gxv (B,I dense): the input gradient of the variance GEMM folded
+ * into dX = G_m.W_m + 2 x (.) (G_v.W_v)  (d/dx of (x^2).var_w^T, LBBNN-GP-MF-LRT.py:173). */
+int lbbnn_dx_combine(float* gx, const float* gxv, const float* x, int ldx, int B, int I, void* stream);
 
 /* lbbnn_adam_step -- torch.optim.Adam's update (the optimizer of the reference's training scripts,
  * LBBNN-GP-MF-LRT.py:358, LBBNN-GP-MF-MNF.py:421) for a LIST of parameter tensors in one launch:
