@@ -218,8 +218,19 @@ def weight_pass_backward(mu, rho, lambdal, dWm, dWv=None, *, z_fwd=None, z_kl=No
 
 
 # ----------------------------------------------------------------------------------------- K2
-# When set to a list, every lrt_gemm launch is bracketed by HIP events recorded on the launch
-# stream and (B, I, O, start, end) is appended -- bench.py's per-kernel roofline timing.
+# When set to a GemmEventLog, every lrt_gemm launch is bracketed by HIP events recorded on the launch stream and
+# (B, I, O, start, end) is logged -- bench.py's per-kernel roofline timing.  The events are created up front:
+# creating them inside the timed loop was measured at ~35 us each on some hosts, i.e. the measurement slowed the
+# step it measures.
+class GemmEventLog(list):
+    def __init__(self, launches: int):
+        super().__init__()
+        self._pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
+
+    def take(self):
+        return self._pool.pop() if self._pool else None
+
+
 GEMM_EVENTS = None
 
 
@@ -241,9 +252,8 @@ def lrt_gemm(x, e_w, var_w, *, I: int, O: int, bias_mean=None, bias_var=None, va
         return out
     if x.stride(1) != 1 or (x.stride(0) < I):
         x = x.contiguous()
-    ev = None
-    if GEMM_EVENTS is not None:
-        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    ev = GEMM_EVENTS.take() if GEMM_EVENTS is not None else None
+    if ev is not None:
         ev[0].record()
     if std_out is None:
         rc = _lib.lib().lbbnn_lrt_gemm(

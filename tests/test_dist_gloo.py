@@ -65,7 +65,7 @@ def _worker(rank, world, port, dims, B, q):
     dp.all_reduce_grads()
     grads = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
     params = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
-    q.put((rank, grads, params))
+    q.put((rank, grads.tolist(), params.tolist()))   # plain lists: no fd passing that needs the sender alive
     dist.barrier()
     dist.destroy_process_group()
 
@@ -79,6 +79,7 @@ def test_two_rank_gradient_equals_single_process():
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    res = [(r, torch.tensor(gr), torch.tensor(pr)) for r, gr, pr in res]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
