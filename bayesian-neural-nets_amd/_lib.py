@@ -70,7 +70,7 @@ class WpbArgs(ctypes.Structure):
     _fields_ = [(n, c_p) for n in ("mu", "rho", "lambdal", "dWm", "dWv", "z_fwd", "z_kl", "r0_c",
                                    "da_mu", "da_var", "g_kl")] + [("priors", Priors)] + \
                [(n, c_p) for n in ("dmu", "drho", "dlambdal", "dz_fwd", "dz_kl", "dr0_c", "work")] + \
-               [("O", c_i), ("I", c_i)]
+               [("O", c_i), ("I", c_i), ("nsplit", c_i), ("split_stride", c_i64)]
 
 
 ADAM_MAX_TENSORS = 80
@@ -128,6 +128,7 @@ SIGNATURES = {
     "lbbnn_weight_pass_backward": (c_i, [ctypes.POINTER(WpbArgs), c_p]),
     "lbbnn_adam_step": (c_i, [ctypes.POINTER(AdamList), ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                               ctypes.c_float, c_p, c_i, c_p]),
+    "lbbnn_matmul_splitk": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "lbbnn_dx_combine": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "lbbnn_output_grad_workspace": (c_i64, [c_i, c_i]),
     "lbbnn_output_grad": (c_i, [ctypes.POINTER(OutGradArgs), c_p]),

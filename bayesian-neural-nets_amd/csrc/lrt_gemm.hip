@@ -42,6 +42,8 @@ struct GemmArgs {
     int ldx, ld, ldo, B, I, O;
     uint32_t rng_stream;
     int relu, log_softmax;
+    int kchunk;              // split-K (bf16x3 kernel only): workgroup z contracts k in [z*kchunk, (z+1)*kchunk), 0 = off
+    long long split_stride;  // ... and writes its partial product to out + z*split_stride
 };
 
 // XCD-aware tile assignment (cdna guide T1).  Workgroups are dealt round-robin over the 8 XCDs, each with
@@ -497,6 +499,9 @@ __global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_bf16x3_kernel(const GemmA
     tile_of_block(tox, tby);
     const int o0 = tox * BN;
     const int b0 = tby * BM;
+    // split-K: this workgroup's k range (kbeg is a multiple of 32, so every alignment below is unchanged)
+    const int kbeg = a.kchunk ? (int)blockIdx.z * a.kchunk : 0;
+    const int Iloc = a.kchunk ? min(a.I - kbeg, a.kchunk) : a.I;
     const char* const eh = reinterpret_cast<const char*>(a.e_w);
     const char* const el = eh + (size_t)a.O * a.ld * 2;
     const char* const vh = reinterpret_cast<const char*>(a.var_w);
@@ -513,18 +518,18 @@ __global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_bf16x3_kernel(const GemmA
         if (g < NGX) {
             const int row = 8 * g + (lane >> 3);
             const int slot = (lane & 7) ^ swzx(row & 15);
-            gp[u] = reinterpret_cast<const char*>(a.x + (size_t)min(b0 + row, a.B - 1) * a.ldx) + 16 * slot;
+            gp[u] = reinterpret_cast<const char*>(a.x + (size_t)min(b0 + row, a.B - 1) * a.ldx + kbeg) + 16 * slot;
             adv[u] = 128; kx[u] = 4 * slot;
         } else {
             const int gw = g - NGX, pl = gw / NGW, row = 16 * (gw % NGW) + (lane >> 2);
             const int slot = (lane & 3) ^ swz(row >> 2);
             const char* base = pl == 0 ? eh : (pl == 1 ? el : (pl == 2 ? vh : vl));
-            gp[u] = base + ((size_t)min(o0 + row, a.O - 1) * a.ld) * 2 + 16 * slot;
+            gp[u] = base + ((size_t)min(o0 + row, a.O - 1) * a.ld + kbeg) * 2 + 16 * slot;
             adv[u] = 64; kx[u] = -1;
         }
     }
-    const int nsteps = (a.I + BKS - 1) / BKS;
-    const bool has_tail = (a.I % BKS) != 0;
+    const int nsteps = (Iloc + BKS - 1) / BKS;
+    const bool has_tail = (Iloc % BKS) != 0;
     auto dma_step = [&](int c, char* buf) {
         const bool tail = has_tail && c == nsteps - 1;
 #pragma unroll
@@ -532,7 +537,7 @@ __global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_bf16x3_kernel(const GemmA
             const int g = wv + WB * u;                   // wave-uniform
             if (g < NG) {
                 const char* src = gp[u] + (size_t)c * adv[u];
-                if (tail && kx[u] >= 0 && c * BKS + kx[u] >= a.I) src = zsrc;
+                if (tail && kx[u] >= 0 && c * BKS + kx[u] >= Iloc) src = zsrc;
                 const int loff = g < NGX ? g * 1024 : XB + (g - NGX) * 1024;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(buf + loff), 16, 0, 0);
@@ -633,19 +638,21 @@ __global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_bf16x3_kernel(const GemmA
         __syncthreads();
     }
 
-    const EpiCtx ec = make_epi_ctx<MEAN_ONLY>(a);
+    GemmArgs ao = a;                                     // split-K: partial product z goes to its own output slab
+    if (a.kchunk) ao.out = a.out + (size_t)blockIdx.z * a.split_stride;
+    const EpiCtx ec = make_epi_ctx<MEAN_ONLY>(ao);
 #pragma unroll
     for (int i = 0; i < TO; ++i) {
         const int o = o0 + i * 16 + 4 * q;
         if (o >= a.O) continue;
-        const OConst oc = load_oconst(a, o);
+        const OConst oc = load_oconst(ao, o);
 #pragma unroll
         for (int j = 0; j < TB; ++j) {
             const int b = b0 + (wv * TB + j) * 16 + lr;
             if (b >= a.B) continue;
             float res[4];
-            epilogue4<MEAN_ONLY>(a, ec, oc, b, o, accm[i][j], accv[i][j], res);
-            store4(a, ec, b, o, res);
+            epilogue4<MEAN_ONLY>(ao, ec, oc, b, o, accm[i][j], accv[i][j], res);
+            store4(ao, ec, b, o, res);
         }
     }
 }
@@ -1038,9 +1045,9 @@ int launch_cfg(const GemmArgs& a, bool mean_only, bool xvec, hipStream_t s) {
 template <int TO, int TB, int WB>
 int launch_split_cfg(const GemmArgs& a, bool mean_only, hipStream_t s) {
     constexpr int BN = TO * 16, BM = TB * WB * 16;
-    dim3 grid((a.O + BN - 1) / BN, (a.B + BM - 1) / BM);
+    dim3 grid((a.O + BN - 1) / BN, (a.B + BM - 1) / BM, a.kchunk ? (a.I + a.kchunk - 1) / a.kchunk : 1);
     dim3 block(WB * 64);
-    const long nblocks = (long)grid.x * grid.y;
+    const long nblocks = (long)grid.x * grid.y * grid.z;
     const size_t l_full = lds_request(2u * (BM * 128 + 4 * BN * 64), nblocks);
     const size_t l_mean = lds_request(2u * (BM * 128 + 2 * BN * 64), nblocks);
     if (mean_only) return launch_one(lrt_gemm_bf16x3_kernel<TO, TB, WB, true>, grid, block, l_mean, s, a);
@@ -1057,14 +1064,15 @@ int launch_split(const GemmArgs& a, bool mean_only, hipStream_t s) {
     const char* ring_env = getenv("LBBNN_GEMM_RING");
     const bool use_ring = ring_env && ring_env[0] == '1';
     const long blocks_ring = (long)((a.O + 79) / 80) * ((a.B + 255) / 256);
-    if (blocks_ring >= 128 && use_ring) {
+    if (blocks_ring >= 128 && use_ring && !a.kchunk) {
         // 256 x 80 tiles, one 8-wave workgroup per CU, 3-buffer LDS ring
         dim3 grid((a.O + 79) / 80, (a.B + 255) / 256), block(512);
         if (mean_only) return launch_one(lrt_gemm_bf16x3_ring_kernel<5, true>, grid, block, 3u * (256 * 128 + 2 * 80 * 64), s, a);
         return launch_one(lrt_gemm_bf16x3_ring_kernel<5, false>, grid, block, 3u * (256 * 128 + 4 * 80 * 64), s, a);
     }
-    const long blocks_big = (long)((a.O + 79) / 80) * ((a.B + 127) / 128);
-    if (blocks_big >= 256) return launch_split_cfg<5, 2, 4>(a, mean_only, s);
+    const long nz = a.kchunk ? (a.I + a.kchunk - 1) / a.kchunk : 1;
+    const long blocks_big = (long)((a.O + 79) / 80) * ((a.B + 127) / 128) * nz;
+    if (blocks_big >= 256 && a.B >= 96) return launch_split_cfg<5, 2, 4>(a, mean_only, s);
     return launch_split_cfg<5, 1, 2>(a, mean_only, s);
 }
 
@@ -1073,7 +1081,7 @@ int launch_split(const GemmArgs& a, bool mean_only, hipStream_t s) {
 static int lrt_gemm_impl(const float* x, int ldx, const void* e_w, const void* var_w, int ld,
                          const float* bias_mean, const float* bias_var, const float* var_scale,
                          const float* eps, const uint64_t* rng, uint32_t rng_stream, int64_t row_offset,
-                         float* out, int ldo, float* std_out, int B, int I, int O, int flags, void* stream) {
+                         float* out, int ldo, float* std_out, int B, int I, int O, int flags, void* stream, int kchunk = 0) {
     if (B == 0 && I > 0 && O > 0) return 0;        // empty batch (torch.mm of 0 rows, LBBNN-GP-MF-LRT.py:172): nothing to do
     if (!x || !e_w || !out) return LBBNN_E_NULL;
     if (B <= 0 || I <= 0 || O <= 0 || ldx < I || ldo < O) return LBBNN_E_SHAPE;
@@ -1093,6 +1101,7 @@ static int lrt_gemm_impl(const float* x, int ldx, const void* e_w, const void* v
     a.ldx = ldx; a.ld = ld; a.ldo = ldo; a.B = B; a.I = I; a.O = O;
     a.rng_stream = rng_stream; a.relu = (flags & LBBNN_F_RELU) ? 1 : 0;
     a.log_softmax = (flags & LBBNN_F_LOG_SOFTMAX) ? 1 : 0;
+    a.kchunk = kchunk; a.split_stride = (long long)B * ldo;
 
     const bool xvec = ((I & 3) == 0) && ((ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0);
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1137,4 +1146,12 @@ extern "C" int lbbnn_lrt_gemm_train(const float* x, int ldx, const void* e_w, co
     if ((flags & LBBNN_F_LOG_SOFTMAX) && std_out) return LBBNN_E_FLAGS;
     return lrt_gemm_impl(x, ldx, e_w, var_w, ld, bias_mean, bias_var, var_scale, eps, rng, rng_stream, row_offset,
                          out, ldo, std_out, B, I, O, flags, stream);
+}
+
+// Split-K plain product on the bf16x3 kernel: out[z] = x[:, Kz] . w[:, Kz]^T for the k ranges Kz = [z*kchunk, (z+1)*kchunk).
+extern "C" int lbbnn_matmul_splitk(const float* x, int ldx, const void* w_op, int ld, float* out, int ldo,
+                                   int B, int I, int O, int kchunk, void* stream) {
+    if (kchunk <= 0 || (kchunk & 31)) return LBBNN_E_ALIGN;
+    return lrt_gemm_impl(x, ldx, w_op, nullptr, ld, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0, out, ldo, nullptr,
+                         B, I, O, LBBNN_F_MEAN_ONLY | LBBNN_F_SPLIT16, stream, kchunk);
 }

@@ -83,13 +83,26 @@ __global__ __launch_bounds__(256) void weight_pass_bwd_kernel(const lbbnn_wpb_ar
             float mu[W], rho[W], lam[W], gm[W], gv[W];
             if (W == 4) {
                 const float4 t0 = *reinterpret_cast<const float4*>(a.mu + off), t1 = *reinterpret_cast<const float4*>(a.rho + off);
-                const float4 t2 = *reinterpret_cast<const float4*>(a.lambdal + off), t3 = *reinterpret_cast<const float4*>(a.dWm + off);
-                const float4 t4 = a.dWv ? *reinterpret_cast<const float4*>(a.dWv + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 t2 = *reinterpret_cast<const float4*>(a.lambdal + off);
+                float4 t3 = *reinterpret_cast<const float4*>(a.dWm + off);
+                float4 t4 = a.dWv ? *reinterpret_cast<const float4*>(a.dWv + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int sp = 1; sp < a.nsplit; ++sp) {               // split-K slabs, fixed order
+                    const float4 u3 = *reinterpret_cast<const float4*>(a.dWm + (size_t)sp * a.split_stride + off);
+                    t3.x += u3.x; t3.y += u3.y; t3.z += u3.z; t3.w += u3.w;
+                    if (a.dWv) {
+                        const float4 u4 = *reinterpret_cast<const float4*>(a.dWv + (size_t)sp * a.split_stride + off);
+                        t4.x += u4.x; t4.y += u4.y; t4.z += u4.z; t4.w += u4.w;
+                    }
+                }
                 mu[0] = t0.x; mu[1] = t0.y; mu[2] = t0.z; mu[3] = t0.w;  rho[0] = t1.x; rho[1] = t1.y; rho[2] = t1.z; rho[3] = t1.w;
                 lam[0] = t2.x; lam[1] = t2.y; lam[2] = t2.z; lam[3] = t2.w;  gm[0] = t3.x; gm[1] = t3.y; gm[2] = t3.z; gm[3] = t3.w;
                 gv[0] = t4.x; gv[1] = t4.y; gv[2] = t4.z; gv[3] = t4.w;
             } else {
                 mu[0] = a.mu[off]; rho[0] = a.rho[off]; lam[0] = a.lambdal[off]; gm[0] = a.dWm[off]; gv[0] = a.dWv ? a.dWv[off] : 0.f;
+                for (int sp = 1; sp < a.nsplit; ++sp) {
+                    gm[0] += a.dWm[(size_t)sp * a.split_stride + off];
+                    if (a.dWv) gv[0] += a.dWv[(size_t)sp * a.split_stride + off];
+                }
             }
             float dm[W], dr[W], dl[W];
 #pragma unroll
@@ -152,7 +165,8 @@ extern "C" int lbbnn_weight_pass_backward(const lbbnn_wpb_args_t* p, void* strea
     if (!p) return LBBNN_E_NULL;
     const lbbnn_wpb_args_t& a = *p;
     if (!a.mu || !a.rho || !a.lambdal || !a.dWm || !a.dmu || !a.drho || !a.dlambdal || !a.work) return LBBNN_E_NULL;
-    if (a.O <= 0 || a.I <= 0) return LBBNN_E_SHAPE;
+    if (a.O <= 0 || a.I <= 0 || a.nsplit < 0) return LBBNN_E_SHAPE;
+    if (a.nsplit > 1 && (a.split_stride < (int64_t)a.O * a.I || (a.split_stride & 3))) return LBBNN_E_ALIGN;
     if ((a.da_mu == nullptr) != (a.da_var == nullptr)) return LBBNN_E_NULL;
     if (a.da_mu && (!a.z_kl || !a.r0_c)) return LBBNN_E_NULL;
     hipStream_t s = static_cast<hipStream_t>(stream);

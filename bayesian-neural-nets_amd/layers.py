@@ -119,8 +119,8 @@ class _BayesLinearFn(torch.autograd.Function):
             gx = _hip_matmul_nt(g, ops.transpose_operand, bw[0][:, :I])
             if stochastic:
                 gx = ops.dx_combine(gx, _hip_matmul_nt(g_v, ops.transpose_operand, bw[1][:, :I]), x)
-        dWm = _hip_matmul_nt(gT, ops.transpose_operand, x)
-        dWv = _hip_matmul_nt(g_vT, ops.transpose_operand, x, square=True) if stochastic else None
+        dWm = _hip_matmul_nt(gT, ops.transpose_operand, x, allow_splitk=True)
+        dWv = _hip_matmul_nt(g_vT, ops.transpose_operand, x, square=True, allow_splitk=True) if stochastic else None
         # ---- K1b: the whole (O,I) chain in one pass
         dmu, drho, dlam, dz_k, dz2, dr0c = ops.weight_pass_backward(
             mu, rho, lam, dWm, dWv, z_fwd=z_k, z_kl=z2, r0_c=r0_c, da_mu=da_mu, da_var=da_var, g_kl=g_kl,
@@ -154,15 +154,23 @@ class _BayesLinearFn(torch.autograd.Function):
         return (None, gx, None, dmu, drho, dlam, *vgrads)
 
 
-def _hip_matmul_nt(a, transpose_fn, w, square=False):
+def _hip_matmul_nt(a, transpose_fn, w, square=False, allow_splitk=False):
     """a (M,K) @ f(w) (K,N) with f = identity or square, through lbbnn_lrt_gemm (mean-only):
-    the operand is f(w)^T = [N][ld(K)], built by lbbnn_transpose_operand."""
+    the operand is f(w)^T = [N][ld(K)], built by lbbnn_transpose_operand.  With ``allow_splitk`` a long contraction
+    with few output tiles (the weight gradients: K = batch) is cut into k ranges that fill the chip; the result is
+    then (S,M,N) slabs for the consumer (lbbnn_weight_pass_backward) to add."""
     M, K = a.shape
     N = w.shape[1]
     assert w.shape[0] == K
     split = (ops.get_precision() == "bf16x3" and ops.split_eligible(K, N)
              and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0)
     op = transpose_fn(w if w.stride(1) == 1 else w.contiguous(), square=square, split=split)
+    if allow_splitk and split and K >= 1024:
+        tiles = ((N + 79) // 80) * ((M + 127) // 128 if M >= 96 else (M + 31) // 32)
+        S = max(1, min(16, (400 + tiles - 1) // tiles, K // 256))
+        if S > 1:
+            kchunk = ((K + S - 1) // S + 31) // 32 * 32
+            return ops.matmul_splitk(a, op, K=K, N=N, kchunk=kchunk)
     return ops.lrt_gemm(a, op, None, I=K, O=N, mean_only=True, split=split)
 
 
@@ -616,12 +624,11 @@ class MNFBayesianLinear(_BayesLinearBase):
 class _NetworkBase(nn.Module):
     """3-layer MLP of Bayesian layers: ReLU, ReLU, log_softmax (LBBNN-GP-MF-LRT.py:206-214).
 
-    Without autograd the forward is scheduled across two HIP streams: everything that does not
-    depend on the activations (flows, weight passes, KL finalisation of ALL layers) runs on a side
-    stream, so the critical path is only  [prep of layer 1] -> GEMM1 -> GEMM2 -> GEMM3  with ReLU /
-    log_softmax fused into the GEMM epilogues; the three layers share one RNG offset (their Philox
-    streams differ by layer id) and the offset is advanced once per forward.  The multi-stream
-    sequence contains no host synchronisation and is HIP-graph capturable.
+    Without autograd the forward is ONE stream and 7 launches (``_forward_streams``): the x-independent kernels of
+    all layers batched into one launch per kind (flows, weight pass, KL finalize), the three GEMMs with ReLU /
+    log_softmax fused into their epilogues, and one finish kernel (KL total, RNG offset += 1).  The three layers
+    share one RNG offset (their Philox streams differ by layer id).  No host synchronisation: HIP-graph capturable.
+    With autograd each layer goes through ``_BayesLinearFn`` (HIP forward + HIP backward).
     """
     _kl_total = None
 

@@ -180,6 +180,18 @@ def output_grad(g_out, *, out=None, std=None, eps=None, rng=None, rng_stream: in
     return gm, gv, gmT, gvT, g_sum, gv_sum
 
 
+def matmul_splitk(a, w_op, *, K: int, N: int, kchunk: int):
+    """lbbnn_matmul_splitk: slabs out[z] = a[:, Kz] @ w[Kz, :] (w given as its bf16x3 operand [N][ld(K)]);
+    returns (S, M, N) with S = ceil(K / kchunk)."""
+    M = a.shape[0]
+    S = (K + kchunk - 1) // kchunk
+    out = torch.empty((S, M, N), dtype=torch.float32, device=a.device)
+    rc = _lib.lib().lbbnn_matmul_splitk(_ptr_rows(a, "a"), a.stride(0), _ptr(w_op), operand_ld(K), out.data_ptr(), N,
+                                        M, K, N, kchunk, _stream())
+    _lib.check(rc, "lbbnn_matmul_splitk")
+    return out
+
+
 def dx_combine(gx, gxv, x):
     """lbbnn_dx_combine: gx += 2 * x * gxv in place (gx, gxv dense (B,I); x may have a row stride)."""
     B, I = gx.shape
@@ -195,9 +207,11 @@ def weight_pass_backward(mu, rho, lambdal, dWm, dWv=None, *, z_fwd=None, z_kl=No
     O, I = mu.shape
     a = _lib.WpbArgs()
     a.mu, a.rho, a.lambdal = _ptr(mu, "weight_mu"), _ptr(rho, "weight_rho"), _ptr(lambdal, "lambdal")
+    nsplit = dWm.shape[0] if dWm.dim() == 3 else 1           # (S,O,I): split-K slabs, added inside the kernel
     for t, name in ((dWm, "dWm"), (dWv, "dWv")):
-        if t is not None and (t.shape != mu.shape or not t.is_contiguous()):
-            raise ValueError("bnn_amd: %s must be a contiguous (O,I) tensor" % name)
+        if t is not None and (tuple(t.shape[-2:]) != tuple(mu.shape) or not t.is_contiguous()
+                              or (t.shape[0] if t.dim() == 3 else 1) != nsplit):
+            raise ValueError("bnn_amd: %s must be a contiguous (O,I) or (S,O,I) tensor" % name)
     a.dWm, a.dWv = _ptr(dWm, "dWm"), _ptr(dWv)
     a.z_fwd, a.z_kl, a.r0_c = _ptr(z_fwd), _ptr(z_kl), _ptr(r0_c)
     a.da_mu, a.da_var, a.g_kl = _ptr(da_mu), _ptr(da_var), _ptr(g_kl)
@@ -213,6 +227,7 @@ def weight_pass_backward(mu, rho, lambdal, dWm, dWv=None, *, z_fwd=None, z_kl=No
     a.dmu, a.drho, a.dlambdal = dmu.data_ptr(), drho.data_ptr(), dlam.data_ptr()
     a.dz_fwd, a.dz_kl, a.dr0_c, a.work = _ptr(dz_fwd), _ptr(dz_kl), _ptr(dr0_c), work.data_ptr()
     a.O, a.I = O, I
+    a.nsplit, a.split_stride = nsplit, O * I
     _lib.check(_lib.lib().lbbnn_weight_pass_backward(ctypes.byref(a), _stream()), "lbbnn_weight_pass_backward")
     return dmu, drho, dlam, dz_fwd, dz_kl, dr0_c
 

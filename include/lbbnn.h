@@ -326,6 +326,8 @@ typedef struct lbbnn_wpb_args {
     float *dz_fwd, *dz_kl, *dr0_c;                        /* (I) outputs or NULL                             */
     float *work;
     int O, I;
+    int nsplit;                                           /* dWm / dWv are nsplit slabs of (O,I), added here; 0 or 1 = plain */
+    int64_t split_stride;                                 /* floats between slabs                                            */
 } lbbnn_wpb_args_t;
 
 int64_t lbbnn_weight_pass_backward_workspace(int O, int I);
@@ -461,6 +463,15 @@ typedef struct lbbnn_adam_list {
 
 int lbbnn_adam_step(const lbbnn_adam_list_t* list, float lr, float beta1, float beta2, float eps, float weight_decay,
                     float* step, int advance, void* stream);
+
+/* lbbnn_matmul_splitk -- split-K form of the mean-only bf16x3 product for long contractions with few output tiles
+ * (the weight gradients dW = G^T.x: K = batch):  out[z] (B,O; row stride ldo; slab stride B*ldo) =
+ * x[:, Kz] . w[:, Kz]^T with Kz = [z*kchunk, min(I, (z+1)*kchunk)), z < ceil(I / kchunk); kchunk a multiple of 32.
+ * w_op: LBBNN_F_SPLIT16 operand planes of lbbnn_transpose_operand / lbbnn_weight_pass.  The consumer adds the slabs
+ * (lbbnn_weight_pass_backward does, in a fixed order => deterministic).
+ */
+int lbbnn_matmul_splitk(const float* x, int ldx, const void* w_op, int ld, float* out, int ldo,
+                        int B, int I, int O, int kchunk, void* stream);
 
 #ifdef __cplusplus
 }

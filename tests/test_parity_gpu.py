@@ -1049,3 +1049,21 @@ def test_training_with_fused_adam_decreases_loss(bnn, dev):
         opt.step()
         losses.append(float(loss.detach()))
     assert losses[-1] < losses[0] and all(math.isfinite(v) for v in losses)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N,kchunk", [(10, 4096, 1200, 256), (1200, 4096, 784, 1376), (130, 1000, 96, 320), (33, 2048, 40, 2048)])
+def test_matmul_splitk_slabs_sum_to_product(bnn, dev, M, K, N, kchunk):
+    """lbbnn_matmul_splitk: the k-range slabs add up to a @ w (fp64 reference), incl. a K tail in the last slab."""
+    from bnn_amd import ops
+    g = torch.Generator().manual_seed(M + K + N)
+    a = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(K, N, generator=g) * 0.1).to(dev)
+    op = ops.transpose_operand(w, split=True)
+    slabs = ops.matmul_splitk(a, op, K=K, N=N, kchunk=kchunk)
+    assert slabs.shape == ((K + kchunk - 1) // kchunk, M, N)
+    ref = a.double().cpu() @ w.double().cpu()
+    assert rel_err(slabs.sum(0).cpu().double(), ref) < 2e-5
+    # each slab is the product over its own k range
+    ref0 = a[:, :kchunk].double().cpu() @ w[:kchunk].double().cpu()
+    assert rel_err(slabs[0].cpu().double(), ref0) < 2e-5
