@@ -1,5 +1,5 @@
 // K1b -- analytic backward of the fused weight pass (see include/lbbnn.h).  HBM-bound: 20 B read + 12 B
-// written per weight.  A 256-thread workgroup owns RB = 8 consecutive rows; a thread owns one column group
+// written per weight.  A 256-thread workgroup owns 64 column groups x RB = 16 rows (see the kernel comment): every
 // (4 columns, or 1 on the unaligned path) at a time and walks the 8 rows, so every global access is a
 // coalesced row segment and the three column sums (dz_fwd, dz_kl, dr0_c) accumulate in registers; the
 // per-row-block partials are reduced in a fixed order by a second launch (deterministic, no float atomics).
@@ -10,7 +10,7 @@
 namespace {
 
 using namespace lbbnn;
-constexpr int RB = 8;
+constexpr int RB = 16;
 
 struct Consts { float mp, inv_sp2, log_sp, log_ap, log_1map, gk; };
 
@@ -51,9 +51,15 @@ __device__ __forceinline__ void elem_bwd(float mu, float rho, float lam, float g
     dlam = Gal * alpha * (1.f - alpha);
 }
 
+// Workgroup = 64 column groups (of W columns) x 4 row lanes, RB = 16 rows: thread (cg, rl) walks rows rl, rl+4, ...
+// of its column group (a wave reads 64 x 16 B = 1 KiB of one row), keeps the three column sums in registers, and
+// the 4 row lanes are added through LDS in a fixed order.  Grid = (column blocks, row blocks): 5 x 75 workgroups
+// for 1200 x 1200 -- the first version (one workgroup per 8 full rows) had 150 workgroups for 256 CUs and an
+// 85 %-idle second loop trip.
 template <int W>
 __global__ __launch_bounds__(256) void weight_pass_bwd_kernel(const lbbnn_wpb_args_t a, int nblk, int ldw) {
-    const int rb = blockIdx.x, tid = threadIdx.x;
+    __shared__ float red[3][4][64 * W];
+    const int rb = blockIdx.y, tid = threadIdx.x, cg = tid & 63, rl = tid >> 6;
     const int r0 = rb * RB, r1 = min(r0 + RB, a.O);
     Consts c;
     c.mp = a.priors.mu_prior;
@@ -61,23 +67,20 @@ __global__ __launch_bounds__(256) void weight_pass_bwd_kernel(const lbbnn_wpb_ar
     c.log_sp = logf(a.priors.sigma_prior); c.log_ap = logf(a.priors.alpha_prior); c.log_1map = logf(1.f - a.priors.alpha_prior);
     const bool has_kl = a.g_kl != nullptr, has_act = a.da_mu != nullptr;
     c.gk = has_kl ? a.g_kl[0] : 0.f;
-    float* const p_zf = a.work + (size_t)rb * 3 * ldw;
-    float* const p_zk = p_zf + ldw;
-    float* const p_rc = p_zk + ldw;
-    const int ngroups = (a.I + W - 1) / W;
-    for (int j = tid; j < ngroups; j += 256) {
-        const int i0 = j * W;
-        float zf[W], zk[W], rc[W], szf[W], szk[W], src[W];
+    const int i0 = (blockIdx.x * 64 + cg) * W;
+    const bool live = i0 < a.I;
+    float zf[W], zk[W], rc[W], szf[W], szk[W], src[W];
 #pragma unroll
-        for (int k = 0; k < W; ++k) {
-            const int i = i0 + k;
-            const bool in = i < a.I;
-            zf[k] = (a.z_fwd && in) ? a.z_fwd[i] : 1.f;
-            zk[k] = (a.z_kl && in) ? a.z_kl[i] : 1.f;
-            rc[k] = (a.r0_c && in) ? a.r0_c[i] : 0.f;
-            szf[k] = szk[k] = src[k] = 0.f;
-        }
-        for (int r = r0; r < r1; ++r) {
+    for (int k = 0; k < W; ++k) {
+        const int i = i0 + k;
+        const bool in = i < a.I;
+        zf[k] = (a.z_fwd && in) ? a.z_fwd[i] : 1.f;
+        zk[k] = (a.z_kl && in) ? a.z_kl[i] : 1.f;
+        rc[k] = (a.r0_c && in) ? a.r0_c[i] : 0.f;
+        szf[k] = szk[k] = src[k] = 0.f;
+    }
+    if (live)
+        for (int r = r0 + rl; r < r1; r += 4) {
             const size_t off = (size_t)r * a.I + i0;
             const float dam = has_act ? a.da_mu[r] : 0.f, dav = has_act ? a.da_var[r] : 0.f;
             float mu[W], rho[W], lam[W], gm[W], gv[W];
@@ -120,10 +123,16 @@ __global__ __launch_bounds__(256) void weight_pass_bwd_kernel(const lbbnn_wpb_ar
                 a.dmu[off] = dm[0]; a.drho[off] = dr[0]; a.dlambdal[off] = dl[0];
             }
         }
+    // column sums of this workgroup's 16 rows: row lanes 0..3 added in order
+#pragma unroll
+    for (int k = 0; k < W; ++k) { red[0][rl][cg * W + k] = szf[k]; red[1][rl][cg * W + k] = szk[k]; red[2][rl][cg * W + k] = src[k]; }
+    __syncthreads();
+    if (rl < 3 && live) {
+        float* const dst = a.work + ((size_t)rb * 3 + rl) * ldw;
 #pragma unroll
         for (int k = 0; k < W; ++k) {
             const int i = i0 + k;
-            if (i < a.I) { p_zf[i] = szf[k]; p_zk[i] = szk[k]; p_rc[i] = src[k]; }
+            if (i < a.I) dst[i] = ((red[rl][0][cg * W + k] + red[rl][1][cg * W + k]) + red[rl][2][cg * W + k]) + red[rl][3][cg * W + k];
         }
     }
 }
@@ -174,8 +183,8 @@ extern "C" int lbbnn_weight_pass_backward(const lbbnn_wpb_args_t* p, void* strea
     const int ldw = (a.I + 3) & ~3;
     const bool vec = (a.I % 4 == 0) && al16(a.mu) && al16(a.rho) && al16(a.lambdal) && al16(a.dWm) &&
                      (!a.dWv || al16(a.dWv)) && al16(a.dmu) && al16(a.drho) && al16(a.dlambdal);
-    if (vec) hipLaunchKernelGGL(weight_pass_bwd_kernel<4>, dim3(nblk), dim3(256), 0, s, a, nblk, ldw);
-    else     hipLaunchKernelGGL(weight_pass_bwd_kernel<1>, dim3(nblk), dim3(256), 0, s, a, nblk, ldw);
+    if (vec) hipLaunchKernelGGL(weight_pass_bwd_kernel<4>, dim3((a.I / 4 + 63) / 64, nblk), dim3(256), 0, s, a, nblk, ldw);
+    else     hipLaunchKernelGGL(weight_pass_bwd_kernel<1>, dim3((a.I + 63) / 64, nblk), dim3(256), 0, s, a, nblk, ldw);
     if (a.dz_fwd || a.dz_kl || a.dr0_c)
         hipLaunchKernelGGL(wpb_reduce_kernel, dim3((a.I + 63) / 64), dim3(1024), 0, s, a.work, nblk, ldw, a.I,
                            a.dz_fwd, a.dz_kl, a.dr0_c);
