@@ -1,8 +1,8 @@
 // K1b -- analytic backward of the fused weight pass (see include/lbbnn.h).  HBM-bound: 20 B read + 12 B
-// written per weight.  A 256-thread workgroup owns 64 column groups x RB = 16 rows (see the kernel comment): every
-// (4 columns, or 1 on the unaligned path) at a time and walks the 8 rows, so every global access is a
-// coalesced row segment and the three column sums (dz_fwd, dz_kl, dr0_c) accumulate in registers; the
-// per-row-block partials are reduced in a fixed order by a second launch (deterministic, no float atomics).
+// written per weight.  A 256-thread workgroup owns 64 column groups (4 columns each, or 1 on the unaligned path) x
+// RB = 16 rows: every global access is a coalesced row segment, the three column sums (dz_fwd, dz_kl, dr0_c)
+// accumulate in registers, and the per-row-block partials are reduced in a fixed order by a second launch
+// (deterministic, no float atomics).
 #include <cmath>
 #include "lbbnn_device.h"
 #include "lbbnn_internal.h"
