@@ -109,7 +109,8 @@ class FlowBwdArgs(ctypes.Structure):
                                    "dz_fwd", "dz_kl", "g_kl", "bias_mu", "bias_rho", "g_sum", "gv_sum")] + \
                [("z_flow", PlanarFlow), ("r_flow", PlanarFlow), ("priors", Priors)] + \
                [(n, c_p) for n in ("d_q0_mean", "d_q0_log_var", "d_r0_b1", "d_r0_b2", "d_bias_mu", "d_bias_rho")] + \
-               [("d_z_flow", PlanarGrad), ("d_r_flow", PlanarGrad), ("work", c_p), ("O", c_i), ("I", c_i)]
+               [("d_z_flow", PlanarGrad), ("d_r_flow", PlanarGrad), ("work", c_p), ("O", c_i), ("I", c_i),
+                ("rng", c_p), ("layer_id", c_u32)]
 
 
 # name -> (restype, argtypes); must list every symbol include/lbbnn.h declares
@@ -133,7 +134,7 @@ SIGNATURES = {
     "lbbnn_output_grad_workspace": (c_i64, [c_i, c_i]),
     "lbbnn_output_grad": (c_i, [ctypes.POINTER(OutGradArgs), c_p]),
     "lbbnn_flow_chain": (c_i, [ctypes.POINTER(FlowChain), c_p, c_p, c_p, c_p, c_p, c_u32, c_i, c_p, c_p, c_p, c_p, c_p]),
-    "lbbnn_mnf_aux_backward": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
+    "lbbnn_mnf_aux_backward": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_u32, c_p]),
     "lbbnn_mnf_flow_backward_workspace": (c_i64, [c_i, c_i, c_i]),
     "lbbnn_mnf_flow_planar_backward": (c_i, [ctypes.POINTER(FlowBwdArgs), c_p]),
     "lbbnn_mnf_flow_planar": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p,

@@ -26,11 +26,20 @@ __device__ __forceinline__ void bsum3(double& a, double& b, double& c, double* s
 __global__ __launch_bounds__(NT) void mnf_aux_backward_kernel(const float* __restrict__ act_mu, const float* __restrict__ act_var,
                                                               const float* __restrict__ eps_act, const float* __restrict__ b1,
                                                               const float* __restrict__ b2, const float* zb_last, const float* g_kl,
-                                                              int O, int I, float* da_mu, float* da_var, float* aux) {
+                                                              int O, int I, float* da_mu, float* da_var, float* aux,
+                                                              const uint64_t* rng, uint32_t layer) {
     __shared__ double scratch[3 * NWV];
     const int tid = threadIdx.x;
+    uint64_t seed = 0, offs = 0;
+    if (!eps_act) { seed = rng[0]; offs = rng[1]; }
+    auto eps_at = [&](int o) -> float {
+        if (eps_act) return eps_act[o];
+        float n[4];
+        philox_normal4(seed, offs, LBBNN_STREAM_EPS_ACT * 64u + layer, (uint64_t)(o >> 2), 0u, n);
+        return n[o & 3];
+    };
     double s_act = 0, z0 = 0, z1 = 0;
-    for (int o = tid; o < O; o += NT) s_act += (double)tanhf(act_mu[o] + sqrtf(act_var[o]) * eps_act[o]);
+    for (int o = tid; o < O; o += NT) s_act += (double)tanhf(act_mu[o] + sqrtf(act_var[o]) * eps_at(o));
     bsum3(s_act, z0, z1, scratch);
     const float m = (float)(s_act / (double)O);
     const float zb = zb_last[0];
@@ -42,11 +51,11 @@ __global__ __launch_bounds__(NT) void mnf_aux_backward_kernel(const float* __res
     bsum3(S, z0, z1, scratch);
     const float cm = g_kl[0] * (float)(-S) / (float)O;          // kl = ... - log_rb  =>  dkl/dm = -S
     for (int o = tid; o < O; o += NT) {
-        const float sd = sqrtf(act_var[o]);
-        const float a = tanhf(act_mu[o] + sd * eps_act[o]);
+        const float sd = sqrtf(act_var[o]), e = eps_at(o);
+        const float a = tanhf(act_mu[o] + sd * e);
         const float d = cm * (1.f - a * a);
         da_mu[o] = d;
-        da_var[o] = d * eps_act[o] / (2.f * sd);
+        da_var[o] = d * e / (2.f * sd);
     }
     if (tid == 0) aux[0] = m;
 }
@@ -80,11 +89,24 @@ __global__ __launch_bounds__(NT) void mnf_flow_planar_backward_kernel(const lbbn
         a.d_bias_mu[o] = gm;
         a.d_bias_rho[o] = gs * dsig;
     }
-    // ---- forward: z0 draws, z flow on both draws
+    // ---- forward: z0 draws, z flow on both draws (draws explicit, or re-created from the forward's Philox state;
+    // kept in DK / DF until the backward sweeps overwrite them, read back at the very end from EF / EK)
+    uint64_t seed = 0, offs = 0;
+    if (!a.eps_fwd) { seed = a.rng[0]; offs = a.rng[1]; }
+    float* const EF = DF + I;
+    float* const EK = EF + I;
     for (int i = tid; i < I; i += NT) {
+        float ef, ek = 0.f;
+        if (a.eps_fwd) { ef = a.eps_fwd[i]; if (has_kl) ek = a.eps_kl[i]; }
+        else {
+            float n[4];
+            philox_normal4(seed, offs, LBBNN_STREAM_EPS_Z * 64u + a.layer_id, (uint64_t)(i >> 2), 0u, n); ef = n[i & 3];
+            if (has_kl) { philox_normal4(seed, offs, LBBNN_STREAM_EPS_Z2 * 64u + a.layer_id, (uint64_t)(i >> 2), 0u, n); ek = n[i & 3]; }
+        }
+        EF[i] = ef; EK[i] = ek;
         const float sd = expf(0.5f * a.q0_log_var[i]);
-        ZF[i] = a.q0_mean[i] + sd * a.eps_fwd[i];
-        if (has_kl) ZK[i] = a.q0_mean[i] + sd * a.eps_kl[i];
+        ZF[i] = a.q0_mean[i] + sd * ef;
+        if (has_kl) ZK[i] = a.q0_mean[i] + sd * ek;
     }
     for (int t = 0; t < Tz; ++t) {
         const float *u = a.z_flow.u[t], *w = a.z_flow.w[t];
@@ -189,9 +211,8 @@ __global__ __launch_bounds__(NT) void mnf_flow_planar_backward_kernel(const lbbn
     // ---- q0 (LBBNN-GP-MF-MNF.py:183-185, 201-205): dlog_q0/dlog_var = -1/2 exactly, dlog_q0/dmean = 0
     for (int i = tid; i < I; i += NT) {
         const float sd = expf(0.5f * a.q0_log_var[i]);
-        const float ek = has_kl ? a.eps_kl[i] : 0.f;
         a.d_q0_mean[i] = DK[i] + DF[i];
-        a.d_q0_log_var[i] = 0.5f * sd * (DK[i] * ek + DF[i] * a.eps_fwd[i]) - 0.5f * G;
+        a.d_q0_log_var[i] = 0.5f * sd * (DK[i] * EK[i] + DF[i] * EF[i]) - 0.5f * G;
     }
 }
 
@@ -199,25 +220,27 @@ __global__ __launch_bounds__(NT) void mnf_flow_planar_backward_kernel(const lbbn
 
 extern "C" int lbbnn_mnf_aux_backward(const float* act_mu, const float* act_var, const float* eps_act, const float* r0_b1,
                                       const float* r0_b2, const float* zb_last, const float* g_kl, int O, int I,
-                                      float* da_mu, float* da_var, float* aux, void* stream) {
-    if (!act_mu || !act_var || !eps_act || !r0_b1 || !r0_b2 || !zb_last || !g_kl || !da_mu || !da_var || !aux) return LBBNN_E_NULL;
+                                      float* da_mu, float* da_var, float* aux, const uint64_t* rng, uint32_t layer_id, void* stream) {
+    if (!act_mu || !act_var || !r0_b1 || !r0_b2 || !zb_last || !g_kl || !da_mu || !da_var || !aux) return LBBNN_E_NULL;
+    if (!eps_act && !rng) return LBBNN_E_NOISE;
     if (O <= 0 || I <= 0) return LBBNN_E_SHAPE;
     hipLaunchKernelGGL(mnf_aux_backward_kernel, dim3(1), dim3(NT), 0, static_cast<hipStream_t>(stream), act_mu, act_var, eps_act,
-                       r0_b1, r0_b2, zb_last, g_kl, O, I, da_mu, da_var, aux);
+                       r0_b1, r0_b2, zb_last, g_kl, O, I, da_mu, da_var, aux, rng, layer_id & 63u);
     return (int)hipGetLastError();
 }
 
 extern "C" int64_t lbbnn_mnf_flow_backward_workspace(int I, int Tz, int Tr) {
     if (I <= 0 || Tz < 0 || Tr < 0) return 0;
-    return (int64_t)I * (2 * (Tz + 1) + Tr + 2);
+    return (int64_t)I * (2 * (Tz + 1) + Tr + 4);
 }
 
 extern "C" int lbbnn_mnf_flow_planar_backward(const lbbnn_flow_bwd_args_t* p, void* stream) {
     if (!p) return LBBNN_E_NULL;
     const lbbnn_flow_bwd_args_t& a = *p;
-    if (!a.q0_mean || !a.q0_log_var || !a.eps_fwd || !a.bias_mu || !a.bias_rho || !a.g_sum || !a.work ||
+    if (!a.eps_fwd && !a.rng) return LBBNN_E_NOISE;
+    if (!a.q0_mean || !a.q0_log_var || !a.bias_mu || !a.bias_rho || !a.g_sum || !a.work ||
         !a.d_q0_mean || !a.d_q0_log_var || !a.d_r0_b1 || !a.d_r0_b2 || !a.d_bias_mu || !a.d_bias_rho) return LBBNN_E_NULL;
-    if (a.g_kl && (!a.eps_kl || !a.r0_b1 || !a.r0_b2 || !a.aux)) return LBBNN_E_NULL;
+    if (a.g_kl && ((a.eps_fwd && !a.eps_kl) || !a.r0_b1 || !a.r0_b2 || !a.aux)) return LBBNN_E_NULL;
     if (a.O <= 0 || a.I <= 0) return LBBNN_E_SHAPE;
     if (a.z_flow.T < 0 || a.z_flow.T > LBBNN_MAX_FLOW_T || a.r_flow.T < 0 || a.r_flow.T > LBBNN_MAX_FLOW_T) return LBBNN_E_SHAPE;
     for (int t = 0; t < a.z_flow.T; ++t)

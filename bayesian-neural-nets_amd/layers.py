@@ -81,8 +81,11 @@ class _BayesLinearFn(torch.autograd.Function):
             g_out, out=out if relu else None, std=std if stochastic else None, eps=explicit.get("eps_out"),
             rng=ctx.saved.get("rng"), rng_stream=ops.STREAM_EPS_OUT * 64 + layer._layer_id, row_offset=layer.row_offset,
             relu=relu)
-        noise = layer._noise_for_backward(ctx.saved, B, need_out=False)
         planar = layer._mnf and layer._check_flows() == "planar"
+        # planar MNF layers re-create their small draws inside V1 / V2; the torch-graph paths need them as tensors
+        rng_snap = ctx.saved.get("rng")
+        in_kernel = planar and not explicit and rng_snap is not None
+        noise = {} if in_kernel else layer._noise_for_backward(ctx.saved, B, need_out=False)
         g_kl = g_kl.contiguous() if want_kl else None
         da_mu = da_var = aux = r0_c = vg = None
         if planar:
@@ -92,8 +95,9 @@ class _BayesLinearFn(torch.autograd.Function):
             z2 = ctx.saved["z_kl"] if want_kl else None
             if want_kl:
                 r0_c = P["r0_c"]
-                da_mu, da_var, aux = ops.mnf_aux_backward(ctx.saved["act_mu"], ctx.saved["act_var"], noise["eps_act"],
-                                                          P["r0_b1"], P["r0_b2"], ctx.saved["scal"][3:4], g_kl)
+                da_mu, da_var, aux = ops.mnf_aux_backward(ctx.saved["act_mu"], ctx.saved["act_var"], noise.get("eps_act"),
+                                                          P["r0_b1"], P["r0_b2"], ctx.saved["scal"][3:4], g_kl,
+                                                          rng=rng_snap, layer_id=layer._layer_id)
         else:
             # ---- vector-sized graph (flows, q/r densities, bias terms) under autograd: O(I + O) work
             with torch.enable_grad():
@@ -128,8 +132,9 @@ class _BayesLinearFn(torch.autograd.Function):
         if planar:
             zp, rp = layer._planar_params_from(params)
             G = ops.mnf_flow_planar_backward(
-                P["q0_mean"], P["q0_log_var"], zp, rp, eps_fwd=noise["eps_z"].contiguous(),
-                eps_kl=noise["eps_z2"].contiguous() if want_kl else None, r0_b1=P["r0_b1"], r0_b2=P["r0_b2"], aux=aux,
+                P["q0_mean"], P["q0_log_var"], zp, rp, eps_fwd=None if in_kernel else noise["eps_z"].contiguous(),
+                eps_kl=noise["eps_z2"].contiguous() if (want_kl and not in_kernel) else None,
+                rng=rng_snap, layer_id=layer._layer_id, r0_b1=P["r0_b1"], r0_b2=P["r0_b2"], aux=aux,
                 dz_fwd=dz_k, dz_kl=dz2, g_kl=g_kl, bias_mu=P["bias_mu"], bias_rho=P["bias_rho"], g_sum=g_sum,
                 gv_sum=gv_sum, priors=layer.priors)
             G["r0_c"] = dr0c if dr0c is not None else torch.zeros_like(P["q0_mean"])

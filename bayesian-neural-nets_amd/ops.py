@@ -348,21 +348,22 @@ def flow_chain(steps, *, I: int, z_in=None, q0_mean=None, q0_log_var=None, eps=N
     return z_out, logdet
 
 
-def mnf_aux_backward(act_mu, act_var, eps_act, r0_b1, r0_b2, zb_last, g_kl):
+def mnf_aux_backward(act_mu, act_var, eps_act, r0_b1, r0_b2, zb_last, g_kl, rng=None, layer_id: int = 0):
     """lbbnn_mnf_aux_backward -> (da_mu, da_var, aux); zb_last: 1-element view of the forward's scal[3]."""
     O, I = act_mu.shape[0], r0_b1.shape[0]
     da_mu, da_var = torch.empty_like(act_mu), torch.empty_like(act_mu)
     aux = torch.empty(4, dtype=torch.float32, device=act_mu.device)
     rc = _lib.lib().lbbnn_mnf_aux_backward(_ptr(act_mu, "act_mu"), _ptr(act_var, "act_var"), _ptr(eps_act, "eps_act"),
                                            _ptr(r0_b1, "r0_b1"), _ptr(r0_b2, "r0_b2"), zb_last.data_ptr(), _ptr(g_kl, "g_kl"),
-                                           O, I, da_mu.data_ptr(), da_var.data_ptr(), aux.data_ptr(), _stream())
+                                           O, I, da_mu.data_ptr(), da_var.data_ptr(), aux.data_ptr(),
+                                           rng.data_ptr() if rng is not None else None, layer_id, _stream())
     _lib.check(rc, "lbbnn_mnf_aux_backward")
     return da_mu, da_var, aux
 
 
-def mnf_flow_planar_backward(q0_mean, q0_log_var, z_params, r_params, *, eps_fwd, eps_kl=None, r0_b1=None, r0_b2=None,
+def mnf_flow_planar_backward(q0_mean, q0_log_var, z_params, r_params, *, eps_fwd=None, eps_kl=None, r0_b1=None, r0_b2=None,
                              aux=None, dz_fwd=None, dz_kl=None, g_kl=None, bias_mu, bias_rho, g_sum, gv_sum=None,
-                             priors: Priors):
+                             priors: Priors, rng=None, layer_id: int = 0):
     """lbbnn_mnf_flow_planar_backward.  Returns a dict: q0_mean, q0_log_var, r0_b1, r0_b2, bias_mu, bias_rho and
     z_flow / r_flow = lists of (du, dw, dbias) per transform."""
     I, O = q0_mean.shape[0], bias_mu.shape[0]
@@ -388,6 +389,7 @@ def mnf_flow_planar_backward(q0_mean, q0_log_var, z_params, r_params, *, eps_fwd
         out[key] = grads
     work = torch.empty(_lib.lib().lbbnn_mnf_flow_backward_workspace(I, len(z_params), len(r_params)), **f)
     a.work, a.O, a.I = work.data_ptr(), O, I
+    a.rng, a.layer_id = (rng.data_ptr() if rng is not None else None), layer_id
     _lib.check(_lib.lib().lbbnn_mnf_flow_planar_backward(ctypes.byref(a), _stream()), "lbbnn_mnf_flow_planar_backward")
     return out
 

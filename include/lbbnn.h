@@ -351,7 +351,8 @@ int lbbnn_log_softmax_rows(const float* in, int ldi, float* out, int ldo, int B,
  * lbbnn_mnf_aux_backward: gradient of the KL wrt the auxiliary activations (LBBNN-GP-MF-MNF.py:211-233).
  *   m = mean_o tanh(act_mu + sqrt(act_var)*eps_act);  kl has -log_rb(m; r0_b1, r0_b2, zb_last);
  *   da_mu = g_kl * dkl/dm / O * (1 - act^2),  da_var = da_mu * eps_act / (2 sqrt(act_var));  aux[0] = m.
- *   zb_last = device pointer to scal[3] of the forward.
+ *   zb_last = device pointer to scal[3] of the forward.  eps_act == NULL: re-created from the Philox state `rng`
+ *   the forward used (stream EPS_ACT of layer_id), as are eps_fwd / eps_kl of the flow backward below.
  *
  * lbbnn_mnf_flow_planar_backward: given dz_fwd / dz_kl (I) from K1b, the upstream g_kl and the column sums of
  *   the output gradients g_sum = sum_b G_m, gv_sum = sum_b G_v (O; gv_sum NULL for a posterior-mean forward), re-runs
@@ -380,11 +381,13 @@ typedef struct lbbnn_flow_bwd_args {
     lbbnn_planar_grad_t d_z_flow, d_r_flow;
     float *work;
     int O, I;
+    const uint64_t* rng;                                     /* eps_fwd / eps_kl == NULL: re-create the forward's draws  */
+    uint32_t layer_id;                                       /*   (Philox streams EPS_Z / EPS_Z2 of this layer id)       */
 } lbbnn_flow_bwd_args_t;
 
 int lbbnn_mnf_aux_backward(const float* act_mu, const float* act_var, const float* eps_act, const float* r0_b1,
                            const float* r0_b2, const float* zb_last, const float* g_kl, int O, int I,
-                           float* da_mu, float* da_var, float* aux, void* stream);
+                           float* da_mu, float* da_var, float* aux, const uint64_t* rng, uint32_t layer_id, void* stream);
 int64_t lbbnn_mnf_flow_backward_workspace(int I, int Tz, int Tr);
 int lbbnn_mnf_flow_planar_backward(const lbbnn_flow_bwd_args_t* args, void* stream);
 

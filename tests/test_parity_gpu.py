@@ -1067,3 +1067,32 @@ def test_matmul_splitk_slabs_sum_to_product(bnn, dev, M, K, N, kchunk):
     # each slab is the product over its own k range
     ref0 = a[:, :kchunk].double().cpu() @ w[:kchunk].double().cpu()
     assert rel_err(slabs[0].cpu().double(), ref0) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("I,O,T", [(96, 40, 2), (1200, 130, 3)])
+def test_backward_in_kernel_noise_equals_injected_noise(bnn, dev, I, O, T):
+    """Planar MNF layer, training mode, no explicit noise: the backward kernels re-create eps_out / eps_z / eps_z2 /
+    eps_act from the forward's Philox state.  Same gradients as a run with those very draws injected as tensors."""
+    from bnn_amd import ops
+    B = 48
+    layer, p, _, x = _mnf_planar_case(bnn, dev, B, I, O, T, seed=3)
+    layer.train()
+    x = x.to(dev)
+    bnn.manual_seed(1234, 7)                     # torch seed too: RngState.get() follows torch.initial_seed()
+    snap = ops.RngState.get(x.device).t.clone()
+    layer.noise = None
+    out_a = layer(x.clone().requires_grad_(True), sample=True)
+    (out_a.pow(2).sum() + layer.kl / 50).backward()
+    grads_a = {n: q.grad.clone() for n, q in layer.named_parameters()}
+    L = layer._layer_id
+    layer.noise = {"eps_out": ops.philox_normal(snap, ops.STREAM_EPS_OUT * 64 + L, B, O, 0),
+                   "eps_z": ops.philox_normal(snap, ops.STREAM_EPS_Z * 64 + L, 0, I),
+                   "eps_z2": ops.philox_normal(snap, ops.STREAM_EPS_Z2 * 64 + L, 0, I),
+                   "eps_act": ops.philox_normal(snap, ops.STREAM_EPS_ACT * 64 + L, 0, O)}
+    layer.zero_grad()
+    out_b = layer(x.clone().requires_grad_(True), sample=True)
+    (out_b.pow(2).sum() + layer.kl / 50).backward()
+    assert torch.equal(out_a, out_b)
+    for n, q in layer.named_parameters():
+        assert rel_err(grads_a[n], q.grad) < 1e-6, n
