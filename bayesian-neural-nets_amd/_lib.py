@@ -145,6 +145,8 @@ SIGNATURES = {
     "lbbnn_kl_finalize": (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p,
                                 ctypes.POINTER(Priors), c_p, c_u32, c_p, c_p, c_i, c_p]),
     "lbbnn_layers_prepare": (c_i, [ctypes.POINTER(LayerDesc), c_i, c_p, c_p]),
+    "lbbnn_layers_operands": (c_i, [ctypes.POINTER(LayerDesc), c_i, c_p, c_p]),
+    "lbbnn_layers_finalize": (c_i, [ctypes.POINTER(LayerDesc), c_i, c_p, ctypes.c_uint64, c_p, c_p]),
     "lbbnn_forward_finish": (c_i, [c_p, c_u64, c_p, c_i, c_p, c_p]),
     "lbbnn_gate_sample": (c_i, [ctypes.POINTER(GateArgs), c_p, c_p]),
     "lbbnn_vd_operands": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),

@@ -60,6 +60,8 @@ LBBNN_HIDDEN int make_weight_pass_args(WeightPassArgs& a, const float* mu, const
                                        int split = 0);
 LBBNN_HIDDEN int launch_weight_pass(const WeightPassArgs* a, int n, hipStream_t s);
 LBBNN_HIDDEN int launch_flow_planar(const FlowArgs* a, int n, hipStream_t s);
+LBBNN_HIDDEN int launch_kl_finalize_all(const FinalizeArgs* a, const int* active, int n, uint64_t* rng, uint64_t advance,
+                                        float* kl_total, hipStream_t s);
 LBBNN_HIDDEN int launch_kl_finalize(const FinalizeArgs* a, int n, hipStream_t s);
 
 }  // namespace lbbnn

@@ -442,6 +442,76 @@ __global__ __launch_bounds__(256) void kl_finalize_lds_kernel(const FinalizeBatc
     }
 }
 
+// K5 of every layer + the network total + the RNG advance in ONE single-workgroup launch at the end of a forward
+// (lbbnn_layers_finalize): thread group g = tid / 256 finalizes layer g exactly as kl_finalize_kernel does; the groups
+// meet at block-wide barriers (every group runs the same barrier sequence), thread 0 adds the layer KLs in layer
+// order and bumps the Philox offset after every group has read it.
+struct FinalizeAllArgs { FinalizeArgs l[LBBNN_MAX_LAYERS]; int active[LBBNN_MAX_LAYERS]; int n; uint64_t* rng; uint64_t advance; float* total; };
+
+__device__ __forceinline__ double group_sum(double v, double (*scr)[4], int g, int lane, int w) {
+    v = wave_sum(v);
+    __syncthreads();                         // protect scr from the previous use
+    if (lane == 0) scr[g][w] = v;
+    __syncthreads();
+    return (scr[g][0] + scr[g][1]) + (scr[g][2] + scr[g][3]);
+}
+
+__global__ __launch_bounds__(LBBNN_MAX_LAYERS * 256) void kl_finalize_all_kernel(const FinalizeAllArgs fa) {
+    __shared__ double scr[LBBNN_MAX_LAYERS][4];
+    __shared__ float s_kl[LBBNN_MAX_LAYERS];
+    const LBBNN_CONST_AS FinalizeAllArgs& A = *kernarg_as<FinalizeAllArgs>();
+    const int g = threadIdx.x >> 8, t = threadIdx.x & 255, lane = t & 63, w = t >> 6;
+    const LBBNN_CONST_AS FinalizeArgs& a = A.l[g];
+    const bool on = g < A.n && A.active[g] != 0;
+    const bool mnf = on && a.scal != nullptr;
+    uint64_t seed = 0, offs = 0;
+    if (mnf && !a.eps_act) { seed = a.rng[0]; offs = a.rng[1]; }
+    double s_rows = 0.0, s_bias = 0.0, s_act = 0.0;
+    if (on)
+        for (int o = t; o < a.O; o += 256) {
+            s_rows += (double)a.kl_rows[o];
+            const float sb = softplus_ref(a.bias_rho[o]);
+            const float d = a.bias_mu[o] - a.bias_mu_prior;
+            const float sp = a.bias_sigma_prior;
+            s_bias += (double)(logf(sp / sb) - 0.5f + (sb * sb + d * d) / (2.f * sp * sp));   // …LRT.py:185-186
+            if (mnf) {
+                float e;
+                if (a.eps_act) e = a.eps_act[o];
+                else { float n[4]; philox_normal4(seed, offs, LBBNN_STREAM_EPS_ACT * 64u + a.layer, (uint64_t)(o >> 2), 0u, n); e = n[o & 3]; }
+                s_act += (double)tanhf(a.act_mu[o] + sqrtf(a.act_var[o]) * e);               // …MNF.py:218-219
+            }
+        }
+    s_rows = group_sum(s_rows, scr, g, lane, w);
+    s_bias = group_sum(s_bias, scr, g, lane, w);
+    s_act = group_sum(s_act, scr, g, lane, w);
+    double kl = s_bias + s_rows;
+    double s_rb = 0.0;
+    if (mnf) {
+        const float m = (float)(s_act / (double)a.O);       // outer(b, act).mean(-1) = b * mean(act)   :220-221
+        const float zb = a.scal[3];
+        for (int i = t; i < a.I; i += 256) {
+            const float mr = a.r0_b1[i] * m, lv = a.r0_b2[i] * m;
+            const float d = zb - mr;
+            s_rb += (double)(-0.5f * 1.1447298858494002f - 0.5f * lv - 0.5f * ((d * d) / expf(lv)));  // :223-224
+        }
+    }
+    s_rb = group_sum(s_rb, scr, g, lane, w);
+    if (mnf) kl += (-(double)a.scal[0] + (double)a.scal[1]) - ((double)a.scal[2] + s_rb);           // :215,:225,:235
+    if (t == 0) {
+        s_kl[g] = on ? (float)kl : 0.f;
+        if (on && a.kl_layer) *a.kl_layer = (float)kl;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (A.total) {
+            float s = 0.f;
+            for (int i = 0; i < A.n; ++i) s += s_kl[i];               // fixed order: l1 + l2 + l3
+            *A.total = s;
+        }
+        if (A.rng && A.advance) A.rng[1] += A.advance;
+    }
+}
+
 // -------------------------------------------------------------------------------------------- utilities
 __global__ void rng_advance_kernel(uint64_t* rng, uint64_t delta) { rng[1] += delta; }
 
@@ -532,6 +602,15 @@ int launch_flow_planar(const FlowArgs* a, int n, hipStream_t s) {
     } else {
         hipLaunchKernelGGL(mnf_flow_planar_kernel, grid, block, (size_t)maxI * sizeof(float), s, bt);
     }
+    return (int)hipGetLastError();
+}
+
+int launch_kl_finalize_all(const FinalizeArgs* a, const int* active, int n, uint64_t* rng, uint64_t advance, float* kl_total,
+                           hipStream_t s) {
+    FinalizeAllArgs fa;
+    for (int i = 0; i < LBBNN_MAX_LAYERS; ++i) { fa.l[i] = i < n ? a[i] : FinalizeArgs{}; fa.active[i] = i < n ? active[i] : 0; }
+    fa.n = n; fa.rng = rng; fa.advance = advance; fa.total = kl_total;
+    hipLaunchKernelGGL(kl_finalize_all_kernel, dim3(1), dim3(n * 256), 0, s, fa);
     return (int)hipGetLastError();
 }
 

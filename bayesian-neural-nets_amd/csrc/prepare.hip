@@ -5,7 +5,7 @@
 
 using namespace lbbnn;
 
-extern "C" int lbbnn_layers_prepare(const lbbnn_layer_desc_t* L, int n, const uint64_t* rng, void* stream) {
+static int layers_prepare_impl(const lbbnn_layer_desc_t* L, int n, const uint64_t* rng, void* stream, bool with_k5) {
     if (!L) return LBBNN_E_NULL;
     if (n <= 0 || n > LBBNN_MAX_LAYERS) return LBBNN_E_SHAPE;
     FlowArgs fa[LBBNN_MAX_LAYERS];
@@ -53,6 +53,40 @@ extern "C" int lbbnn_layers_prepare(const lbbnn_layer_desc_t* L, int n, const ui
     int rc = 0;
     if (nf) { rc = launch_flow_planar(fa, nf, s); if (rc) return rc; }
     rc = launch_weight_pass(wa, n, s); if (rc) return rc;
-    if (nk) { rc = launch_kl_finalize(ka, nk, s); if (rc) return rc; }
+    if (nk && with_k5) { rc = launch_kl_finalize(ka, nk, s); if (rc) return rc; }
     return 0;
+}
+
+extern "C" int lbbnn_layers_prepare(const lbbnn_layer_desc_t* L, int n, const uint64_t* rng, void* stream) {
+    return layers_prepare_impl(L, n, rng, stream, true);
+}
+
+extern "C" int lbbnn_layers_operands(const lbbnn_layer_desc_t* L, int n, const uint64_t* rng, void* stream) {
+    return layers_prepare_impl(L, n, rng, stream, false);
+}
+
+extern "C" int lbbnn_layers_finalize(const lbbnn_layer_desc_t* L, int n, uint64_t* rng, uint64_t advance, float* kl_total,
+                                     void* stream) {
+    if (!L) return LBBNN_E_NULL;
+    if (n <= 0 || n > LBBNN_MAX_LAYERS) return LBBNN_E_SHAPE;
+    FinalizeArgs ka[LBBNN_MAX_LAYERS];
+    int active[LBBNN_MAX_LAYERS];
+    for (int i = 0; i < n; ++i) {
+        const lbbnn_layer_desc_t& d = L[i];
+        const bool mnf = d.q0_mean != nullptr;
+        active[i] = d.want_kl ? 1 : 0;
+        FinalizeArgs& k = ka[i];
+        k = FinalizeArgs{};
+        if (!d.want_kl) continue;
+        if (!d.kl_rows || !d.kl_layer || !d.bias_mu || !d.bias_rho) return LBBNN_E_NULL;
+        if (mnf && (!d.scal || !d.r0_b1 || !d.r0_b2 || !d.act_mu || !d.act_var)) return LBBNN_E_NULL;
+        if (mnf && !d.eps_act && !rng) return LBBNN_E_NOISE;
+        k.kl_rows = d.kl_rows; k.bias_mu = d.bias_mu; k.bias_rho = d.bias_rho;
+        k.act_mu = mnf ? d.act_mu : nullptr; k.act_var = mnf ? d.act_var : nullptr; k.eps_act = d.eps_act;
+        k.r0_b1 = d.r0_b1; k.r0_b2 = d.r0_b2; k.scal = mnf ? d.scal : nullptr; k.rng = rng;
+        k.kl_out = nullptr; k.kl_layer = d.kl_layer; k.O = d.O; k.I = d.I; k.accum = 0; k.layer = d.layer_id & 63u;
+        k.bias_mu_prior = d.priors.bias_mu_prior; k.bias_sigma_prior = d.priors.bias_sigma_prior;
+    }
+    if (kl_total) for (int i = 0; i < n; ++i) if (!active[i]) return LBBNN_E_NULL;   // a total needs every layer's KL
+    return launch_kl_finalize_all(ka, active, n, rng, advance, kl_total, static_cast<hipStream_t>(stream));
 }

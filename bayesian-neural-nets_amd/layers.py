@@ -652,11 +652,11 @@ class _NetworkBase(nn.Module):
         return self._forward_streams(x.float(), sample)
 
     def _forward_streams(self, x, sample):
-        """Fused no-grad forward: ONE stream, 3 + 3 + 1 launches.
+        """Fused no-grad forward: ONE stream, 2 + 3 + 1 launches.
 
-        lbbnn_layers_prepare runs the x-independent kernels of all layers (flows, weight pass, KL
-        finalize: one launch per kind), then the three GEMMs run back to back (ReLU / log_softmax in
-        their epilogues), then lbbnn_forward_finish sums the layer KLs and advances the RNG offset.
+        lbbnn_layers_operands runs the x-independent kernels the GEMMs need for all layers (flows, weight pass: one
+        launch per kind), then the three GEMMs run back to back (ReLU / log_softmax in their epilogues), then
+        lbbnn_layers_finalize finishes every layer's KL, sums them and advances the RNG offset in one launch.
         (A two-stream schedule was measured first: every cross-stream dependency cost 13-15 us on
         the critical path and the side-stream kernels were starved by the GEMM -- see DESIGN.md.)
         """
@@ -678,18 +678,17 @@ class _NetworkBase(nn.Module):
             l._split_now = l._split(x if i == 0 else None) and (i == 0 or layers[i - 1].out_features % 4 == 0)
             keep.append(l._fill_desc(descs[i], c, kls[i] if c[1] else None))
         stream = torch.cuda.current_stream(dev).cuda_stream
-        _lib.check(_lib.lib().lbbnn_layers_prepare(descs, n, rng.data_ptr() if rng is not None else None, stream),
-                   "lbbnn_layers_prepare")
+        _lib.check(_lib.lib().lbbnn_layers_operands(descs, n, rng.data_ptr() if rng is not None else None, stream),
+                   "lbbnn_layers_operands")
         for i, (l, c) in enumerate(zip(layers, cfgs)):
             x = l._gemm(x, c, rng, log_softmax=(i == n - 1 and l.out_features <= 16))
         if layers[-1].out_features > 16:
             x = F.log_softmax(x, dim=1)
         if want_kl or st is not None:
-            ptrs = (ctypes.c_void_p * n)(*[kls[i].data_ptr() if (want_kl and cfgs[i][1]) else None for i in range(n)])
             all_kl = want_kl and all(c[1] for c in cfgs)
-            _lib.check(_lib.lib().lbbnn_forward_finish(rng.data_ptr() if st is not None else None, 1, ptrs, n,
-                                                       kls[n:].data_ptr() if all_kl else None, stream),
-                       "lbbnn_forward_finish")
+            _lib.check(_lib.lib().lbbnn_layers_finalize(descs, n, rng.data_ptr() if st is not None else None, 1,
+                                                        kls[n:].data_ptr() if all_kl else None, stream),
+                       "lbbnn_layers_finalize")
         for i, (l, c) in enumerate(zip(layers, cfgs)):
             l.kl = kls[i] if c[1] else 0
         self._kl_total = kls[n] if (want_kl and all(c[1] for c in cfgs)) else None

@@ -234,6 +234,13 @@ typedef struct lbbnn_layer_desc {
 } lbbnn_layer_desc_t;
 
 int lbbnn_layers_prepare(const lbbnn_layer_desc_t* layers, int n, const uint64_t* rng, void* stream);
+/* The same forward with K5 moved to the END (it feeds no GEMM):  lbbnn_layers_operands = K3 + K1 of all layers;
+ * lbbnn_layers_finalize = K5 of every layer with want_kl, kl_total = sum of the layer KLs in layer order (NULL = no
+ * total; needs want_kl on every layer otherwise) and rng offset += advance, all in ONE single-workgroup launch.
+ * A network forward is then 6 launches: operands (2), three GEMMs, finalize. */
+int lbbnn_layers_operands(const lbbnn_layer_desc_t* layers, int n, const uint64_t* rng, void* stream);
+int lbbnn_layers_finalize(const lbbnn_layer_desc_t* layers, int n, uint64_t* rng, uint64_t advance, float* kl_total,
+                          void* stream);
 
 /* End of a network forward: *kl_total = sum_l *kl_layers[l] (fixed order; BayesianNetwork.kl(),
  * …LRT.py:213-214) and rng[1] += advance, one tiny launch.  kl_total may be NULL (n ignored). */
