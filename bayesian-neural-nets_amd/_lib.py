@@ -82,6 +82,11 @@ class AdamList(ctypes.Structure):
                 ("v", c_p * ADAM_MAX_TENSORS), ("numel", c_i64 * ADAM_MAX_TENSORS), ("n", c_i)]
 
 
+class CopyList(ctypes.Structure):
+    """lbbnn_copy_list_t"""
+    _fields_ = [("dst", c_p * ADAM_MAX_TENSORS), ("src", c_p * ADAM_MAX_TENSORS), ("numel", c_i64 * ADAM_MAX_TENSORS), ("n", c_i)]
+
+
 class OutGradArgs(ctypes.Structure):
     """lbbnn_outgrad_args_t"""
     _fields_ = [(n, c_p) for n in ("g_out", "out", "std", "eps", "rng", "gm", "gv", "gmT", "gvT", "g_sum", "gv_sum", "work")] + \
@@ -127,6 +132,7 @@ SIGNATURES = {
     "lbbnn_transpose_operand": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p]),
     "lbbnn_weight_pass_backward_workspace": (c_i64, [c_i, c_i]),
     "lbbnn_weight_pass_backward": (c_i, [ctypes.POINTER(WpbArgs), c_p]),
+    "lbbnn_multi_copy": (c_i, [ctypes.POINTER(CopyList), c_p]),
     "lbbnn_adam_step": (c_i, [ctypes.POINTER(AdamList), ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                               ctypes.c_float, c_p, c_i, c_p]),
     "lbbnn_matmul_splitk": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),

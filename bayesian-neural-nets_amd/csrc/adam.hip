@@ -68,6 +68,29 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamKArgs ka) {
 
 __global__ void adam_advance_kernel(float* step) { step[0] += 1.f; }
 
+struct CopyKArgs { lbbnn_copy_list_t l; int first[LBBNN_ADAM_MAX_TENSORS + 1]; };
+
+__global__ __launch_bounds__(256) void multi_copy_kernel(const CopyKArgs ka) {
+    const LBBNN_CONST_AS CopyKArgs& a = *kernarg_as<CopyKArgs>();
+    const int blk = blockIdx.x;
+    int lo = 0, hi = a.l.n;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.first[mid] <= blk) lo = mid; else hi = mid; }
+    float* __restrict__ d = a.l.dst[lo];
+    const float* __restrict__ sp = a.l.src[lo];
+    const int64_t n = a.l.numel[lo], base = (int64_t)(blk - a.first[lo]) * CHUNK;
+    const bool vec = ((reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(sp)) & 15u) == 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t i = base + (int64_t)(threadIdx.x + 256 * k) * 4;
+        if (i >= n) break;
+        if (vec && i + 4 <= n) {
+            *reinterpret_cast<float4*>(d + i) = sp ? *reinterpret_cast<const float4*>(sp + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            for (int64_t q = i; q < n && q < i + 4; ++q) d[q] = sp ? sp[q] : 0.f;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int lbbnn_adam_step(const lbbnn_adam_list_t* list, float lr, float beta1, float beta2, float eps, float weight_decay,
@@ -90,5 +113,23 @@ extern "C" int lbbnn_adam_step(const lbbnn_adam_list_t* list, float lr, float be
         hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(256), 0, s, ka);
     }
     if (advance) hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, s, step);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lbbnn_multi_copy(const lbbnn_copy_list_t* list, void* stream) {
+    if (!list) return LBBNN_E_NULL;
+    if (list->n < 0 || list->n > LBBNN_ADAM_MAX_TENSORS) return LBBNN_E_SHAPE;
+    if (list->n == 0) return 0;
+    CopyKArgs ka;
+    ka.l = *list;
+    int nb = 0;
+    for (int i = 0; i < list->n; ++i) {
+        if (!list->dst[i]) return LBBNN_E_NULL;
+        if (list->numel[i] <= 0) return LBBNN_E_SHAPE;
+        ka.first[i] = nb;
+        nb += (int)((list->numel[i] + CHUNK - 1) / CHUNK);
+    }
+    for (int i = list->n; i <= LBBNN_ADAM_MAX_TENSORS; ++i) ka.first[i] = nb;
+    hipLaunchKernelGGL(multi_copy_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), ka);
     return (int)hipGetLastError();
 }

@@ -36,7 +36,12 @@ class Adam(torch.optim.Optimizer):
         return group["step_dev"]
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, grads=None):
+        """``grads``: optional (params, tensors) pair -- gradients to use instead of ``p.grad`` (the views of a
+        data-parallel flat bucket after its all-reduce, so they are consumed where RCCL left them)."""
+        override = {}
+        if grads is not None:
+            override = {id(p): g for p, g in zip(*grads)}
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -45,7 +50,7 @@ class Adam(torch.optim.Optimizer):
             if not group["params"]:
                 continue
             step = self._group_state(group)
-            ps = [p for p in group["params"] if p.grad is not None]
+            ps = [p for p in group["params"] if (id(p) in override or p.grad is not None)]
             stream = torch.cuda.current_stream(step.device).cuda_stream
             b1, b2 = group["betas"]
             keep = []
@@ -54,7 +59,7 @@ class Adam(torch.optim.Optimizer):
                 lst = _lib.AdamList()
                 lst.n = len(chunk)
                 for k, p in enumerate(chunk):
-                    g = p.grad
+                    g = override.get(id(p), p.grad)
                     if g.is_sparse:
                         raise RuntimeError("bnn_amd.optim.Adam does not support sparse gradients")
                     if not g.is_contiguous() or g.dtype != torch.float32:

@@ -34,32 +34,65 @@ class GradBucket:
         dev = self.params[0].device if self.params else torch.device("cpu")
         self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
 
-    def pack(self):
+    def _slices(self):
         off = 0
         for p in self.params:
             n = p.numel()
-            if p.grad is None:
-                self.flat[off:off + n].zero_()
-            else:
-                self.flat[off:off + n].copy_(p.grad.reshape(-1))
+            yield p, self.flat[off:off + n]
             off += n
 
+    def views(self):
+        """Per-parameter views of the flat buffer (what ``bnn_amd.optim.Adam.step(grads=...)`` consumes, so the reduced
+        gradients never have to be copied back into ``p.grad``)."""
+        return [s.view_as(p) for p, s in self._slices()]
+
+    def _multi_copy(self, pairs):
+        """pairs: (dst, src-or-None) fp32 HIP tensors -> lbbnn_multi_copy, <= 80 tensors per launch."""
+        import ctypes
+        from . import _lib
+        stream = torch.cuda.current_stream(self.flat.device).cuda_stream
+        for i in range(0, len(pairs), _lib.ADAM_MAX_TENSORS):
+            chunk = pairs[i:i + _lib.ADAM_MAX_TENSORS]
+            lst = _lib.CopyList()
+            lst.n = len(chunk)
+            for k, (d, s) in enumerate(chunk):
+                lst.dst[k], lst.src[k], lst.numel[k] = d.data_ptr(), (s.data_ptr() if s is not None else None), d.numel()
+            _lib.check(_lib.lib().lbbnn_multi_copy(ctypes.byref(lst), stream), "lbbnn_multi_copy")
+
+    def _hip_ok(self, grads):
+        return self.flat.is_cuda and all(g is None or (g.is_cuda and g.dtype == torch.float32 and g.is_contiguous()) for g in grads)
+
+    def pack(self):
+        grads = [p.grad for p in self.params]
+        if self._hip_ok(grads):                          # one launch for all parameters
+            self._multi_copy([(s, g) for (p, s), g in zip(self._slices(), grads)])
+            return
+        for (p, s), g in zip(self._slices(), grads):
+            if g is None:
+                s.zero_()
+            else:
+                s.copy_(g.reshape(-1))
+
     def unpack(self):
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            g = self.flat[off:off + n].view_as(p)
+        if self.flat.is_cuda and all(p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32
+                                     for p in self.params):
+            self._multi_copy([(p.grad, s) for p, s in self._slices()])
+            return
+        for p, s in self._slices():
+            g = s.view_as(p)
             if p.grad is None:
                 p.grad = g.clone()
             else:
                 p.grad.copy_(g)
-            off += n
 
-    def all_reduce(self, group=None):
+    def all_reduce(self, group=None, unpack: bool = True):
+        """pack -> all_reduce(SUM) -> unpack.  ``unpack=False`` leaves the reduced gradients in the flat buffer only
+        (use ``views()`` with ``bnn_amd.optim.Adam.step(grads=...)``)."""
         self.pack()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-        self.unpack()
+        if unpack:
+            self.unpack()
 
 
 class DataParallelELBO:
@@ -95,5 +128,9 @@ class DataParallelELBO:
         nll = torch.nn.functional.nll_loss(log_probs, target, reduction="sum")
         return nll + self.net.kl() / (num_batches * self.world)
 
-    def all_reduce_grads(self):
-        self.bucket.all_reduce(self.group)
+    def all_reduce_grads(self, unpack: bool = True):
+        self.bucket.all_reduce(self.group, unpack=unpack)
+
+    def reduced_grads(self):
+        """(parameters, gradient views into the reduced flat bucket) for ``optim.Adam.step(grads=...)``."""
+        return self.bucket.params, self.bucket.views()

@@ -483,6 +483,18 @@ int lbbnn_adam_step(const lbbnn_adam_list_t* list, float lr, float beta1, float 
 int lbbnn_matmul_splitk(const float* x, int ldx, const void* w_op, int ld, float* out, int ldo,
                         int B, int I, int O, int kchunk, void* stream);
 
+/* lbbnn_multi_copy -- dst[i][0..numel[i]) = src[i][...] for a LIST of fp32 tensors in one launch: packing the gradients
+ * of all parameters into the flat bucket that is all-reduced over RCCL (and unpacking it), instead of one copy kernel
+ * per parameter tensor. */
+typedef struct lbbnn_copy_list {
+    float* dst[LBBNN_ADAM_MAX_TENSORS];
+    const float* src[LBBNN_ADAM_MAX_TENSORS];      /* NULL = fill dst with zeros (a parameter without a gradient) */
+    int64_t numel[LBBNN_ADAM_MAX_TENSORS];
+    int n;
+} lbbnn_copy_list_t;
+
+int lbbnn_multi_copy(const lbbnn_copy_list_t* list, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

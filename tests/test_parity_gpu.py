@@ -1096,3 +1096,40 @@ def test_backward_in_kernel_noise_equals_injected_noise(bnn, dev, I, O, T):
     assert torch.equal(out_a, out_b)
     for n, q in layer.named_parameters():
         assert rel_err(grads_a[n], q.grad) < 1e-6, n
+
+
+@pytest.mark.gpu
+def test_data_parallel_bucket_path_equals_plain_step(bnn, dev):
+    """World size 1 on the GPU: pack (lbbnn_multi_copy) -> [all-reduce = identity] -> Adam reading the flat bucket
+    gives the same parameters as the plain loss.backward(); opt.step(); unpack restores p.grad.  (Same network object
+    for both runs: the in-kernel noise streams are keyed by layer id.)"""
+    import copy
+    from bnn_amd.parallel import DataParallelELBO
+    torch.manual_seed(5)
+    net = bnn.mnf.BayesianNetwork((784, 64, 48, 10), 2, z_flow_type="Planar", r_flow_type="Planar").to(dev).train()
+    init = copy.deepcopy(net.state_dict())
+    data, target = torch.rand(32, 1, 28, 28, device=dev), torch.randint(0, 10, (32,), device=dev)
+    finals = []
+    for mode in ("plain", "bucket"):
+        net.load_state_dict(init)
+        opt = bnn.optim.Adam(net.parameters(), lr=1e-3)
+        dp = DataParallelELBO(net)
+        for it in range(3):
+            bnn.manual_seed(100 + it)                       # same draws in both runs
+            net.zero_grad()
+            if mode == "plain":
+                loss = torch.nn.functional.nll_loss(net(data, sample=True), target, reduction="sum") + net.kl() / 10
+                loss.backward()
+                opt.step()
+            else:
+                x_r, y_r = dp.shard(data, target)
+                loss = dp.loss(net(x_r, sample=True), y_r, num_batches=10)
+                loss.backward()
+                dp.all_reduce_grads(unpack=(it == 0))        # the first step also exercises the unpack launch
+                if it == 0:
+                    for p, v in zip(*dp.reduced_grads()):
+                        assert torch.equal(p.grad, v)
+                opt.step(grads=dp.reduced_grads())
+        finals.append({k: v.detach().clone() for k, v in net.named_parameters()})
+    for k in finals[0]:
+        assert torch.equal(finals[0][k], finals[1][k]), k
