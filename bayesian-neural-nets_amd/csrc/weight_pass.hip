@@ -27,14 +27,20 @@ __device__ __forceinline__ uint32_t bf16_rne(float f) {
     return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
 __device__ __forceinline__ float bf16_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
-// split w = hi + lo (both bf16): hi = rne(w), lo = rne(w - hi); packs 4 elements into two uint2
+// split w = hi + lo (both bf16): hi = rne(w), lo = rne(w - hi); packs 4 elements into two uint2.  The roundings are
+// the hardware's v_cvt_pk_bf16_f32 (RNE, two values per instruction): ~12 VALU per float4 instead of ~50 for the
+// integer form above, bit-identical for finite inputs.
+typedef __bf16 k1_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float k1_floatx2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cvt_pk(float a, float b) {
+    const k1_floatx2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, k1_bf16x2));
+}
 __device__ __forceinline__ void split4(const float4 w, uint2& hi, uint2& lo) {
-    const float v[4] = {w.x, w.y, w.z, w.w};
-    uint32_t h[4], l[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { h[i] = bf16_rne(v[i]); l[i] = bf16_rne(v[i] - bf16_to_f32(h[i])); }
-    hi = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-    lo = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+    const uint32_t h0 = cvt_pk(w.x, w.y), h1 = cvt_pk(w.z, w.w);
+    hi = make_uint2(h0, h1);
+    lo = make_uint2(cvt_pk(w.x - __uint_as_float(h0 << 16), w.y - __uint_as_float(h0 & 0xFFFF0000u)),
+                    cvt_pk(w.z - __uint_as_float(h1 << 16), w.w - __uint_as_float(h1 & 0xFFFF0000u)));
 }
 
 // All per-weight arithmetic (LBBNN-GP-MF-LRT.py:167-171,189-192; LBBNN-GP-MF-MNF.py:195-196,211-212,230-233).
@@ -45,6 +51,10 @@ __device__ __forceinline__ void split4(const float4 w, uint2& hi, uint2& lo) {
 // exp(rho) < 0.04 (the reference's init has exp(rho) in [0.0067, 0.018]; truncation error < 1e-9 relative)
 // and libm log1pf otherwise;  log(a/b) = log a - log b with the prior logs precomputed on the host.
 // Measured against the fp64 oracle: operands and row sums stay within 2e-6 relative (tests).
+// Ablations (tools/lab, all layers of the headline net): full 21.1 us; operand stores removed 19.1; arithmetic
+// removed 14.6 -- the floor is the per-workgroup load -> reduce -> store latency of 2410 short workgroups.  A version
+// walking ~4 rows per workgroup with the next row's loads in flight was measured at 29.5 us (fewer workgroups in
+// flight per CU cost more than the prefetch saves) and dropped.
 __device__ __forceinline__ float softplus_fast(float rho) {
     const float y = __expf(rho);
     if (y < 0.04f) {
@@ -57,6 +67,10 @@ __device__ __forceinline__ float softplus_fast(float rho) {
 __device__ __forceinline__ Elem weight_elem(float mu, float rho, float lam, float zf, float zk, float rc,
                                             bool want_kl, bool want_act, const WeightPassArgs& a) {
     Elem e;
+#ifdef LAB_K1_NOMATH         // tools/lab ablation only: keep the loads/stores, drop the transcendental chain
+    e.ew = mu * zf + lam; e.vw = rho * lam; e.kl = mu; e.amu = rho * rc; e.avar = lam * zk;
+    return e;
+#endif
     const float alpha = __frcp_rn(1.0f + __expf(-lam));
     const float sigma = softplus_fast(rho);
     const float ea = mu * alpha;
@@ -124,6 +138,9 @@ __global__ __launch_bounds__(256) void weight_pass_kernel(const WeightPassBatch 
                 amu += (e0.amu + e1.amu) + (e2.amu + e3.amu);
                 avar += (e0.avar + e1.avar) + (e2.avar + e3.avar);
             }
+#ifdef LAB_K1_NOSTORE        // tools/lab ablation only
+            if (ew.x == 12345.678f)
+#endif
             if (!a.split) {
                 if (a.e_w) reinterpret_cast<float4*>(a.e_w + (size_t)o * a.ld)[j] = ew;
                 if (a.var_w) reinterpret_cast<float4*>(a.var_w + (size_t)o * a.ld)[j] = vw;
