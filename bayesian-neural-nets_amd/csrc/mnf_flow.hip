@@ -4,12 +4,13 @@
 // K3  mnf_flow_planar : z sampling + planar normalizing flows + log_q0.
 //     Work is O(T*I) (a few KB): launch/latency bound, so everything a layer needs from the flows
 //     is done in ONE launch of two independent workgroups per layer (forward multiplier z_k | KL
-//     branch z2 + r_flow), each a single 256-thread workgroup.  Fast path: every parameter element a
-//     thread needs is loaded into registers before the first reduction (one HBM/L2 latency for the
-//     whole kernel); generic path: z resident in LDS.  Dot products use fixed-order wave butterflies
-//     => deterministic.
+//     branch z2 + r_flow).  Three forms: mnf_flow_planar_fast_kernel (chains of <= 4 transforms: one
+//     reduction for the whole chain, 512 threads, inputs prefetched into LDS by LDS-DMA), the _lds_kernel
+//     (longer chains, one reduction per transform) and the generic kernel (vectors too large for LDS).
+//     Dot products are fixed-order sums (DPP + readlane inside a wave, LDS across waves) => deterministic.
 // K5  kl_finalize     : O(O+I) tail of the KL: kl_bias, tanh/mean of the auxiliary activations,
-//     log_rb, and the final scalar.
+//     log_rb, and the final scalar; kl_finalize_all_kernel does it for every layer of a network, adds the
+//     network total and advances the RNG offset in one launch.
 #include "lbbnn_device.h"
 #include "lbbnn_internal.h"
 

@@ -375,8 +375,8 @@ def test_error_paths(bnn, dev):
 
 # --------------------------------------------------------------------------- scheduling variants
 def test_stream_schedule_equals_sequential(bnn, dev, golden):
-    """The two-stream no-grad schedule (fused ReLU/log_softmax, deferred K5) and the per-layer
-    autograd path compute the same numbers."""
+    """The fused no-grad schedule (batched K3/K1, ReLU/log_softmax in the GEMM epilogues, K5 of all layers at the
+    end) and the per-layer autograd path compute the same numbers."""
     c = golden("mnf.npz").case("smallnet")
     dims = [int(v) for v in c["dims"]]
     net = bnn.mnf.BayesianNetwork(dims, 2, z_flow_type="Planar", r_flow_type="Planar")
