@@ -657,175 +657,6 @@ __global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_bf16x3_kernel(const GemmA
     }
 }
 
-#ifdef LAB_PLANES
-// ------------------------------------------------------------------------------------------------
-// LAB ONLY (tools/lab, -DLAB_PLANES): "P" variant -- timing experiment, not a product kernel.
-// a.x is reinterpreted as FOUR bf16 planes [xh | xl | sh | sl], each [B][I] (the caller passes a (B, 2I) fp32 buffer).
-// Derived from the "Q" variant of the split-precision kernel: 128(b) x 160(o) tile, 8 waves = 4 row groups x 2 column halves, ONE
-// workgroup per CU, and the bf16 splitting of x done ONCE per tile and shared through LDS.
-//
-// Why (measured on the 128x80 kernel): the issue port is the co-limit -- 60 MFMA (480 issue-hold
-// cycles) + ~104 conversion VALU per wave-step -- and operand delivery (L2 -> LDS) is the other.  Here a K step is
-//   A: wave w converts rows [16w, 16w+16) of the fp32 x tile (1/8 of it: ~50 VALU) into four bf16 planes in LDS
-//   barrier
-//   B: wave (r, c) reads the planes of its 32 rows + the weight planes of its 80 columns and issues 60 MFMAs
-//   barrier
-// so every x element is converted once for 160 output columns instead of once per 80 (half the VALU per MFMA), and
-// the x tile is fetched once per 160 columns (DMA bytes per CU and step: 56 KB instead of 2 x 36.9 KB).
-// LDS: 2 stages x (16 KB x + 4 x 10 KB weight planes) + 32 KB converted planes = 144 KB.
-template <bool MEAN_ONLY>
-__global__ __launch_bounds__(512, 1) void lrt_gemm_bf16x3_p_kernel(const GemmArgs a) {
-    constexpr int TO = 5, TB = 2, WB = 8;
-    constexpr int BN = 160, BM = 128;
-    constexpr int NPL = MEAN_ONLY ? 2 : 4;               // weight planes: e_w hi, lo (, var_w hi, lo)
-    constexpr int NXP = MEAN_ONLY ? 2 : 4;               // x planes
-    constexpr int XB = NXP * BM * 64;                    // bytes of the x-plane region of a stage
-    constexpr int PB = BN * 64;                          // bytes of one weight plane region
-    constexpr int BUFB = XB + NPL * PB;                  // bytes per stage
-    constexpr int XPB = BM * 64;                         // bytes of one converted x plane (xh, xl, sh, sl)
-    constexpr int NGX = NXP * (BM / 16), NGW = BN / 16;   // 1-KiB pieces: 16 rows x 64 B
-    constexpr int NG = NGX + NPL * NGW;
-    constexpr int NPW = (NG + WB - 1) / WB;
-    extern __shared__ __attribute__((aligned(16))) char smc[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wv & 3, wc = wv >> 2;
-    const int lr = lane & 15, q = lane >> 4;
-    int tox, tby;
-    tile_of_block(tox, tby);
-    const int o0 = tox * BN;
-    const int b0 = tby * BM;
-    const int kbeg = a.kchunk ? (int)blockIdx.z * a.kchunk : 0;
-    const int Iloc = a.kchunk ? min(a.I - kbeg, a.kchunk) : a.I;
-    const char* const eh = reinterpret_cast<const char*>(a.e_w);
-    const char* const el = eh + (size_t)a.O * a.ld * 2;
-    const char* const vh = reinterpret_cast<const char*>(a.var_w);
-    const char* const vl = vh + (size_t)a.O * a.ld * 2;
-    const char* const zsrc = eh + (size_t)a.I * 2;
-
-    const char* gp[NPW];
-    int adv[NPW], kx[NPW];
-#pragma unroll
-    for (int u = 0; u < NPW; ++u) {
-        const int g = wv + WB * u;
-        if (g < NGX) {
-            const int pl = g / (BM / 16), row = 16 * (g % (BM / 16)) + (lane >> 2);
-            const int slot = (lane & 3) ^ swz(row >> 2);
-            const char* base = reinterpret_cast<const char*>(a.x) + (size_t)pl * a.B * a.I * 2;
-            gp[u] = base + ((size_t)min(b0 + row, a.B - 1) * a.I + kbeg) * 2 + 16 * slot;
-            adv[u] = 64; kx[u] = -1;
-        } else {
-            const int gw = g - NGX, pl = gw / NGW, row = 16 * (gw % NGW) + (lane >> 2);
-            const int slot = (lane & 3) ^ swz(row >> 2);
-            const char* base = pl == 0 ? eh : (pl == 1 ? el : (pl == 2 ? vh : vl));
-            gp[u] = base + ((size_t)min(o0 + row, a.O - 1) * a.ld + kbeg) * 2 + 16 * slot;
-            adv[u] = 64; kx[u] = -1;
-        }
-    }
-    const int nsteps = (Iloc + BKS - 1) / BKS;
-    const bool has_tail = (Iloc % BKS) != 0;
-    auto dma_step = [&](int c, char* buf) {
-        const bool tail = has_tail && c == nsteps - 1;
-#pragma unroll
-        for (int u = 0; u < NPW; ++u) {
-            const int g = wv + WB * u;
-            if (g < NG) {
-                const char* src = gp[u] + (size_t)c * adv[u];
-                if (tail && kx[u] >= 0 && c * BKS + kx[u] >= Iloc) src = zsrc;
-                const int loff = g < NGX ? g * 1024 : XB + (g - NGX) * 1024;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(buf + loff), 16, 0, 0);
-            }
-        }
-    };
-
-    floatx4 accm[TO][TB], accv[TO][TB];
-#pragma unroll
-    for (int i = 0; i < TO; ++i)
-#pragma unroll
-        for (int j = 0; j < TB; ++j) { accm[i][j] = floatx4{0.f, 0.f, 0.f, 0.f}; accv[i][j] = floatx4{0.f, 0.f, 0.f, 0.f}; }
-
-    // phase B offsets: x planes of rows (wr*32 + 16j + lr), weight planes of rows (wc*80 + 16i + lr)
-    const int bxo = (wr * 32 + lr) * 64 + 16 * (q ^ swz(lr >> 2));          // (16j rows further: + j*1024; swizzle unchanged)
-    const int wo = XB + (wc * 80 + lr) * 64 + 16 * (q ^ swz(lr >> 2));      // (16i rows further: + i*1024)
-
-    uint4 xh[TB], xl[TB], sh[TB], sl[TB];
-    uint4 wh[TO], wl[TO], wvh[TO], wvl[TO];
-    auto read_frags = [&](const char* cur) {
-#pragma unroll
-        for (int j = 0; j < TB; ++j) {
-            xh[j] = *reinterpret_cast<const uint4*>(cur + bxo + j * 1024);
-            xl[j] = *reinterpret_cast<const uint4*>(cur + XPB + bxo + j * 1024);
-            if (!MEAN_ONLY) {
-                sh[j] = *reinterpret_cast<const uint4*>(cur + 2 * XPB + bxo + j * 1024);
-                sl[j] = *reinterpret_cast<const uint4*>(cur + 3 * XPB + bxo + j * 1024);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < TO; ++i) {
-            wh[i] = *reinterpret_cast<const uint4*>(cur + wo + i * 1024);
-            wl[i] = *reinterpret_cast<const uint4*>(cur + wo + PB + i * 1024);
-            if (!MEAN_ONLY) {
-                wvh[i] = *reinterpret_cast<const uint4*>(cur + wo + 2 * PB + i * 1024);
-                wvl[i] = *reinterpret_cast<const uint4*>(cur + wo + 3 * PB + i * 1024);
-            }
-        }
-    };
-    auto mfmas = [&]() {
-#pragma unroll
-        for (int j = 0; j < TB; ++j) {
-            const bf16x8 bxh = __builtin_bit_cast(bf16x8, xh[j]), bxl = __builtin_bit_cast(bf16x8, xl[j]);
-#pragma unroll
-            for (int i = 0; i < TO; ++i) {
-                const bf16x8 ah = __builtin_bit_cast(bf16x8, wh[i]);
-                accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bxh, accm[i][j], 0, 0, 0);
-                accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wl[i]), bxh, accm[i][j], 0, 0, 0);
-                accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bxl, accm[i][j], 0, 0, 0);
-                if (!MEAN_ONLY) {
-                    const bf16x8 bh = __builtin_bit_cast(bf16x8, wvh[i]);
-                    accv[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, __builtin_bit_cast(bf16x8, sh[j]), accv[i][j], 0, 0, 0);
-                    accv[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wvl[i]), __builtin_bit_cast(bf16x8, sh[j]), accv[i][j], 0, 0, 0);
-                    accv[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, __builtin_bit_cast(bf16x8, sl[j]), accv[i][j], 0, 0, 0);
-                }
-            }
-        }
-    };
-
-    dma_step(0, smc);
-    __syncthreads();                                     // vmcnt(0) + barrier: stage 0 landed
-    for (int c = 0; c < nsteps; ++c) {
-        const char* cur = smc + (c & 1) * BUFB;
-        read_frags(cur);                                 // B: reads issued before the next stage's DMA (see the 128x80 kernel)
-        __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < nsteps) dma_step(c + 1, smc + ((c & 1) ^ 1) * BUFB);
-        __builtin_amdgcn_sched_barrier(0);
-        mfmas();
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();                                 // DMA landed; everyone done with the planes and with `cur`
-    }
-
-    GemmArgs ao = a;
-    if (a.kchunk) ao.out = a.out + (size_t)blockIdx.z * a.split_stride;
-    const EpiCtx ec = make_epi_ctx<MEAN_ONLY>(ao);
-#pragma unroll
-    for (int i = 0; i < TO; ++i) {
-        const int o = o0 + wc * 80 + i * 16 + 4 * q;
-        if (o >= a.O) continue;
-        const OConst oc = load_oconst(ao, o);
-#pragma unroll
-        for (int j = 0; j < TB; ++j) {
-            const int b = b0 + (wr * TB + j) * 16 + lr;
-            if (b >= a.B) continue;
-            float res[4];
-            epilogue4<MEAN_ONLY>(ao, ec, oc, b, o, accm[i][j], accv[i][j], res);
-            store4(ao, ec, b, o, res);
-        }
-    }
-}
-
-#endif  // LAB_PLANES
-
 // ------------------------------------------------------------------------------------------------
 // Ring variant of the split-precision kernel: 256(b) x 80(o) tile, 8 waves, ONE workgroup per CU, and a
 // 3-buffer LDS ring (3 x 52 KB) with LDS-DMA running TWO K steps ahead.
@@ -1239,13 +1070,6 @@ int launch_split(const GemmArgs& a, bool mean_only, hipStream_t s) {
         if (mean_only) return launch_one(lrt_gemm_bf16x3_ring_kernel<5, true>, grid, block, 3u * (256 * 128 + 2 * 80 * 64), s, a);
         return launch_one(lrt_gemm_bf16x3_ring_kernel<5, false>, grid, block, 3u * (256 * 128 + 4 * 80 * 64), s, a);
     }
-#ifdef LAB_PLANES           // tools/lab timing experiment only
-    if (!a.kchunk && a.B >= 1024 && a.O >= 640) {
-        dim3 grid((a.O + 159) / 160, (a.B + 127) / 128), block(512);
-        if (mean_only) return launch_one(lrt_gemm_bf16x3_p_kernel<true>, grid, block, 2u * (2 * 128 * 64 + 2 * 160 * 64), s, a);
-        return launch_one(lrt_gemm_bf16x3_p_kernel<false>, grid, block, 2u * (4 * 128 * 64 + 4 * 160 * 64), s, a);
-    }
-#endif
     const long nz = a.kchunk ? (a.I + a.kchunk - 1) / a.kchunk : 1;
     const long blocks_big = (long)((a.O + 79) / 80) * ((a.B + 127) / 128) * nz;
     if (blocks_big >= 256 && a.B >= 96) return launch_split_cfg<5, 2, 4>(a, mean_only, s);
