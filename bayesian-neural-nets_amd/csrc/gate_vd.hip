@@ -13,14 +13,15 @@ __device__ __forceinline__ uint32_t bf16_rne_bits(float f) {
     const uint32_t u = __float_as_uint(f);
     return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
-// store one operand value at [o][i] either as fp32 or as bf16 hi/lo planes
+// store one operand value at [o][i] either as fp32 or in the split bf16 hi|lo layout
 __device__ __forceinline__ void store_operand(void* base, int split, size_t O, int ld, int o, int i, float v) {
     if (!split) { static_cast<float*>(base)[(size_t)o * ld + i] = v; return; }
-    uint16_t* hi = static_cast<uint16_t*>(base);
-    uint16_t* lo = hi + O * (size_t)ld;
+    uint16_t* const w = static_cast<uint16_t*>(base);           // [hi 32 | lo 32] per 32-k chunk (lbbnn_device.h)
+    const size_t at = split_hi_index((size_t)o, i, ld);
     const uint32_t h = bf16_rne_bits(v);
-    hi[(size_t)o * ld + i] = (uint16_t)h;
-    lo[(size_t)o * ld + i] = (uint16_t)bf16_rne_bits(v - __uint_as_float(h << 16));
+    w[at] = (uint16_t)h;
+    w[at + kSplitLoOffset] = (uint16_t)bf16_rne_bits(v - __uint_as_float(h << 16));
+    (void)O;
 }
 
 // ------------------------------------------------------------------------------------------------ K6

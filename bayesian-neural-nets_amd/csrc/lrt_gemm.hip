@@ -468,11 +468,14 @@ __global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_f32_dma_kernel(const Gemm
 // x stays fp32 in HBM and in LDS (the previous layer's output as it is); each lane splits its fragment in
 // registers: xh = bits & 0xFFFF0000 (truncation, so xl = x - xh is exact), xl -> bf16 RNE; same for x^2
 // (v_and, v_sub, v_perm, v_cvt_pk, v_mul: ~56 VALU per 8 values, hidden under the 60 MFMAs of the step).
-// Weight operands come from lbbnn_weight_pass(LBBNN_F_SPLIT16) as bf16 planes [hi | lo] of e_w and of var_w.
+// Weight operands come from lbbnn_weight_pass(LBBNN_F_SPLIT16) in the split layout of lbbnn_device.h: per row and
+// 32-k chunk one 128-B line [hi 64 B | lo 64 B], e_w and var_w each.
 //
-// K step = 32.  LDS image per step: X 128 rows x 128 B (fp32) | Wh, Wl, Vh, Vl 80 rows x 64 B (bf16), all filled
-// by LDS-DMA; conflict-free swizzles on the source side: X slots (16 B) ^ G[row&15],
-// G(r) = ((r>>1)&3)*2 + ((r>>3)&1); W slots ^ F[(row>>2)&3] as in the fp32 kernel.
+// K step = 32.  LDS image per step: X 128 rows x 128 B (fp32) | E 80 rows x 128 B | V 80 rows x 128 B, all filled by
+// LDS-DMA in 1-KiB pieces of 8 rows x 128 B (delivery-only build: 48.9 us against 58.0 us with 16 x 64-B pieces
+// from separate hi / lo planes).  Conflict-free swizzle on the source side, the same for all three regions:
+// 16-B slot s of row r is stored at slot s ^ G(r & 15), G(r) = ((r>>1)&3)*2 + ((r>>3)&1)  (a ds_read_b128 group of
+// 16 lanes reads one logical slot of 16 consecutive rows: (r&1)*8 + (s ^ G(r)) is a permutation of 0..15).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float floatx2 __attribute__((ext_vector_type(2)));
@@ -483,12 +486,12 @@ __device__ __forceinline__ int swzx(int r) { return (((r >> 1) & 3) << 1) | ((r 
 template <int TO, int TB, int WB, bool MEAN_ONLY>
 __global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_bf16x3_kernel(const GemmArgs a) {
     constexpr int BN = TO * 16, BM = TB * WB * 16;
-    constexpr int NPL = MEAN_ONLY ? 2 : 4;               // weight planes: e_w hi, lo (, var_w hi, lo)
+    constexpr int NWR = MEAN_ONLY ? 1 : 2;               // weight regions: e_w (, var_w); a row = [hi 64 B | lo 64 B]
     constexpr int XB = BM * 128;                         // bytes of the X region
-    constexpr int PB = BN * 64;                          // bytes of one weight plane region
-    constexpr int BUFB = XB + NPL * PB;                  // bytes per buffer
-    constexpr int NGX = BM / 8, NGW = BN / 16;           // 1-KiB DMA groups: X (8 rows each), per plane (16 rows each)
-    constexpr int NG = NGX + NPL * NGW;
+    constexpr int WRB = BN * 128;                        // bytes of one weight region
+    constexpr int BUFB = XB + NWR * WRB;                 // bytes per buffer
+    constexpr int NGX = BM / 8, NGW = BN / 8;            // 1-KiB DMA pieces: 8 rows x 128 B, for x and for the weights
+    constexpr int NG = NGX + NWR * NGW;
     constexpr int NPW = (NG + WB - 1) / WB;
     extern __shared__ __attribute__((aligned(16))) char smc[];
 
@@ -502,12 +505,10 @@ __global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_bf16x3_kernel(const GemmA
     // split-K: this workgroup's k range (kbeg is a multiple of 32, so every alignment below is unchanged)
     const int kbeg = a.kchunk ? (int)blockIdx.z * a.kchunk : 0;
     const int Iloc = a.kchunk ? min(a.I - kbeg, a.kchunk) : a.I;
-    const char* const eh = reinterpret_cast<const char*>(a.e_w);
-    const char* const el = eh + (size_t)a.O * a.ld * 2;
-    const char* const vh = reinterpret_cast<const char*>(a.var_w);
-    const char* const vl = vh + (size_t)a.O * a.ld * 2;
-    // 16 B of zeros for x lanes past I in the K tail: the zero-filled tail of row 0 of the hi plane
-    const char* const zsrc = eh + (size_t)a.I * 2;
+    const char* const eb = reinterpret_cast<const char*>(a.e_w);       // rows of 4*ld bytes: per 32-k chunk [hi | lo]
+    const char* const vb = reinterpret_cast<const char*>(a.var_w);
+    // 16 B of zeros for x lanes past I in the K tail: the zero-filled hi tail of row 0's last chunk
+    const char* const zsrc = eb + (size_t)(a.I >> 5) * 128 + (size_t)(a.I & 31) * 2;
 
     const char* gp[NPW];      // per-lane source (byte pointer) of DMA group wv + WB*u at K step 0
     int adv[NPW];             // bytes per K step: 128 (x) or 64 (weights)
@@ -521,11 +522,11 @@ __global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_bf16x3_kernel(const GemmA
             gp[u] = reinterpret_cast<const char*>(a.x + (size_t)min(b0 + row, a.B - 1) * a.ldx + kbeg) + 16 * slot;
             adv[u] = 128; kx[u] = 4 * slot;
         } else {
-            const int gw = g - NGX, pl = gw / NGW, row = 16 * (gw % NGW) + (lane >> 2);
-            const int slot = (lane & 3) ^ swz(row >> 2);
-            const char* base = pl == 0 ? eh : (pl == 1 ? el : (pl == 2 ? vh : vl));
-            gp[u] = base + ((size_t)min(o0 + row, a.O - 1) * a.ld + kbeg) * 2 + 16 * slot;
-            adv[u] = 64; kx[u] = -1;
+            const int gw = g - NGX, reg = gw / NGW, row = 8 * (gw % NGW) + (lane >> 3);
+            const int slot = (lane & 7) ^ swzx(row & 15);        // slots 0-3 = hi, 4-7 = lo; same swizzle as the x rows
+            const char* base = reg == 0 ? eb : vb;
+            gp[u] = base + (size_t)min(o0 + row, a.O - 1) * a.ld * 4 + (size_t)(kbeg >> 5) * 128 + 16 * slot;
+            adv[u] = 128; kx[u] = -1;
         }
     }
     const int nsteps = (Iloc + BKS - 1) / BKS;
@@ -555,7 +556,8 @@ __global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_bf16x3_kernel(const GemmA
     const int gx = swzx(lr);
     const int xo0 = (wv * TB * 16 + lr) * 128 + 16 * ((2 * q) ^ gx);
     const int xo1 = (wv * TB * 16 + lr) * 128 + 16 * ((2 * q + 1) ^ gx);
-    const int wo = XB + lr * 64 + 16 * (q ^ swz(lr >> 2));
+    const int woh = XB + lr * 128 + 16 * (q ^ gx);           // hi part of weight row lr (slot q), lo part: slot 4 + q
+    const int wol = XB + lr * 128 + 16 * ((4 + q) ^ gx);
 
     float4 xr[TB][2];
     uint4 wh[TO], wl[TO], wvh[TO], wvl[TO];
@@ -567,11 +569,11 @@ __global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_bf16x3_kernel(const GemmA
         }
 #pragma unroll
         for (int i = 0; i < TO; ++i) {
-            wh[i] = *reinterpret_cast<const uint4*>(cur + wo + i * 16 * 64);
-            wl[i] = *reinterpret_cast<const uint4*>(cur + wo + PB + i * 16 * 64);
+            wh[i] = *reinterpret_cast<const uint4*>(cur + woh + i * 16 * 128);
+            wl[i] = *reinterpret_cast<const uint4*>(cur + wol + i * 16 * 128);
             if (!MEAN_ONLY) {
-                wvh[i] = *reinterpret_cast<const uint4*>(cur + wo + 2 * PB + i * 16 * 64);
-                wvl[i] = *reinterpret_cast<const uint4*>(cur + wo + 3 * PB + i * 16 * 64);
+                wvh[i] = *reinterpret_cast<const uint4*>(cur + WRB + woh + i * 16 * 128);
+                wvl[i] = *reinterpret_cast<const uint4*>(cur + WRB + wol + i * 16 * 128);
             }
         }
     };
@@ -653,239 +655,6 @@ __global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_bf16x3_kernel(const GemmA
             float res[4];
             epilogue4<MEAN_ONLY>(ao, ec, oc, b, o, accm[i][j], accv[i][j], res);
             store4(ao, ec, b, o, res);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Ring variant of the split-precision kernel: 256(b) x 80(o) tile, 8 waves, ONE workgroup per CU, and a
-// 3-buffer LDS ring (3 x 52 KB) with LDS-DMA running TWO K steps ahead.
-//
-// Why: with a 2-buffer scheme the DMA for step c+1 is issued at the top of step c and must have landed by
-// its end; measured alone, a workgroup spent 1.64 us per step for 0.4 us of MFMA work -- the L2->LDS
-// latency was exposed every step.  Here the DMA of step c+2 is issued during step c, so it has two full
-// steps to land.  The larger tile also cuts LDS fill per flop by 28 % (the W planes are shared by 256 rows).
-//
-// Synchronisation (cdna guide 5 "Pipelining across barriers"): each wave retires ITS OWN DMA of step c with
-// a COUNTED s_waitcnt vmcnt(n) that leaves the step-(c+1) DMA in flight, then ONE raw s_barrier makes every
-// wave's step-c image visible; fragments are read one phase after that wait; the DMA for step c+2 is issued
-// after the barrier, into the buffer whose last reads (step c-1) every wave completed before arriving.
-// hipcc would drain vmcnt(0) before any LDS read it can see while an LDS-DMA is pending, so the fragment
-// reads are inline-asm ds_read_b128 with their own lgkmcnt wait (+sched_barrier, guide 5.4 rule 18).
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-#define LBBNN_DS_READ128(dst, addr, off) \
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off) : "memory")
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
-
-template <int TO, bool MEAN_ONLY, bool STAGGER = true>
-__global__ __launch_bounds__(512, 2) void lrt_gemm_bf16x3_ring_kernel(const GemmArgs a) {
-    constexpr int TB = 2, WB = 8;
-    constexpr int BN = TO * 16, BM = TB * WB * 16;       // 80 x 256
-    constexpr int NPL = MEAN_ONLY ? 2 : 4;
-    constexpr int XB = BM * 128;
-    constexpr int PB = BN * 64;
-    constexpr int BUFB = XB + NPL * PB;                  // 52 KB (full) / 41.5 KB (mean only)
-    constexpr int NGX = BM / 8, NGW = BN / 16;
-    constexpr int NG = NGX + NPL * NGW;
-    constexpr int NPW = (NG + WB - 1) / WB;              // DMA instructions per step of the "long" waves
-    constexpr int REM = NG % WB;                         // waves < REM issue NPW, the others NPW - 1 (REM == 0: all NPW)
-    extern __shared__ __attribute__((aligned(16))) char smc[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lr = lane & 15, q = lane >> 4;
-    int tox, tby;
-    tile_of_block(tox, tby);
-    const int o0 = tox * BN;
-    const int b0 = tby * BM;
-    const char* const eh = reinterpret_cast<const char*>(a.e_w);
-    const char* const el = eh + (size_t)a.O * a.ld * 2;
-    const char* const vh = reinterpret_cast<const char*>(a.var_w);
-    const char* const vl = vh + (size_t)a.O * a.ld * 2;
-    const char* const zsrc = eh + (size_t)a.I * 2;
-
-    const char* gp[NPW];
-    int adv[NPW], kx[NPW];
-#pragma unroll
-    for (int u = 0; u < NPW; ++u) {
-        const int g = wv + WB * u;
-        if (g < NGX) {
-            const int row = 8 * g + (lane >> 3);
-            const int slot = (lane & 7) ^ swzx(row & 15);
-            gp[u] = reinterpret_cast<const char*>(a.x + (size_t)min(b0 + row, a.B - 1) * a.ldx) + 16 * slot;
-            adv[u] = 128; kx[u] = 4 * slot;
-        } else {
-            const int gw = min(g, NG - 1) - NGX, pl = gw / NGW, row = 16 * (gw % NGW) + (lane >> 2);
-            const int slot = (lane & 3) ^ swz(row >> 2);
-            const char* base = pl == 0 ? eh : (pl == 1 ? el : (pl == 2 ? vh : vl));
-            gp[u] = base + ((size_t)min(o0 + row, a.O - 1) * a.ld) * 2 + 16 * slot;
-            adv[u] = 64; kx[u] = -1;
-        }
-    }
-    const int nsteps = (a.I + BKS - 1) / BKS;
-    const bool has_tail = (a.I % BKS) != 0;
-    auto dma_step = [&](int c) {
-        char* buf = smc + (c % 3) * BUFB;
-        const bool tail = has_tail && c == nsteps - 1;
-#pragma unroll
-        for (int u = 0; u < NPW; ++u) {
-            const int g = wv + WB * u;                   // wave-uniform
-            if (g < NG) {
-                const char* src = gp[u] + (size_t)c * adv[u];
-                if (tail && kx[u] >= 0 && c * BKS + kx[u] >= a.I) src = zsrc;
-                const int loff = g < NGX ? g * 1024 : XB + (g - NGX) * 1024;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(buf + loff), 16, 0, 0);
-            }
-        }
-    };
-    const bool long_wave = (REM == 0) || (wv < REM);
-
-    floatx4 accm[TO][TB], accv[TO][TB];
-#pragma unroll
-    for (int i = 0; i < TO; ++i)
-#pragma unroll
-        for (int j = 0; j < TB; ++j) { accm[i][j] = floatx4{0.f, 0.f, 0.f, 0.f}; accv[i][j] = floatx4{0.f, 0.f, 0.f, 0.f}; }
-
-    // LDS byte addresses of this lane's fragments inside buffer 0 (the dynamic region starts at LDS address 0)
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smc;
-    const int gx = swzx(lr);
-    const uint32_t xa0 = lds0 + (wv * TB * 16 + lr) * 128 + 16 * ((2 * q) ^ gx);
-    const uint32_t xa1 = lds0 + (wv * TB * 16 + lr) * 128 + 16 * ((2 * q + 1) ^ gx);
-    const uint32_t wa = lds0 + XB + lr * 64 + 16 * (q ^ swz(lr >> 2));
-
-    // Fragment registers live across the barrier for the staggered half (see below)
-    u32x4 xr[TB][2], wh[TO], wl[TO], wvh[TO], wvl[TO];
-    bf16x8 xh[TB], xl[TB], sh[TB], sl[TB];
-
-    auto retire = [&](int c) {       // my DMA of step c has landed (step c+1's may stay in flight); then everyone's
-        if (c + 1 < nsteps) { if (long_wave) wait_vmcnt<NPW>(); else wait_vmcnt<(NPW > 1 ? NPW - 1 : 0)>(); }
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-    };
-    auto read_frags = [&](int c) {   // inline asm: invisible to hipcc's LDS-DMA alias waits
-        const uint32_t bo = (uint32_t)((c % 3) * BUFB);
-        const uint32_t x0 = xa0 + bo, x1 = xa1 + bo, w0 = wa + bo;
-        LBBNN_DS_READ128(xr[0][0], x0, 0);
-        LBBNN_DS_READ128(xr[0][1], x1, 0);
-        LBBNN_DS_READ128(xr[1][0], x0, 16 * 128);
-        LBBNN_DS_READ128(xr[1][1], x1, 16 * 128);
-#pragma unroll
-        for (int i = 0; i < TO; ++i) {
-            LBBNN_DS_READ128(wh[i], w0, i * 1024);
-            LBBNN_DS_READ128(wl[i], w0, PB + i * 1024);
-            if (!MEAN_ONLY) {
-                LBBNN_DS_READ128(wvh[i], w0, 2 * PB + i * 1024);
-                LBBNN_DS_READ128(wvl[i], w0, 3 * PB + i * 1024);
-            }
-        }
-    };
-    auto wait_frags = [&]() {        // every destination is named so no use can be scheduled above the wait
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xr[0][0]), "+v"(xr[0][1]), "+v"(xr[1][0]), "+v"(xr[1][1]) :: "memory");
-#pragma unroll
-        for (int i = 0; i < TO; ++i) {
-            asm volatile("" : "+v"(wh[i]), "+v"(wl[i]) :: "memory");
-            if (!MEAN_ONLY) asm volatile("" : "+v"(wvh[i]), "+v"(wvl[i]) :: "memory");
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto convert = [&]() {           // split x and x^2 into bf16 hi/lo
-#pragma unroll
-        for (int j = 0; j < TB; ++j) {
-            const float v[8] = {__uint_as_float(xr[j][0][0]), __uint_as_float(xr[j][0][1]), __uint_as_float(xr[j][0][2]),
-                                __uint_as_float(xr[j][0][3]), __uint_as_float(xr[j][1][0]), __uint_as_float(xr[j][1][1]),
-                                __uint_as_float(xr[j][1][2]), __uint_as_float(xr[j][1][3])};
-            uint32_t ph[4], pl[4], qh[4], ql[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const uint32_t u0 = __float_as_uint(v[2 * t]), u1 = __float_as_uint(v[2 * t + 1]);
-                ph[t] = __builtin_amdgcn_perm(u1, u0, 0x07060302);
-                const floatx2 lo = {v[2 * t] - __uint_as_float(u0 & 0xFFFF0000u), v[2 * t + 1] - __uint_as_float(u1 & 0xFFFF0000u)};
-                pl[t] = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2));
-                if (!MEAN_ONLY) {
-                    const float s0 = v[2 * t] * v[2 * t], s1 = v[2 * t + 1] * v[2 * t + 1];
-                    const uint32_t y0 = __float_as_uint(s0), y1 = __float_as_uint(s1);
-                    qh[t] = __builtin_amdgcn_perm(y1, y0, 0x07060302);
-                    const floatx2 slo = {s0 - __uint_as_float(y0 & 0xFFFF0000u), s1 - __uint_as_float(y1 & 0xFFFF0000u)};
-                    ql[t] = __builtin_bit_cast(uint32_t, __builtin_convertvector(slo, bf16x2));
-                }
-            }
-            xh[j] = __builtin_bit_cast(bf16x8, u32x4{ph[0], ph[1], ph[2], ph[3]});
-            xl[j] = __builtin_bit_cast(bf16x8, u32x4{pl[0], pl[1], pl[2], pl[3]});
-            if (!MEAN_ONLY) {
-                sh[j] = __builtin_bit_cast(bf16x8, u32x4{qh[0], qh[1], qh[2], qh[3]});
-                sl[j] = __builtin_bit_cast(bf16x8, u32x4{ql[0], ql[1], ql[2], ql[3]});
-            }
-        }
-    };
-    auto mfmas = [&]() {             // 6 MFMAs per (o-tile, b-tile)
-#pragma unroll
-        for (int j = 0; j < TB; ++j) {
-#pragma unroll
-            for (int i = 0; i < TO; ++i) {
-                const bf16x8 ah = __builtin_bit_cast(bf16x8, wh[i]);
-                const bf16x8 al = __builtin_bit_cast(bf16x8, wl[i]);
-                accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh[j], accm[i][j], 0, 0, 0);
-                accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xh[j], accm[i][j], 0, 0, 0);
-                accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xl[j], accm[i][j], 0, 0, 0);
-                if (!MEAN_ONLY) {
-                    const bf16x8 bh = __builtin_bit_cast(bf16x8, wvh[i]);
-                    accv[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, sh[j], accv[i][j], 0, 0, 0);
-                    accv[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wvl[i]), sh[j], accv[i][j], 0, 0, 0);
-                    accv[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, sl[j], accv[i][j], 0, 0, 0);
-                }
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    // Stagger (cdna guide, "Two waves per SIMD" item 9): all 8 waves share one barrier per step, so run in
-    // lockstep they ALL read LDS / convert, then ALL issue MFMAs, and the matrix pipe idles during the first
-    // phase (measured: 67 us for barrier + reads + MFMAs alone).  Waves 4-7 (the SIMD partners of waves 0-3)
-    // therefore run half a step late: after the barrier of step c they first issue the MFMAs of step c-1 from
-    // operands kept in registers, THEN read and convert step c -- while waves 0-3 read/convert first and
-    // issue MFMAs second.  Same barriers, same buffers (a buffer is refilled two steps after its last read by
-    // either half), bit-identical results.
-    const bool late = STAGGER && wv >= WB / 2;
-    dma_step(0);
-    if (nsteps > 1) dma_step(1);
-    if (!late) {
-        for (int c = 0; c < nsteps; ++c) {
-            retire(c);
-            read_frags(c);
-            if (c + 2 < nsteps) dma_step(c + 2);                    // into the buffer last read in step c-1
-            wait_frags();
-            convert();
-            mfmas();
-        }
-    } else {
-        for (int c = 0; c < nsteps; ++c) {
-            retire(c);
-            if (c + 2 < nsteps) dma_step(c + 2);
-            if (c > 0) mfmas();                                       // step c-1, operands already in registers
-            read_frags(c);
-            wait_frags();
-            convert();
-        }
-        mfmas();                                                      // step nsteps-1
-    }
-
-    const EpiCtx ec = make_epi_ctx<MEAN_ONLY>(a);
-#pragma unroll
-    for (int i = 0; i < TO; ++i) {
-        const int o = o0 + i * 16 + 4 * q;
-        if (o >= a.O) continue;
-        const OConst oc = load_oconst(a, o);
-#pragma unroll
-        for (int j = 0; j < TB; ++j) {
-            const int b = b0 + (wv * TB + j) * 16 + lr;
-            if (b >= a.B) continue;
-            float res[4];
-            epilogue4<MEAN_ONLY>(a, ec, oc, b, o, accm[i][j], accv[i][j], res);
-            store4(a, ec, b, o, res);
         }
     }
 }
@@ -1048,28 +817,15 @@ int launch_split_cfg(const GemmArgs& a, bool mean_only, hipStream_t s) {
     dim3 grid((a.O + BN - 1) / BN, (a.B + BM - 1) / BM, a.kchunk ? (a.I + a.kchunk - 1) / a.kchunk : 1);
     dim3 block(WB * 64);
     const long nblocks = (long)grid.x * grid.y * grid.z;
-    const size_t l_full = lds_request(2u * (BM * 128 + 4 * BN * 64), nblocks);
-    const size_t l_mean = lds_request(2u * (BM * 128 + 2 * BN * 64), nblocks);
+    const size_t l_full = lds_request(2u * (BM * 128 + 2 * BN * 128), nblocks);
+    const size_t l_mean = lds_request(2u * (BM * 128 + 1 * BN * 128), nblocks);
     if (mean_only) return launch_one(lrt_gemm_bf16x3_kernel<TO, TB, WB, true>, grid, block, l_mean, s, a);
     return launch_one(lrt_gemm_bf16x3_kernel<TO, TB, WB, false>, grid, block, l_full, s, a);
 }
 
 int launch_split(const GemmArgs& a, bool mean_only, hipStream_t s) {
-    // Measured on MI355X at the headline shapes (B=4096, O=1200; I=784 / 1200), layer-1 / layer-2 us:
-    //   128x80 tile, 2 workgroups/CU, 2 LDS buffers (below)        59.5 / 87.2   <- default
-    //   256x80 ring, 1 workgroup/CU, 3 buffers, no stagger          68.7 / 97.1
-    //   256x80 ring + half-step stagger of waves 4-7                64.5 / 90.2
-    // The ring kernel is kept selectable (LBBNN_GEMM_RING=1) and tested: it wins nothing here because the VALU
-    // port (bf16 splitting + MFMA issue) is as loaded as the matrix pipe, not because of exposed DMA latency.
-    const char* ring_env = getenv("LBBNN_GEMM_RING");
-    const bool use_ring = ring_env && ring_env[0] == '1';
-    const long blocks_ring = (long)((a.O + 79) / 80) * ((a.B + 255) / 256);
-    if (blocks_ring >= 128 && use_ring && !a.kchunk) {
-        // 256 x 80 tiles, one 8-wave workgroup per CU, 3-buffer LDS ring
-        dim3 grid((a.O + 79) / 80, (a.B + 255) / 256), block(512);
-        if (mean_only) return launch_one(lrt_gemm_bf16x3_ring_kernel<5, true>, grid, block, 3u * (256 * 128 + 2 * 80 * 64), s, a);
-        return launch_one(lrt_gemm_bf16x3_ring_kernel<5, false>, grid, block, 3u * (256 * 128 + 4 * 80 * 64), s, a);
-    }
+    // 128x80 tile, 2 workgroups/CU, 2 LDS stages.  Variants measured and dropped: 256x80 3-stage ring
+    // (one workgroup/CU), 128x160 with 4 or 8 waves, x split once per tile through LDS, x delivered pre-split.
     const long nz = a.kchunk ? (a.I + a.kchunk - 1) / a.kchunk : 1;
     const long blocks_big = (long)((a.O + 79) / 80) * ((a.B + 127) / 128) * nz;
     if (blocks_big >= 256 && a.B >= 96) return launch_split_cfg<5, 2, 4>(a, mean_only, s);

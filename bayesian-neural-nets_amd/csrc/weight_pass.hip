@@ -145,21 +145,21 @@ __global__ __launch_bounds__(256) void weight_pass_kernel(const WeightPassBatch 
                 if (a.e_w) reinterpret_cast<float4*>(a.e_w + (size_t)o * a.ld)[j] = ew;
                 if (a.var_w) reinterpret_cast<float4*>(a.var_w + (size_t)o * a.ld)[j] = vw;
             } else {
-                // split-precision operands: bf16 hi / lo planes of e_w and of var_w (zero tail kept)
-                uint16_t* const eh = reinterpret_cast<uint16_t*>(a.e_w);
-                uint16_t* const el = eh + (size_t)a.O * a.ld;
+                // split-precision operands: [hi 32 | lo 32] bf16 per 32-k chunk of e_w and of var_w (zero tail kept);
+                // this thread's 4 consecutive k sit inside one chunk
+                const size_t at = split_hi_index((size_t)o, 4 * j, a.ld);
                 uint2 hi, lo;
                 split4(ew, hi, lo);
                 if (a.e_w) {
-                    reinterpret_cast<uint2*>(eh + (size_t)o * a.ld)[j] = hi;
-                    reinterpret_cast<uint2*>(el + (size_t)o * a.ld)[j] = lo;
+                    uint16_t* const e = reinterpret_cast<uint16_t*>(a.e_w);
+                    *reinterpret_cast<uint2*>(e + at) = hi;
+                    *reinterpret_cast<uint2*>(e + at + kSplitLoOffset) = lo;
                 }
                 if (a.var_w) {
-                    uint16_t* const vh = reinterpret_cast<uint16_t*>(a.var_w);
-                    uint16_t* const vl = vh + (size_t)a.O * a.ld;
+                    uint16_t* const v = reinterpret_cast<uint16_t*>(a.var_w);
                     split4(vw, hi, lo);
-                    reinterpret_cast<uint2*>(vh + (size_t)o * a.ld)[j] = hi;
-                    reinterpret_cast<uint2*>(vl + (size_t)o * a.ld)[j] = lo;
+                    *reinterpret_cast<uint2*>(v + at) = hi;
+                    *reinterpret_cast<uint2*>(v + at + kSplitLoOffset) = lo;
                 }
             }
         }

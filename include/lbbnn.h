@@ -42,7 +42,7 @@ extern "C" {
 /* GEMM flags */
 #define LBBNN_F_RELU 0x1       /* fuse F.relu on the output (LBBNN-GP-MF-LRT.py:208-209)      */
 #define LBBNN_F_MEAN_ONLY 0x2  /* posterior-mean branch: out = x.e_w^T + b (…LRT.py:178-180)  */
-#define LBBNN_F_SPLIT16 0x4    /* split-precision MFMA path (bf16x3 mean, fp16 variance)      */
+#define LBBNN_F_SPLIT16 0x4    /* split-precision MFMA path: bf16x3 products, operands hi + lo  */
 #define LBBNN_F_LOG_SOFTMAX 0x8 /* fuse F.log_softmax(dim=1) on the output; O <= 16 only (…LRT.py:210) */
 
 /* Philox stream ids (third counter word) -- one per kind of draw, per layer (stream = kind*64+layer) */
@@ -84,8 +84,8 @@ int lbbnn_operand_ld(int I);
  * Outputs: e_w, var_w: GEMM operands [O][ld] (ld = lbbnn_operand_ld(I), zero-filled tail),
  *          either may be NULL.  kl_rows (O): per-row sum of the KL integrand (NULL = skip).
  *          act_mu, act_var (O) (NULL = skip; need z_kl and r0_c).  bias_var (O) = softplus(bias_rho)^2.
- *          With LBBNN_F_SPLIT16, e_w is written as two bf16 planes (hi, lo) and var_w as scaled fp16;
- *          see DESIGN.md "operand formats".
+ *          With LBBNN_F_SPLIT16 each operand row (the same 4*ld bytes) holds w = hi + lo in bf16: per 32-k chunk
+ *          32 hi values (64 B) followed by the 32 lo values (64 B); see DESIGN.md "Data layout".
  */
 int lbbnn_weight_pass(const float* mu, const float* rho, const float* lambdal,
                       const float* z_fwd, const float* z_kl, const float* r0_c,
@@ -262,7 +262,7 @@ int lbbnn_forward_finish(uint64_t* rng, uint64_t advance, const float* const* kl
  *             + Gaussian.log_prob(bias) :89-92
  * The Gamma draws tau_w (1) / tau_b (O) of :141 are inputs (drawn by the host wrapper with torch).
  * exact bits (the reference's `.exact` switches, :559-627): 1 weight_prior, 2 bias_prior, 4 gamma_prior, 8 gamma.
- * Outputs: w_out = GEMM operand [O][ld] (fp32, or bf16 hi/lo planes with LBBNN_F_SPLIT16) for
+ * Outputs: w_out = GEMM operand [O][ld] (fp32, or the split bf16 hi|lo layout with LBBNN_F_SPLIT16) for
  *          lbbnn_lrt_gemm(LBBNN_F_MEAN_ONLY) = F.linear (:255); bias_out (O); log_prior, log_q (1 float each);
  *          rows: workspace of 4*O floats.  eps_w (O,I) / eps_b (O) NULL => Philox (streams EPS_W / EPS_B).
  */
@@ -301,7 +301,7 @@ int lbbnn_vd_operands(const float* theta, void* e_w, void* var_w, int ld, int I,
  *
  * lbbnn_transpose_operand: dst[c][r] = src[r][c] (squared when `square`) for src (R,C) with row stride
  * lds_src, written as a GEMM operand [C][ld] (ld = lbbnn_operand_ld(R), zero tail; fp32 or, with
- * LBBNN_F_SPLIT16, bf16 hi/lo planes).  With it every backward product is an "x . operand^T" GEMM on the
+ * LBBNN_F_SPLIT16, the split bf16 hi|lo layout).  With it every backward product is an "x . operand^T" GEMM on the
  * same kernels as the forward:
  *   dX  = G_m . W_m + 2 x (.) (G_v . W_v)      operands W_m^T, W_v^T          (K = O)
  *   dW_m = G_m^T . x ,  dW_v = G_v^T . x^2     operands x^T, (x^2)^T          (K = B)
@@ -477,7 +477,7 @@ int lbbnn_adam_step(const lbbnn_adam_list_t* list, float lr, float beta1, float 
 /* lbbnn_matmul_splitk -- split-K form of the mean-only bf16x3 product for long contractions with few output tiles
  * (the weight gradients dW = G^T.x: K = batch):  out[z] (B,O; row stride ldo; slab stride B*ldo) =
  * x[:, Kz] . w[:, Kz]^T with Kz = [z*kchunk, min(I, (z+1)*kchunk)), z < ceil(I / kchunk); kchunk a multiple of 32.
- * w_op: LBBNN_F_SPLIT16 operand planes of lbbnn_transpose_operand / lbbnn_weight_pass.  The consumer adds the slabs
+ * w_op: LBBNN_F_SPLIT16 operand of lbbnn_transpose_operand / lbbnn_weight_pass.  The consumer adds the slabs
  * (lbbnn_weight_pass_backward does, in a fixed order => deterministic).
  */
 int lbbnn_matmul_splitk(const float* x, int ldx, const void* w_op, int ld, float* out, int ldo,
