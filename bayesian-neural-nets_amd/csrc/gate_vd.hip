@@ -16,7 +16,7 @@ __device__ __forceinline__ uint32_t bf16_rne_bits(float f) {
 // store one operand value at [o][i] either as fp32 or in the split bf16 hi|lo layout
 __device__ __forceinline__ void store_operand(void* base, int split, size_t O, int ld, int o, int i, float v) {
     if (!split) { static_cast<float*>(base)[(size_t)o * ld + i] = v; return; }
-    uint16_t* const w = static_cast<uint16_t*>(base);           // [hi 32 | lo 32] per 32-k chunk (lbbnn_device.h)
+    uint16_t* const w = static_cast<uint16_t*>(base);           // split hi|lo layout (lbbnn_device.h)
     const size_t at = split_hi_index((size_t)o, i, ld);
     const uint32_t h = bf16_rne_bits(v);
     w[at] = (uint16_t)h;

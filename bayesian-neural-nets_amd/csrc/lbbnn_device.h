@@ -79,14 +79,16 @@ __host__ __device__ __forceinline__ int pad64(int n) { return (n + 63) & ~63; }
 
 // ------------------------------------------------------------------------------------------ split (bf16x3) operand layout
 // LBBNN_F_SPLIT16 operands hold w = hi + lo (both bf16) as rows of 2*ld bf16 (= the 4*ld bytes of the fp32 row they
-// replace): for every 32-k chunk c, 32 hi values (64 B) followed by the 32 lo values (64 B).  One 128-B line thus
-// carries everything the GEMM needs from a row for one K step, and an LDS-DMA piece is 8 rows x 128 B (measured: the
-// delivery-only build of the GEMM takes 48.9 us with such pieces against 58.0 us with 16 rows x 64 B from two separate
-// hi / lo planes).  ld is a multiple of 32; the tail k in [I, ld) is zero in both parts.
+// replace).  Per 32-k chunk one 128-B line of eight 16-B units: unit 2g = hi of k in [8g, 8g+8), unit 2g+1 = lo of the
+// same k (g = 0..3) -- an MFMA lane (k group g) needs exactly units 2g and 2g+1, the access shape of the fp32 x rows, so
+// one LDS swizzle serves x and weights conflict-free.  One line carries everything the GEMM needs from a row for one K
+// step, and an LDS-DMA piece is 8 rows x 128 B (measured: the delivery-only build of the GEMM takes 48.9 us with such
+// pieces against 58.0 us with 16 rows x 64 B from two separate hi / lo planes).  ld is a multiple of 32; the tail k in
+// [I, ld) is zero in both parts.
 __host__ __device__ __forceinline__ size_t split_hi_index(size_t row, int k, int ld) {
-    return row * (2 * (size_t)ld) + (size_t)(k >> 5) * 64 + (size_t)(k & 31);
+    return row * (2 * (size_t)ld) + (size_t)(k >> 5) * 64 + (size_t)((k >> 3) & 3) * 16 + (size_t)(k & 7);
 }
-constexpr int kSplitLoOffset = 32;      // lo part of the same k: +32 bf16
+constexpr int kSplitLoOffset = 8;       // lo part of the same k: the next 16-B unit (+8 bf16)
 
 // ------------------------------------------------------------------------------------------ kernel arguments as memory
 // A by-value kernel-argument struct indexed with a RUNTIME index (bt.l[blockIdx.y], a.zf.u[t]) is copied to scratch

@@ -469,13 +469,14 @@ __global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_f32_dma_kernel(const Gemm
 // registers: xh = bits & 0xFFFF0000 (truncation, so xl = x - xh is exact), xl -> bf16 RNE; same for x^2
 // (v_and, v_sub, v_perm, v_cvt_pk, v_mul: ~56 VALU per 8 values, hidden under the 60 MFMAs of the step).
 // Weight operands come from lbbnn_weight_pass(LBBNN_F_SPLIT16) in the split layout of lbbnn_device.h: per row and
-// 32-k chunk one 128-B line [hi 64 B | lo 64 B], e_w and var_w each.
+// 32-k chunk one 128-B line of units (hi k0-7 | lo k0-7 | hi k8-15 | lo k8-15 | ...), e_w and var_w each.
 //
 // K step = 32.  LDS image per step: X 128 rows x 128 B (fp32) | E 80 rows x 128 B | V 80 rows x 128 B, all filled by
 // LDS-DMA in 1-KiB pieces of 8 rows x 128 B (delivery-only build: 48.9 us against 58.0 us with 16 x 64-B pieces
 // from separate hi / lo planes).  Conflict-free swizzle on the source side, the same for all three regions:
 // 16-B slot s of row r is stored at slot s ^ G(r & 15), G(r) = ((r>>1)&3)*2 + ((r>>3)&1)  (a ds_read_b128 group of
-// 16 lanes reads one logical slot of 16 consecutive rows: (r&1)*8 + (s ^ G(r)) is a permutation of 0..15).
+// 16 lanes -- the hardware's, e.g. lanes {0-3, 12-15, 20-27} -- reads units 2q / 2q+1 of 16 rows conflict-free;
+// SQ_LDS_BANK_CONFLICT = 0.  A first weight layout [hi 64 B | lo 64 B] read as units q / 4+q showed 2-way conflicts.)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float floatx2 __attribute__((ext_vector_type(2)));
@@ -508,7 +509,7 @@ __global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_bf16x3_kernel(const GemmA
     const char* const eb = reinterpret_cast<const char*>(a.e_w);       // rows of 4*ld bytes: per 32-k chunk [hi | lo]
     const char* const vb = reinterpret_cast<const char*>(a.var_w);
     // 16 B of zeros for x lanes past I in the K tail: the zero-filled hi tail of row 0's last chunk
-    const char* const zsrc = eb + (size_t)(a.I >> 5) * 128 + (size_t)(a.I & 31) * 2;
+    const char* const zsrc = eb + split_hi_index(0, a.I, a.ld) * 2;
 
     const char* gp[NPW];      // per-lane source (byte pointer) of DMA group wv + WB*u at K step 0
     int adv[NPW];             // bytes per K step: 128 (x) or 64 (weights)
@@ -523,7 +524,7 @@ __global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_bf16x3_kernel(const GemmA
             adv[u] = 128; kx[u] = 4 * slot;
         } else {
             const int gw = g - NGX, reg = gw / NGW, row = 8 * (gw % NGW) + (lane >> 3);
-            const int slot = (lane & 7) ^ swzx(row & 15);        // slots 0-3 = hi, 4-7 = lo; same swizzle as the x rows
+            const int slot = (lane & 7) ^ swzx(row & 15);        // units 2g = hi, 2g+1 = lo of k group g; same swizzle as the x rows
             const char* base = reg == 0 ? eb : vb;
             gp[u] = base + (size_t)min(o0 + row, a.O - 1) * a.ld * 4 + (size_t)(kbeg >> 5) * 128 + 16 * slot;
             adv[u] = 128; kx[u] = -1;
@@ -556,8 +557,8 @@ __global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_bf16x3_kernel(const GemmA
     const int gx = swzx(lr);
     const int xo0 = (wv * TB * 16 + lr) * 128 + 16 * ((2 * q) ^ gx);
     const int xo1 = (wv * TB * 16 + lr) * 128 + 16 * ((2 * q + 1) ^ gx);
-    const int woh = XB + lr * 128 + 16 * (q ^ gx);           // hi part of weight row lr (slot q), lo part: slot 4 + q
-    const int wol = XB + lr * 128 + 16 * ((4 + q) ^ gx);
+    const int woh = XB + lr * 128 + 16 * ((2 * q) ^ gx);     // weight row lr: hi of this lane's k group = unit 2q, lo = unit 2q+1
+    const int wol = XB + lr * 128 + 16 * ((2 * q + 1) ^ gx);
 
     float4 xr[TB][2];
     uint4 wh[TO], wl[TO], wvh[TO], wvl[TO];

@@ -145,8 +145,8 @@ __global__ __launch_bounds__(256) void weight_pass_kernel(const WeightPassBatch 
                 if (a.e_w) reinterpret_cast<float4*>(a.e_w + (size_t)o * a.ld)[j] = ew;
                 if (a.var_w) reinterpret_cast<float4*>(a.var_w + (size_t)o * a.ld)[j] = vw;
             } else {
-                // split-precision operands: [hi 32 | lo 32] bf16 per 32-k chunk of e_w and of var_w (zero tail kept);
-                // this thread's 4 consecutive k sit inside one chunk
+                // split-precision operands (layout: lbbnn_device.h): this thread's 4 consecutive k are half of one 16-B
+                // hi unit, the matching lo values sit one unit further; zero tail kept
                 const size_t at = split_hi_index((size_t)o, 4 * j, a.ld);
                 uint2 hi, lo;
                 split4(ew, hi, lo);

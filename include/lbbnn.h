@@ -84,8 +84,9 @@ int lbbnn_operand_ld(int I);
  * Outputs: e_w, var_w: GEMM operands [O][ld] (ld = lbbnn_operand_ld(I), zero-filled tail),
  *          either may be NULL.  kl_rows (O): per-row sum of the KL integrand (NULL = skip).
  *          act_mu, act_var (O) (NULL = skip; need z_kl and r0_c).  bias_var (O) = softplus(bias_rho)^2.
- *          With LBBNN_F_SPLIT16 each operand row (the same 4*ld bytes) holds w = hi + lo in bf16: per 32-k chunk
- *          32 hi values (64 B) followed by the 32 lo values (64 B); see DESIGN.md "Data layout".
+ *          With LBBNN_F_SPLIT16 each operand row (the same 4*ld bytes) holds w = hi + lo in bf16: per 32-k chunk one
+ *          128-B line of 16-B units, unit 2g = hi of k in [8g, 8g+8), unit 2g+1 = lo of the same k; see DESIGN.md
+ *          "Data layout".  The format is produced and consumed only by this library.
  */
 int lbbnn_weight_pass(const float* mu, const float* rho, const float* lambdal,
                       const float* z_fwd, const float* z_kl, const float* r0_c,
