@@ -107,6 +107,20 @@ __device__ __forceinline__ float softplus_ref(float rho) { return log1pf(expf(rh
 // alpha = 1/(1+exp(-lambda)) (LBBNN-GP-MF-LRT.py:167)
 __device__ __forceinline__ float sigmoid_ref(float l) { return 1.0f / (1.0f + expf(-l)); }
 
+// Hardware-transcendental forms (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp each) for the latency-bound tails where the
+// libm sequences (30-50 instructions each) are the cost: log1p(exp(rho)) by a 5-term series while exp(rho) < 0.04,
+// tanh through one exp.  Absolute errors ~1e-7, far inside the 1e-4 contract of the sums they feed.
+__device__ __forceinline__ float softplus_fast(float rho) {
+    const float y = __expf(rho);
+    if (y < 0.04f) return y * (1.f + y * (-0.5f + y * (0.33333334f + y * (-0.25f + y * 0.2f))));
+    return log1pf(y);
+}
+__device__ __forceinline__ float tanh_fast(float x) {
+    const float t = __expf(-2.f * fabsf(x));
+    const float r = (1.f - t) * __frcp_rn(1.f + t);
+    return copysignf(r, x);
+}
+
 // ------------------------------------------------------------------------------------------ Philox4x32-10
 struct Philox4 { uint32_t x, y, z, w; };
 

@@ -456,48 +456,97 @@ __device__ __forceinline__ double group_sum(double v, double (*scr)[4], int g, i
     __syncthreads();
     return (scr[g][0] + scr[g][1]) + (scr[g][2] + scr[g][3]);
 }
+// three sums behind one pair of barriers
+__device__ __forceinline__ void group_sum3(double& a, double& b, double& c, double (*scr)[3][4], int g, int lane, int w) {
+    a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+    __syncthreads();
+    if (lane == 0) { scr[g][0][w] = a; scr[g][1][w] = b; scr[g][2][w] = c; }
+    __syncthreads();
+    a = (scr[g][0][0] + scr[g][0][1]) + (scr[g][0][2] + scr[g][0][3]);
+    b = (scr[g][1][0] + scr[g][1][1]) + (scr[g][1][2] + scr[g][1][3]);
+    c = (scr[g][2][0] + scr[g][2][1]) + (scr[g][2][2] + scr[g][2][3]);
+}
 
-__global__ __launch_bounds__(LBBNN_MAX_LAYERS * 256) void kl_finalize_all_kernel(const FinalizeAllArgs fa) {
+__global__ __launch_bounds__(LBBNN_MAX_LAYERS * 256) void kl_finalize_all_kernel(const FinalizeAllArgs fa, int staged) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ double scr[LBBNN_MAX_LAYERS][4];
+    __shared__ double scr3[LBBNN_MAX_LAYERS][3][4];
     __shared__ float s_kl[LBBNN_MAX_LAYERS];
     const LBBNN_CONST_AS FinalizeAllArgs& A = *kernarg_as<FinalizeAllArgs>();
     const int g = threadIdx.x >> 8, t = threadIdx.x & 255, lane = t & 63, w = t >> 6;
+    // ---- every input vector of every layer is prefetched into LDS by ALL waves (LDS-DMA, one wait): the dependent
+    // global loads of the loops below were what made the first single-launch version slower than three workgroups
+    const float *klr[LBBNN_MAX_LAYERS], *bmu[LBBNN_MAX_LAYERS], *brho[LBBNN_MAX_LAYERS], *amu[LBBNN_MAX_LAYERS];
+    const float *avar[LBBNN_MAX_LAYERS], *eact[LBBNN_MAX_LAYERS], *b1[LBBNN_MAX_LAYERS], *b2[LBBNN_MAX_LAYERS];
+    {
+        float* p = sm;
+#pragma unroll
+        for (int li = 0; li < LBBNN_MAX_LAYERS; ++li) {
+            const LBBNN_CONST_AS FinalizeArgs& a = A.l[li];
+            const bool on = li < A.n && A.active[li] != 0, mnf = on && a.scal != nullptr;
+            klr[li] = a.kl_rows; bmu[li] = a.bias_mu; brho[li] = a.bias_rho; amu[li] = a.act_mu; avar[li] = a.act_var;
+            eact[li] = a.eps_act; b1[li] = a.r0_b1; b2[li] = a.r0_b2;
+            if (!staged || !on) continue;
+            const int PO = pad64(a.O), PI = pad64(a.I);
+            dma_stage(p, a.kl_rows, a.O); klr[li] = p; p += PO;
+            dma_stage(p, a.bias_mu, a.O); bmu[li] = p; p += PO;
+            dma_stage(p, a.bias_rho, a.O); brho[li] = p; p += PO;
+            if (mnf) {
+                dma_stage(p, a.act_mu, a.O); amu[li] = p; p += PO;
+                dma_stage(p, a.act_var, a.O); avar[li] = p; p += PO;
+                if (a.eps_act) { dma_stage(p, a.eps_act, a.O); eact[li] = p; p += PO; }
+                dma_stage(p, a.r0_b1, a.I); b1[li] = p; p += PI;
+                dma_stage(p, a.r0_b2, a.I); b2[li] = p; p += PI;
+            }
+        }
+    }
     const LBBNN_CONST_AS FinalizeArgs& a = A.l[g];
     const bool on = g < A.n && A.active[g] != 0;
     const bool mnf = on && a.scal != nullptr;
     uint64_t seed = 0, offs = 0;
     if (mnf && !a.eps_act) { seed = a.rng[0]; offs = a.rng[1]; }
+    const float zb = mnf ? a.scal[3] : 0.f, ldq = mnf ? a.scal[0] : 0.f, lq0 = mnf ? a.scal[1] : 0.f, ldr = mnf ? a.scal[2] : 0.f;
+    if (staged) dma_wait_all();
+    // select this group's vectors (constant-index chain: no dynamic indexing of the pointer arrays)
+    const float *Gklr = klr[0], *Gbmu = bmu[0], *Gbrho = brho[0], *Gamu = amu[0], *Gavar = avar[0], *Geact = eact[0], *Gb1 = b1[0], *Gb2 = b2[0];
+#pragma unroll
+    for (int li = 1; li < LBBNN_MAX_LAYERS; ++li)
+        if (g == li) { Gklr = klr[li]; Gbmu = bmu[li]; Gbrho = brho[li]; Gamu = amu[li]; Gavar = avar[li]; Geact = eact[li]; Gb1 = b1[li]; Gb2 = b2[li]; }
+    // this single workgroup is issue-bound (12 waves on one CU): hardware exp / log / rcp forms, see lbbnn_device.h
+    const float log_sp = on ? __logf(a.bias_sigma_prior) : 0.f;
+    const float inv_2sp2 = on ? 1.f / (2.f * a.bias_sigma_prior * a.bias_sigma_prior) : 0.f;
     double s_rows = 0.0, s_bias = 0.0, s_act = 0.0;
     if (on)
-        for (int o = t; o < a.O; o += 256) {
-            s_rows += (double)a.kl_rows[o];
-            const float sb = softplus_ref(a.bias_rho[o]);
-            const float d = a.bias_mu[o] - a.bias_mu_prior;
-            const float sp = a.bias_sigma_prior;
-            s_bias += (double)(logf(sp / sb) - 0.5f + (sb * sb + d * d) / (2.f * sp * sp));   // …LRT.py:185-186
-            if (mnf) {
-                float e;
-                if (a.eps_act) e = a.eps_act[o];
-                else { float n[4]; philox_normal4(seed, offs, LBBNN_STREAM_EPS_ACT * 64u + a.layer, (uint64_t)(o >> 2), 0u, n); e = n[o & 3]; }
-                s_act += (double)tanhf(a.act_mu[o] + sqrtf(a.act_var[o]) * e);               // …MNF.py:218-219
+        for (int o4 = 4 * t; o4 < a.O; o4 += 1024) {                  // 4 consecutive outputs share one Philox call
+            float n[4] = {0.f, 0.f, 0.f, 0.f};
+            if (mnf && !a.eps_act) philox_normal4(seed, offs, LBBNN_STREAM_EPS_ACT * 64u + a.layer, (uint64_t)(o4 >> 2), 0u, n);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int o = o4 + k;
+                if (o >= a.O) break;
+                s_rows += (double)Gklr[o];
+                const float sb = softplus_fast(Gbrho[o]);
+                const float d = Gbmu[o] - a.bias_mu_prior;
+                s_bias += (double)((log_sp - __logf(sb)) - 0.5f + (sb * sb + d * d) * inv_2sp2);  // …LRT.py:185-186
+                if (mnf) {
+                    const float e = a.eps_act ? Geact[o] : n[k];
+                    s_act += (double)tanh_fast(Gamu[o] + sqrtf(Gavar[o]) * e);                   // …MNF.py:218-219
+                }
             }
         }
-    s_rows = group_sum(s_rows, scr, g, lane, w);
-    s_bias = group_sum(s_bias, scr, g, lane, w);
-    s_act = group_sum(s_act, scr, g, lane, w);
+    group_sum3(s_rows, s_bias, s_act, scr3, g, lane, w);
     double kl = s_bias + s_rows;
     double s_rb = 0.0;
     if (mnf) {
         const float m = (float)(s_act / (double)a.O);       // outer(b, act).mean(-1) = b * mean(act)   :220-221
-        const float zb = a.scal[3];
         for (int i = t; i < a.I; i += 256) {
-            const float mr = a.r0_b1[i] * m, lv = a.r0_b2[i] * m;
+            const float mr = Gb1[i] * m, lv = Gb2[i] * m;
             const float d = zb - mr;
-            s_rb += (double)(-0.5f * 1.1447298858494002f - 0.5f * lv - 0.5f * ((d * d) / expf(lv)));  // :223-224
+            s_rb += (double)(-0.5f * 1.1447298858494002f - 0.5f * lv - 0.5f * ((d * d) * __expf(-lv)));  // :223-224
         }
     }
     s_rb = group_sum(s_rb, scr, g, lane, w);
-    if (mnf) kl += (-(double)a.scal[0] + (double)a.scal[1]) - ((double)a.scal[2] + s_rb);           // :215,:225,:235
+    if (mnf) kl += (-(double)ldq + (double)lq0) - ((double)ldr + s_rb);                             // :215,:225,:235
     if (t == 0) {
         s_kl[g] = on ? (float)kl : 0.f;
         if (on && a.kl_layer) *a.kl_layer = (float)kl;
@@ -611,7 +660,18 @@ int launch_kl_finalize_all(const FinalizeArgs* a, const int* active, int n, uint
     FinalizeAllArgs fa;
     for (int i = 0; i < LBBNN_MAX_LAYERS; ++i) { fa.l[i] = i < n ? a[i] : FinalizeArgs{}; fa.active[i] = i < n ? active[i] : 0; }
     fa.n = n; fa.rng = rng; fa.advance = advance; fa.total = kl_total;
-    hipLaunchKernelGGL(kl_finalize_all_kernel, dim3(1), dim3(n * 256), 0, s, fa);
+    size_t need = 0;
+    for (int i = 0; i < n; ++i)
+        if (active[i]) need += (size_t)(6 * pad64(a[i].O) + 2 * pad64(a[i].scal ? a[i].I : 1)) * sizeof(float);
+    const int staged = need <= (size_t)kFlowLdsBudget ? 1 : 0;
+    static size_t raised = 0;                        // dynamic-LDS limit of the function: raise once per size
+    if (staged && need > 64 * 1024 && need > raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kl_finalize_all_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+        if (e != hipSuccess) return (int)e;
+        raised = need;
+    }
+    hipLaunchKernelGGL(kl_finalize_all_kernel, dim3(1), dim3(n * 256), staged ? need : 0, s, fa, staged);
     return (int)hipGetLastError();
 }
 

@@ -55,15 +55,6 @@ __device__ __forceinline__ void split4(const float4 w, uint2& hi, uint2& lo) {
 // removed 14.6 -- the floor is the per-workgroup load -> reduce -> store latency of 2410 short workgroups.  A version
 // walking ~4 rows per workgroup with the next row's loads in flight was measured at 29.5 us (fewer workgroups in
 // flight per CU cost more than the prefetch saves) and dropped.
-__device__ __forceinline__ float softplus_fast(float rho) {
-    const float y = __expf(rho);
-    if (y < 0.04f) {
-        // log1p(y) = y - y^2/2 + y^3/3 - y^4/4 + y^5/5
-        return y * (1.f + y * (-0.5f + y * (0.33333334f + y * (-0.25f + y * 0.2f))));
-    }
-    return log1pf(y);
-}
-
 __device__ __forceinline__ Elem weight_elem(float mu, float rho, float lam, float zf, float zk, float rc,
                                             bool want_kl, bool want_act, const WeightPassArgs& a) {
     Elem e;
