@@ -511,23 +511,31 @@ __global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_bf16x3_kernel(const GemmA
     // 16 B of zeros for x lanes past I in the K tail: the zero-filled hi tail of row 0's last chunk
     const char* const zsrc = eb + split_hi_index(0, a.I, a.ld) * 2;
 
-    const char* gp[NPW];      // per-lane source (byte pointer) of DMA group wv + WB*u at K step 0
-    int adv[NPW];             // bytes per K step: 128 (x) or 64 (weights)
-    int kx[NPW];              // first k of this lane's x slot (for the tail redirect), or -1
+    // LDS-DMA through buffer descriptors (buffer_load_dwordx4 ... offen lds): the per-lane byte offset of a piece is
+    // computed once, the K step advances a SCALAR offset (x and weights both move 128 B per step), and an x lane past
+    // I in the K tail is pointed out of range -- the descriptor's bounds check returns zeros.  (The flat-pointer form
+    // needed a 64-bit VALU add per piece and step plus a zero-source redirect.)
+    const unsigned xbytes = (unsigned)min((size_t)0x7FFFFFF0u, ((size_t)(a.B - 1) * a.ldx + a.I) * 4);
+    const unsigned wbytes = (unsigned)min((size_t)0x7FFFFFF0u, (size_t)a.O * a.ld * 4);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc((void*)a.e_w, 0, (int)wbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(MEAN_ONLY ? a.e_w : a.var_w), 0, (int)wbytes, 0x00020000);
+    (void)eb; (void)vb; (void)zsrc;
+    int gv[NPW];              // per-lane byte offset of DMA piece wv + WB*u at this workgroup's first K step
+    int kx[NPW];              // first k of this lane's x slot (for the tail), or -1
 #pragma unroll
     for (int u = 0; u < NPW; ++u) {
         const int g = wv + WB * u;
         if (g < NGX) {
             const int row = 8 * g + (lane >> 3);
             const int slot = (lane & 7) ^ swzx(row & 15);
-            gp[u] = reinterpret_cast<const char*>(a.x + (size_t)min(b0 + row, a.B - 1) * a.ldx + kbeg) + 16 * slot;
-            adv[u] = 128; kx[u] = 4 * slot;
+            gv[u] = (int)(((size_t)min(b0 + row, a.B - 1) * a.ldx + kbeg) * 4) + 16 * slot;
+            kx[u] = 4 * slot;
         } else {
-            const int gw = g - NGX, reg = gw / NGW, row = 8 * (gw % NGW) + (lane >> 3);
+            const int gw = g - NGX, row = 8 * (gw % NGW) + (lane >> 3);
             const int slot = (lane & 7) ^ swzx(row & 15);        // units 2g = hi, 2g+1 = lo of k group g; same swizzle as the x rows
-            const char* base = reg == 0 ? eb : vb;
-            gp[u] = base + (size_t)min(o0 + row, a.O - 1) * a.ld * 4 + (size_t)(kbeg >> 5) * 128 + 16 * slot;
-            adv[u] = 128; kx[u] = -1;
+            gv[u] = (int)((size_t)min(o0 + row, a.O - 1) * a.ld * 4) + (kbeg >> 5) * 128 + 16 * slot;
+            kx[u] = -1;
         }
     }
     const int nsteps = (Iloc + BKS - 1) / BKS;
@@ -538,11 +546,13 @@ __global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_bf16x3_kernel(const GemmA
         for (int u = 0; u < NPW; ++u) {
             const int g = wv + WB * u;                   // wave-uniform
             if (g < NG) {
-                const char* src = gp[u] + (size_t)c * adv[u];
-                if (tail && kx[u] >= 0 && c * BKS + kx[u] >= Iloc) src = zsrc;
+                int vo = gv[u];
+                if (tail && kx[u] >= 0 && c * BKS + kx[u] >= Iloc) vo = 0x7FFFFFF0;     // out of range => zeros
                 const int loff = g < NGX ? g * 1024 : XB + (g - NGX) * 1024;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(buf + loff), 16, 0, 0);
+                auto* dst = (__attribute__((address_space(3))) void*)(buf + loff);
+                if (g < NGX)                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, dst, 16, vo, c * 128, 0, 0);
+                else if (g - NGX < NGW)      __builtin_amdgcn_raw_ptr_buffer_load_lds(re, dst, 16, vo, c * 128, 0, 0);
+                else                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, dst, 16, vo, c * 128, 0, 0);
             }
         }
     };
@@ -869,6 +879,8 @@ static int lrt_gemm_impl(const float* x, int ldx, const void* e_w, const void* v
         // split-precision operands: aligned x, I % 8 == 0, >= 16 B of zero tail when there is a K tail, O > 16
         const bool tail = (I % BKS) != 0;
         if (!xvec || (I & 7) || O <= 16 || (tail && (ld - I) < 8)) return LBBNN_E_ALIGN;
+        // the split kernel addresses x and the operands through 32-bit buffer offsets
+        if (((size_t)(B - 1) * ldx + I) * 4 >= 0x7FFFFFF0u || (size_t)O * ld * 4 >= 0x7FFFFFF0u) return LBBNN_E_SHAPE;
         return launch_split(a, mean_only, s);
     }
     if (O <= 16) {

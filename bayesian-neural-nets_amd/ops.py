@@ -43,8 +43,9 @@ def get_precision() -> str:
 
 
 def split_eligible(I: int, O: int) -> bool:
-    """Shapes the split-precision kernels accept (see lbbnn_lrt_gemm, LBBNN_F_SPLIT16)."""
-    return O > 16 and I % 8 == 0 and (I % 32 == 0 or operand_ld(I) - I >= 8)
+    """Shapes the split-precision kernels accept (see lbbnn_lrt_gemm, LBBNN_F_SPLIT16); operands and x must also stay
+    under 2 GiB each (32-bit buffer offsets), which the callers' batch sizes do by orders of magnitude."""
+    return O > 16 and I % 8 == 0 and (I % 32 == 0 or operand_ld(I) - I >= 8) and O * operand_ld(I) * 4 < 0x7FFFFFF0
 
 
 def _stream() -> int:
