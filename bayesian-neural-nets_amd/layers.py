@@ -231,7 +231,8 @@ class _BayesLinearBase(nn.Module):
         """Use the split-precision (bf16x3) operands/kernels for this layer call?"""
         if ops.get_precision() != "bf16x3" or not ops.split_eligible(self.in_features, self.out_features):
             return False
-        if x is not None and (x.stride(0) % 4 != 0 or x.data_ptr() % 16 != 0 or x.stride(1) != 1):
+        if x is not None and (x.stride(0) % 4 != 0 or x.data_ptr() % 16 != 0 or x.stride(1) != 1
+                              or x.shape[0] * x.stride(0) * 4 >= 0x7FFFFFF0):      # 32-bit buffer offsets in the split kernel
             return False
         return True
 
