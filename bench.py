@@ -135,11 +135,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # LBBNN_BENCH_BACKEND=gloo + fewer devices than ranks: rehearsal of the N-rank flow on a 1-GPU box (ranks share the
+    # card); the driver's runs use nccl (= RCCL) with one rank per GPU
+    backend = os.environ.get("LBBNN_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if (backend == "nccl" or local_rank < ndev) else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     import bnn_amd
     from bnn_amd import ops
