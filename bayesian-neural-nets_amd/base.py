@@ -14,7 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _grad, _lib, ops
-from .distributions import Bernoulli, Gaussian, TEMPER_PRIOR
+from .distributions import Bernoulli, Gaussian, TEMPER_PRIOR  # noqa: F401  (TEMPER_PRIOR re-exported: the reference scripts read it here)
 
 _ids = itertools.count(32)
 

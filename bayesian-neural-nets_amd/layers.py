@@ -18,7 +18,6 @@ r_flow_type=`` (module globals in the reference, LBBNN-GP-MF-MNF.py:46-47), and 
 There is no CPU path: parameters may be *constructed* on CPU (as the reference does) but
 ``forward`` needs them on a HIP device.
 """
-import ctypes
 import itertools
 from typing import Dict, Optional
 

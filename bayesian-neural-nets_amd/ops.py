@@ -5,7 +5,7 @@ enqueues on torch's current stream and returns without synchronising.  Nothing h
 on the host; a CPU tensor or a missing library raises.
 """
 import ctypes
-from typing import List, Optional, Sequence
+from typing import Optional, Sequence
 
 import torch
 
