@@ -60,7 +60,8 @@ __global__ __launch_bounds__(NT) void mnf_aux_backward_kernel(const float* __res
     if (tid == 0) aux[0] = m;
 }
 
-__global__ __launch_bounds__(NT) void mnf_flow_planar_backward_kernel(const lbbnn_flow_bwd_args_t a) {
+__global__ __launch_bounds__(NT) void mnf_flow_planar_backward_kernel(const lbbnn_flow_bwd_args_t a, int in_lds) {
+    extern __shared__ __attribute__((aligned(16))) float dyn[];
     __shared__ double scratch[3 * NWV];
     __shared__ float thF[LBBNN_MAX_FLOW_T], thK[LBBNN_MAX_FLOW_T], uwZ[LBBNN_MAX_FLOW_T], thR[LBBNN_MAX_FLOW_T], uwR[LBBNN_MAX_FLOW_T];
     __shared__ float s_zb;
@@ -68,8 +69,9 @@ __global__ __launch_bounds__(NT) void mnf_flow_planar_backward_kernel(const lbbn
     const int Tz = a.z_flow.T, Tr = a.r_flow.T;
     const bool has_kl = a.g_kl != nullptr;
     const float G = has_kl ? a.g_kl[0] : 0.f;
-    // work layout: ZF[0..Tz], ZK[0..Tz], R[1..Tr] (R[0] aliases ZK[Tz]), DK, DF
-    float* const ZF = a.work;
+    // work layout: ZF[0..Tz], ZK[0..Tz], R[1..Tr] (R[0] aliases ZK[Tz]), DK, DF, EF, EK -- in LDS when it fits (every
+    // phase of the chain re-reads what the previous one wrote: an L2 round trip per phase otherwise), else in a.work
+    float* const ZF = in_lds ? dyn : a.work;
     float* const ZK = ZF + (size_t)(Tz + 1) * I;
     float* const RR = ZK + (size_t)(Tz + 1) * I;
     float* const DK = RR + (size_t)Tr * I;
@@ -247,6 +249,16 @@ extern "C" int lbbnn_mnf_flow_planar_backward(const lbbnn_flow_bwd_args_t* p, vo
         if (!a.z_flow.u[t] || !a.z_flow.w[t] || !a.z_flow.b[t] || !a.d_z_flow.u[t] || !a.d_z_flow.w[t] || !a.d_z_flow.b[t]) return LBBNN_E_NULL;
     for (int t = 0; t < a.r_flow.T; ++t)
         if (!a.r_flow.u[t] || !a.r_flow.w[t] || !a.r_flow.b[t] || !a.d_r_flow.u[t] || !a.d_r_flow.w[t] || !a.d_r_flow.b[t]) return LBBNN_E_NULL;
-    hipLaunchKernelGGL(mnf_flow_planar_backward_kernel, dim3(1), dim3(NT), 0, static_cast<hipStream_t>(stream), a);
+    const size_t bytes = (size_t)lbbnn_mnf_flow_backward_workspace(a.I, a.z_flow.T, a.r_flow.T) * sizeof(float);
+    const int in_lds = bytes <= 144 * 1024 ? 1 : 0;
+    static size_t raised = 0;
+    if (in_lds && bytes > 64 * 1024 && bytes > raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnf_flow_planar_backward_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return (int)e;
+        raised = bytes;
+    }
+    hipLaunchKernelGGL(mnf_flow_planar_backward_kernel, dim3(1), dim3(NT), in_lds ? bytes : 0, static_cast<hipStream_t>(stream),
+                       a, in_lds);
     return (int)hipGetLastError();
 }
