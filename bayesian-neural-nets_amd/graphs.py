@@ -1,16 +1,18 @@
 """HIP-graph capture of launch-bound loops (one process per GPU; graphs instead of a tracing compiler).
 
-``make_graphed_train_step`` captures ONE full training step -- forward (HIP kernels), backward (HIP GEMMs +
-the torch parameter chain) and the optimizer update -- into a HIP graph and returns a callable that replays
-it on new data.  The eager step of the headline net issues ~760 kernel launches for 2.6 ms of GPU work and is
-host-bound at ~11.7 ms; replayed from a graph it runs at GPU speed.  Noise stays fresh across replays because
-the Philox {seed, offset} pair lives in device memory and is advanced by a kernel inside the graph.
+``make_graphed_train_step`` captures ONE full training step -- forward, backward (both HIP kernels) and the
+optimizer update -- into a HIP graph and returns a callable that replays it on new data.  The eager step of the
+headline net issues ~85 launches and is host-bound at ~2.3 ms; replayed from a graph it runs at GPU speed (~1.1 ms;
+DESIGN.md section 9).  Noise stays fresh across replays because the Philox {seed, offset} pair lives in device memory and
+is advanced by a kernel inside the graph.
 """
 import torch
 
 
 def make_graphed_train_step(net, optimizer, loss_fn, example_x, example_y, warmup: int = 3):
-    """loss_fn(net, x, y) -> scalar loss.  The optimizer must be capture-safe (e.g. Adam(capturable=True)).
+    """loss_fn(net, x, y) -> scalar loss.  The optimizer must be capture-safe: ``bnn_amd.optim.Adam`` (device-side
+    step counter) or ``torch.optim.Adam(capturable=True)``.  The warm-up steps run eagerly first, so optimizer state is
+    allocated outside the capture.
     Returns step(x, y) -> loss tensor (a static buffer, overwritten by the next replay)."""
     dev = example_x.device
     static_x, static_y = example_x.clone(), example_y.clone()
