@@ -10,7 +10,9 @@
  *  - Every pointer is a DEVICE pointer to contiguous row-major fp32 unless stated otherwise.
  *    The caller (PyTorch) owns all buffers, including workspaces; nothing here allocates.
  *  - `stream` is a hipStream_t passed as void*.  Calls only enqueue work and return; they
- *    never synchronise, keep no global state, and are safe under HIP-graph capture.
+ *    never synchronise and are safe under HIP-graph capture.  The only process-wide state is an idempotent cache
+ *    of "dynamic-LDS limit already raised" per kernel (hipFuncSetAttribute is a host-side attribute, not a stream
+ *    operation); a few environment variables read once select measurement knobs (LBBNN_GEMM_RESIDENCY, LBBNN_GEMM_NO_DMA).
  *  - Return value: 0 on success; a negative LBBNN_E_* for argument errors (nothing was
  *    launched); a positive hipError_t if the launch failed.  No C++ exception crosses.
  *  - Noise: every stochastic entry takes either an explicit draw (`eps`, parity mode) or,
