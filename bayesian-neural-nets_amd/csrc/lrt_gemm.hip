@@ -775,7 +775,8 @@ constexpr int kNumCU = 256;
 
 inline size_t lds_request(size_t needed, long nblocks) {
     long r = (nblocks + kNumCU - 1) / kNumCU;
-    if (const char* e = getenv("LBBNN_GEMM_RESIDENCY")) r = atol(e);      // tuning knob (bench sweeps only)
+    static const char* const res_env = getenv("LBBNN_GEMM_RESIDENCY");   // tuning knob (bench sweeps only), read once
+    if (res_env) r = atol(res_env);
     if (r < 1) r = 1;
     if (r >= 3) return needed;                       // as many as fit
     const size_t cap = kLdsPerCU / (size_t)(r + 1) + 256;   // r fit, r+1 do not
