@@ -8,7 +8,8 @@ import bnn_amd
 dev = torch.device("cuda:0")
 bnn_amd.set_precision(os.environ.get("PREC", "bf16x3"))
 torch.manual_seed(0)
-net = bnn_amd.mnf.BayesianNetwork((784, 1200, 1200, 10), 2, z_flow_type="Planar", r_flow_type="Planar").to(dev).train()
+FLOW = os.environ.get("FLOW", "Planar")      # Planar (headline) | RNVP (the reference default) | MNF
+net = bnn_amd.mnf.BayesianNetwork((784, 1200, 1200, 10), 2, z_flow_type=FLOW, r_flow_type=FLOW).to(dev).train()
 FUSED = os.environ.get("FUSED_ADAM", "1") == "1"
 opt = (bnn_amd.optim.Adam if FUSED else torch.optim.Adam)(net.parameters(), lr=1e-3)
 x = torch.rand(4096, 1, 28, 28, device=dev); y = torch.randint(0, 10, (4096,), device=dev)
