@@ -95,12 +95,115 @@ def _vector(z, tr):
     return z, logdet
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# Dense coupling flows: forward and backward as ONE HIP launch each (lbbnn_flow_dense_apply[_backward]) instead of the
+# ~75 torch ops per application of the formulas in _dense above.
+_RNVP_NAMES = ("network.0.weight", "network.0.bias", "network.2.weight", "network.2.bias", "network.4.weight",
+               "network.4.bias", "network.6.weight", "network.6.bias", "t.weight", "t.bias", "s.weight", "s.bias")
+_MNF_NAMES = ("f.weight", "f.bias", "g.weight", "g.bias", "k.weight", "k.bias")
+
+
+def _dense_descs(kind, params, masks, grads=None):
+    """ctypes arrays of lbbnn_dense_transform_t (and lbbnn_dense_grad_t) from the flat parameter list."""
+    import ctypes
+    from . import _lib
+    names = _RNVP_NAMES if kind == "RNVP" else _MNF_NAMES
+    T = len(masks)
+    arr = (_lib.DenseTransform * max(T, 1))()
+    garr = (_lib.DenseGrad * max(T, 1))() if grads is not None else None
+    n = len(names)
+    for t in range(T):
+        p = dict(zip(names, params[t * n:(t + 1) * n]))
+        d = arr[t]
+        if kind == "RNVP":
+            d.kind, d.hidden = 0, p["network.0.weight"].shape[0]
+            d.w_in, d.b_in = p["network.0.weight"].data_ptr(), p["network.0.bias"].data_ptr()
+            for l, idx in enumerate((2, 4, 6)):
+                d.w_mid[l], d.b_mid[l] = p["network.%d.weight" % idx].data_ptr(), p["network.%d.bias" % idx].data_ptr()
+            d.w_a, d.b_a, d.w_b, d.b_b = (p["t.weight"].data_ptr(), p["t.bias"].data_ptr(), p["s.weight"].data_ptr(),
+                                          p["s.bias"].data_ptr())
+        else:
+            d.kind, d.hidden = 1, p["f.weight"].shape[0]
+            d.w_in, d.b_in = p["f.weight"].data_ptr(), p["f.bias"].data_ptr()
+            d.w_a, d.b_a, d.w_b, d.b_b = (p["g.weight"].data_ptr(), p["g.bias"].data_ptr(), p["k.weight"].data_ptr(),
+                                          p["k.bias"].data_ptr())
+        d.mask_fwd = masks[t].data_ptr()
+        if grads is not None:
+            g = dict(zip(names, grads[t * n:(t + 1) * n]))
+            gd = garr[t]
+            if kind == "RNVP":
+                gd.w_in, gd.b_in = g["network.0.weight"].data_ptr(), g["network.0.bias"].data_ptr()
+                for l, idx in enumerate((2, 4, 6)):
+                    gd.w_mid[l], gd.b_mid[l] = g["network.%d.weight" % idx].data_ptr(), g["network.%d.bias" % idx].data_ptr()
+                gd.w_a, gd.b_a, gd.w_b, gd.b_b = (g["t.weight"].data_ptr(), g["t.bias"].data_ptr(), g["s.weight"].data_ptr(),
+                                                  g["s.bias"].data_ptr())
+            else:
+                gd.w_in, gd.b_in = g["f.weight"].data_ptr(), g["f.bias"].data_ptr()
+                gd.w_a, gd.b_a, gd.w_b, gd.b_b = (g["g.weight"].data_ptr(), g["g.bias"].data_ptr(), g["k.weight"].data_ptr(),
+                                                  g["k.bias"].data_ptr())
+    return arr, garr, T
+
+
+class _DenseFlowFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, kind, nmask, z, *rest):
+        from . import _lib
+        masks = [m.reshape(-1).contiguous().float() for m in rest[:nmask]]
+        params = [p.contiguous() for p in rest[nmask:]]
+        z = z.contiguous()
+        arr, _, T = _dense_descs(kind, params, masks)
+        I = z.shape[0]
+        z_out = torch.empty_like(z)
+        logdet = torch.empty((), dtype=torch.float32, device=z.device)
+        stream = torch.cuda.current_stream(z.device).cuda_stream
+        _lib.check(_lib.lib().lbbnn_flow_dense_apply(arr, T, 0, z.data_ptr(), I, z_out.data_ptr(), logdet.data_ptr(), stream),
+                   "lbbnn_flow_dense_apply")
+        ctx.kind, ctx.nmask = kind, nmask
+        ctx.save_for_backward(z, *masks, *params)
+        return z_out, logdet
+
+    @staticmethod
+    def backward(ctx, dz, dld):
+        from . import _lib
+        saved = ctx.saved_tensors
+        z, masks, params = saved[0], list(saved[1:1 + ctx.nmask]), list(saved[1 + ctx.nmask:])
+        grads = [torch.empty_like(p) for p in params]
+        arr, garr, T = _dense_descs(ctx.kind, params, masks, grads)
+        I = z.shape[0]
+        if dz is None:
+            dz = torch.zeros_like(z)
+        dz = dz.contiguous()
+        dz_in = torch.empty_like(z)
+        work = torch.empty(_lib.lib().lbbnn_flow_dense_apply_workspace(I, T), dtype=torch.float32, device=z.device)
+        stream = torch.cuda.current_stream(z.device).cuda_stream
+        dldp = dld.contiguous().data_ptr() if dld is not None else None
+        _lib.check(_lib.lib().lbbnn_flow_dense_apply_backward(arr, garr, T, 0, z.data_ptr(), dz.data_ptr(), dldp, I,
+                                                              dz_in.data_ptr(), work.data_ptr(), stream),
+                   "lbbnn_flow_dense_apply_backward")
+        return (None, None, dz_in, *([None] * ctx.nmask), *grads)
+
+
+def _dense_hip(z, kind, tr, masks):
+    names = _RNVP_NAMES if kind == "RNVP" else _MNF_NAMES
+    flat = [t[n] for t in tr for n in names]
+    return _DenseFlowFn.apply(kind, len(masks), z, *masks, *flat)
+
+
+import os as _os
+# The single-workgroup HIP forward/backward of the coupling MLPs is parity-green but SLOWER than the torch formulas of
+# _dense for the headline sizes (one CU is instruction-bound on 1200 rows x 75 columns: 0.36 ms per launch, graphed
+# training step 8.8 ms against 5.7 ms), so it is opt-in until it is spread over workgroups (DESIGN.md section 10).
+_DENSE_HIP = _os.environ.get("LBBNN_DENSE_HIP_BWD", "0") == "1"
+
+
 def _flow(z, spec, masks):
     kind, tr = spec
     if kind == "Planar":
         return _planar(z, tr)
     if kind in ("Radial", "Householder", "Sylvester", "mixed"):
         return _vector(z, tr)
+    if z.is_cuda and _DENSE_HIP and len(tr) <= 8:
+        return _dense_hip(z, kind, tr, masks)
     return _dense(z, kind, tr, masks)
 
 

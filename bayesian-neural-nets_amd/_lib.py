@@ -87,6 +87,15 @@ class CopyList(ctypes.Structure):
     _fields_ = [("dst", c_p * ADAM_MAX_TENSORS), ("src", c_p * ADAM_MAX_TENSORS), ("numel", c_i64 * ADAM_MAX_TENSORS), ("n", c_i)]
 
 
+class DenseGrad(ctypes.Structure):
+    """lbbnn_dense_grad_t"""
+    _fields_ = [("w_in", c_p), ("b_in", c_p), ("w_mid", c_p * 3), ("b_mid", c_p * 3),
+                ("w_a", c_p), ("b_a", c_p), ("w_b", c_p), ("b_b", c_p)]
+
+
+MAX_DENSE_T = 8
+
+
 class OutGradArgs(ctypes.Structure):
     """lbbnn_outgrad_args_t"""
     _fields_ = [(n, c_p) for n in ("g_out", "out", "std", "eps", "rng", "gm", "gv", "gmT", "gvT", "g_sum", "gv_sum", "work")] + \
@@ -132,6 +141,10 @@ SIGNATURES = {
     "lbbnn_transpose_operand": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p]),
     "lbbnn_weight_pass_backward_workspace": (c_i64, [c_i, c_i]),
     "lbbnn_weight_pass_backward": (c_i, [ctypes.POINTER(WpbArgs), c_p]),
+    "lbbnn_flow_dense_apply_workspace": (c_i64, [c_i, c_i]),
+    "lbbnn_flow_dense_apply": (c_i, [ctypes.POINTER(DenseTransform), c_i, c_i, c_p, c_i, c_p, c_p, c_p]),
+    "lbbnn_flow_dense_apply_backward": (c_i, [ctypes.POINTER(DenseTransform), ctypes.POINTER(DenseGrad), c_i, c_i, c_p, c_p,
+                                              c_p, c_i, c_p, c_p, c_p]),
     "lbbnn_multi_copy": (c_i, [ctypes.POINTER(CopyList), c_p]),
     "lbbnn_adam_step": (c_i, [ctypes.POINTER(AdamList), ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                               ctypes.c_float, c_p, c_i, c_p]),

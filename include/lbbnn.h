@@ -498,6 +498,26 @@ typedef struct lbbnn_copy_list {
 
 int lbbnn_multi_copy(const lbbnn_copy_list_t* list, void* stream);
 
+/* Stand-alone application of a dense coupling flow (RNVP / MNF type, flows2.py:188-241) to ONE vector, and its analytic
+ * backward -- the pieces the vector-sized backward of an MNF layer with the reference's default flows is made of:
+ *   lbbnn_flow_dense_apply:           z_out = f_T(...f_1(z_in)),  *logdet = sum of the transforms' log-dets
+ *   lbbnn_flow_dense_apply_backward:  given d_zout (I) and *d_logdet (device scalar, NULL = 0): dz_in (I) and the
+ *                                     gradient of every parameter of every transform (written, not accumulated).
+ * which_mask selects mask_fwd (0) or mask_kl (1) of each transform.  One single-workgroup launch each; the backward
+ * re-runs the forward keeping each transform's input (work: lbbnn_flow_dense_apply_workspace floats).
+ */
+#define LBBNN_MAX_DENSE_T 8
+typedef struct lbbnn_dense_grad {
+    float *w_in, *b_in, *w_mid[3], *b_mid[3], *w_a, *b_a, *w_b, *b_b;      /* same shapes as lbbnn_dense_transform_t */
+} lbbnn_dense_grad_t;
+
+int64_t lbbnn_flow_dense_apply_workspace(int I, int T);
+int lbbnn_flow_dense_apply(const lbbnn_dense_transform_t* tr, int T, int which_mask, const float* z_in, int I,
+                           float* z_out, float* logdet, void* stream);
+int lbbnn_flow_dense_apply_backward(const lbbnn_dense_transform_t* tr, const lbbnn_dense_grad_t* grads, int T,
+                                    int which_mask, const float* z_in, const float* d_zout, const float* d_logdet, int I,
+                                    float* dz_in, float* work, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1157,3 +1157,48 @@ def test_bench_contract_json_line():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert cb["kind"] == "port" and cb["value"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,B,I,O,T", [("RNVP", 16, 96, 40, 2), ("MNF", 16, 96, 40, 2), ("RNVP", 32, 1200, 64, 2),
+                                          ("MNF", 8, 1200, 32, 1)])
+@pytest.mark.parametrize("hip_mlp", [True, False])
+def test_dense_flow_hip_backward_vs_oracle_autograd(bnn, dev, kind, B, I, O, T, hip_mlp, monkeypatch):
+    """MNF layer with RNVP / MNF-type flows: forward, KL and every gradient against fp64 autograd of the oracle, with the
+    coupling MLPs' backward either as one HIP launch per flow application (lbbnn_flow_dense_apply[_backward], opt-in:
+    correct but slower than torch on one CU) or as the default torch formulas on the vector-sized chain."""
+    from bnn_amd import _grad
+    monkeypatch.setattr(_grad, "_DENSE_HIP", hip_mlp)
+    torch.manual_seed(21)
+    layer = bnn.mnf.BayesianLinear(I, O, T, z_flow_type=kind, r_flow_type=kind)
+    with torch.no_grad():
+        layer.q0_mean.add_(1.0)
+        layer.weight_mu.mul_(10)
+    g = torch.Generator().manual_seed(22)
+    bern = lambda: torch.bernoulli(torch.full((I,), 0.5), generator=g)
+    noise = {"eps_z": torch.randn(1, I, generator=g), "eps_out": torch.randn(B, O, generator=g),
+             "eps_z2": torch.randn(1, I, generator=g), "eps_act": torch.randn(O, generator=g),
+             "zmask": [bern() for _ in range(T)], "zmask2": [bern() for _ in range(T)], "rmask": [bern() for _ in range(T)]}
+    x = torch.rand(B, I, generator=g)
+    p = {k: v.detach().clone() for k, v in layer.state_dict().items()}
+    layer = layer.to(dev).train()
+    layer.noise = {k: ([m.to(dev) for m in v] if isinstance(v, list) else v.to(dev)) for k, v in noise.items()}
+    xg = x.to(dev).requires_grad_(True)
+    out = layer(xg, sample=True)
+    (out.pow(2).sum() + layer.kl / 60).backward()
+    pc = {k: v.double().requires_grad_(True) for k, v in p.items()}
+    xc = x.double().requires_grad_(True)
+    zf = orc.flow_from_state("z_flow", kind, pc, T)
+    rf = orc.flow_from_state("r_flow", kind, pc, T)
+    n64 = {k: ([m.double() for m in v] if isinstance(v, list) else v.double()) for k, v in noise.items()}
+    o, kl, _ = orc.mnf_forward(xc, pc, zf, rf, n64)
+    (o.pow(2).sum() + kl / 60).backward()
+    assert rel_err(out.detach().cpu().double(), o.detach()) < TOL
+    assert abs(float(layer.kl) - float(kl)) / abs(float(kl)) < TOL
+    assert rel_err(xg.grad.cpu().double(), xc.grad) < TOL
+    for name, prm in layer.named_parameters():
+        ref = pc[name].grad
+        if ref is None or float(ref.abs().max()) == 0.0:
+            assert prm.grad is None or float(prm.grad.abs().max()) < 1e-12, name
+            continue
+        assert rel_err(prm.grad.cpu().double(), ref) < 5e-4, name
