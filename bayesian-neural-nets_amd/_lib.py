@@ -46,7 +46,8 @@ class LayerDesc(ctypes.Structure):
                 ("O", c_i), ("I", c_i), ("layer_id", c_u32), ("stochastic", c_i), ("want_kl", c_i), ("split", c_i),
                 ("eps_z", c_p), ("eps_z2", c_p), ("eps_act", c_p),
                 ("z_fwd", c_p), ("z_kl", c_p), ("scal", c_p), ("e_w", c_p), ("var_w", c_p),
-                ("kl_rows", c_p), ("act_mu", c_p), ("act_var", c_p), ("bias_var", c_p), ("kl_layer", c_p)]
+                ("kl_rows", c_p), ("act_mu", c_p), ("act_var", c_p), ("bias_var", c_p), ("kl_layer", c_p),
+                ("flows_done", c_i)]
 
 
 class DenseTransform(ctypes.Structure):
@@ -85,6 +86,13 @@ class AdamList(ctypes.Structure):
 class CopyList(ctypes.Structure):
     """lbbnn_copy_list_t"""
     _fields_ = [("dst", c_p * ADAM_MAX_TENSORS), ("src", c_p * ADAM_MAX_TENSORS), ("numel", c_i64 * ADAM_MAX_TENSORS), ("n", c_i)]
+
+
+class DenseLayer(ctypes.Structure):
+    """lbbnn_dense_layer_t"""
+    _fields_ = [("q0_mean", c_p), ("q0_log_var", c_p), ("zt", ctypes.POINTER(DenseTransform)), ("rt", ctypes.POINTER(DenseTransform)),
+                ("eps_fwd", c_p), ("eps_kl", c_p), ("z_fwd", c_p), ("z_kl", c_p), ("scal", c_p), ("work", c_p),
+                ("Tz", c_i), ("Tr", c_i), ("I", c_i), ("want_kl", c_i), ("layer_id", c_u32)]
 
 
 class DenseGrad(ctypes.Structure):
@@ -141,6 +149,7 @@ SIGNATURES = {
     "lbbnn_transpose_operand": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p]),
     "lbbnn_weight_pass_backward_workspace": (c_i64, [c_i, c_i]),
     "lbbnn_weight_pass_backward": (c_i, [ctypes.POINTER(WpbArgs), c_p]),
+    "lbbnn_layers_dense_flows": (c_i, [ctypes.POINTER(DenseLayer), c_i, c_p, c_p]),
     "lbbnn_flow_dense_apply_workspace": (c_i64, [c_i, c_i]),
     "lbbnn_flow_dense_apply": (c_i, [ctypes.POINTER(DenseTransform), c_i, c_i, c_p, c_i, c_p, c_p, c_p]),
     "lbbnn_flow_dense_apply_backward": (c_i, [ctypes.POINTER(DenseTransform), ctypes.POINTER(DenseGrad), c_i, c_i, c_p, c_p,

@@ -21,9 +21,13 @@ struct InitArgs {
 };
 
 // z0 = q0_mean + exp(q0_log_var)^.5 * eps  (LBBNN-GP-MF-MNF.py:183-185) for both paths; log_q0 partials (:213-214)
-__global__ __launch_bounds__(256) void dense_init_kernel(const InitArgs a) {
+struct InitBatch { InitArgs l[LBBNN_MAX_LAYERS]; };
+
+__global__ __launch_bounds__(256) void dense_init_kernel(const InitBatch bt) {
     __shared__ double scratch[4];
+    const LBBNN_CONST_AS InitArgs& a = kernarg_as<InitBatch>()->l[blockIdx.z];      // layer = blockIdx.z, no scratch copy
     const int path = blockIdx.y;
+    if (blockIdx.x * 256 >= a.I) return;                                            // grid sized for the widest layer
     const int i = blockIdx.x * 256 + threadIdx.x;
     double lq = 0.0;
     if (i < a.I) {
@@ -60,7 +64,10 @@ struct StageArgs {
 
 // Stage A: one wave per hidden unit j: h[j] = act( sum_i W_in[j,i] * (m_i z_i) + b_in[j] )
 //   RNVP: LeakyReLU(0.1) (flows2.py:176-185,212)   MNF: tanh (flows2.py:235)
-__global__ __launch_bounds__(256) void dense_stage_a_kernel(const StageArgs a) {
+struct StageBatch { StageArgs l[LBBNN_MAX_LAYERS]; };
+
+__global__ __launch_bounds__(256) void dense_stage_a_kernel(const StageBatch bt) {
+    const LBBNN_CONST_AS StageArgs& a = kernarg_as<StageBatch>()->l[blockIdx.z];
     const int path = a.path_lo + blockIdx.y;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -79,9 +86,11 @@ __global__ __launch_bounds__(256) void dense_stage_a_kernel(const StageArgs a) {
 
 // Output stage: (RNVP) finish the MLP chain h1 -> h4 in LDS, then per output i the two H-long dots,
 // the gate and the coupling update, plus this workgroup's log-det partial.
-__global__ __launch_bounds__(CB) void dense_stage_c_kernel(const StageArgs a) {
+__global__ __launch_bounds__(CB) void dense_stage_c_kernel(const StageBatch bt) {
     __shared__ float hs[2][HMAX];
     __shared__ double scratch[4];
+    const LBBNN_CONST_AS StageArgs& a = kernarg_as<StageBatch>()->l[blockIdx.z];
+    if (blockIdx.x * CB >= a.I) return;                                             // grid sized for the widest layer
     const int path = a.path_lo + blockIdx.y;
     const int H = a.tr.hidden, tid = threadIdx.x;
     if (tid < H) hs[0][tid] = a.h[path][tid];
@@ -129,7 +138,10 @@ struct FinishArgs {
 };
 
 // scal[0] = log_det_q, [1] = log_q0, [2] = log_det_r, [3] = r_flow(z2)[-1], [4] = forward-draw log-det
-__global__ void dense_finish_kernel(const FinishArgs a) {
+struct FinishBatch { FinishArgs l[LBBNN_MAX_LAYERS]; };
+
+__global__ void dense_finish_kernel(const FinishBatch bt) {
+    const LBBNN_CONST_AS FinishArgs& a = kernarg_as<FinishBatch>()->l[blockIdx.x];
     if (threadIdx.x != 0) return;
     float s = 0.f;
     for (int t = 0; t < a.Tz * a.nblk; ++t) s += a.ldf[t];
@@ -167,6 +179,81 @@ extern "C" int64_t lbbnn_flow_dense_workspace(int I) {
     return 2 * (int64_t)I + 2 * HMAX + nblk_i + 3 * (int64_t)LBBNN_MAX_FLOW_T * nblk + 64;
 }
 
+// K4 of n layers in 2 + 2*(Tz+Tr) launches (blockIdx.z = layer); the layers must agree on Tz, Tr and want_kl
+static int dense_flows_impl(const lbbnn_dense_layer_t* L, int n, const uint64_t* rng, void* stream) {
+    if (!L) return LBBNN_E_NULL;
+    if (n <= 0 || n > LBBNN_MAX_LAYERS) return LBBNN_E_SHAPE;
+    const int Tz = L[0].Tz, Tr = L[0].Tr, want_kl = L[0].want_kl;
+    int maxI = 0, maxH = 1;
+    for (int k = 0; k < n; ++k) {
+        const lbbnn_dense_layer_t& d = L[k];
+        if (!d.q0_mean || !d.q0_log_var || !d.z_fwd || !d.scal || !d.work) return LBBNN_E_NULL;
+        if (d.I <= 0 || d.Tz < 0 || d.Tz > LBBNN_MAX_FLOW_T || d.Tr < 0 || d.Tr > LBBNN_MAX_FLOW_T) return LBBNN_E_SHAPE;
+        if (d.Tz != Tz || d.Tr != Tr || (d.want_kl != 0) != (want_kl != 0)) return LBBNN_E_SHAPE;
+        if (d.want_kl && !d.z_kl) return LBBNN_E_NULL;
+        if ((!d.eps_fwd || (d.want_kl && !d.eps_kl)) && !rng) return LBBNN_E_NOISE;
+        if ((d.Tz && !d.zt) || (d.want_kl && d.Tr && !d.rt)) return LBBNN_E_NULL;
+        for (int t = 0; t < d.Tz; ++t) { if (!transform_ok(d.zt[t], true, d.want_kl != 0)) return LBBNN_E_NULL; maxH = d.zt[t].hidden > maxH ? d.zt[t].hidden : maxH; }
+        if (d.want_kl) for (int t = 0; t < d.Tr; ++t) { if (!transform_ok(d.rt[t], false, true)) return LBBNN_E_NULL; maxH = d.rt[t].hidden > maxH ? d.rt[t].hidden : maxH; }
+        maxI = d.I > maxI ? d.I : maxI;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int npaths = want_kl ? 2 : 1;
+    const int gblk = (maxI + CB - 1) / CB, gblk_i = (maxI + 255) / 256;
+    struct Bufs { float *zbuf1, *h0, *h1, *lq0, *ldf, *ldz, *ldr; int nblk, nblk_i; } B[LBBNN_MAX_LAYERS];
+    InitBatch ib{};
+    for (int k = 0; k < n; ++k) {
+        const lbbnn_dense_layer_t& d = L[k];
+        Bufs& b = B[k];
+        b.nblk = (d.I + CB - 1) / CB; b.nblk_i = (d.I + 255) / 256;
+        b.zbuf1 = d.work + d.I;                  // (work[0..I) was the path-0 scratch row of an earlier version)
+        b.h0 = d.work + 2 * (size_t)d.I; b.h1 = b.h0 + HMAX; b.lq0 = b.h1 + HMAX;
+        b.ldf = b.lq0 + b.nblk_i;
+        b.ldz = b.ldf + (size_t)LBBNN_MAX_FLOW_T * b.nblk;
+        b.ldr = b.ldz + (size_t)LBBNN_MAX_FLOW_T * b.nblk;
+        InitArgs& ia = ib.l[k];
+        ia.q0_mean = d.q0_mean; ia.q0_log_var = d.q0_log_var; ia.eps[0] = d.eps_fwd; ia.eps[1] = d.eps_kl; ia.rng = rng;
+        ia.z[0] = d.z_fwd; ia.z[1] = b.zbuf1; ia.lq0_part = b.lq0; ia.I = d.I; ia.layer = d.layer_id & 63u; ia.npaths = npaths;
+    }
+    hipLaunchKernelGGL(dense_init_kernel, dim3(gblk_i, npaths, n), dim3(256), 0, s, ib);
+
+    for (int t = 0; t < Tz + (want_kl ? Tr : 0); ++t) {
+        const bool zphase = t < Tz;
+        StageBatch sb{};
+        for (int k = 0; k < n; ++k) {
+            const lbbnn_dense_layer_t& d = L[k];
+            const Bufs& b = B[k];
+            StageArgs& sa = sb.l[k];
+            sa.tr = zphase ? d.zt[t] : d.rt[t - Tz];
+            sa.z[0] = d.z_fwd; sa.z[1] = b.zbuf1; sa.h[0] = b.h0; sa.h[1] = b.h1;
+            sa.zcopy = (zphase && want_kl && t == Tz - 1) ? d.z_kl : nullptr;
+            sa.ld_part[0] = b.ldf + (size_t)t * b.nblk;
+            sa.ld_part[1] = zphase ? b.ldz + (size_t)t * b.nblk : b.ldr + (size_t)(t - Tz) * b.nblk;
+            sa.I = d.I;
+            sa.path_lo = zphase ? 0 : 1;
+            sa.npaths = zphase ? npaths : 1;
+        }
+        const int np = zphase ? npaths : 1;
+        hipLaunchKernelGGL(dense_stage_a_kernel, dim3((maxH + 3) / 4, np, n), dim3(256), 0, s, sb);
+        hipLaunchKernelGGL(dense_stage_c_kernel, dim3(gblk, np, n), dim3(CB), 0, s, sb);
+    }
+    FinishBatch fb{};
+    for (int k = 0; k < n; ++k) {
+        const lbbnn_dense_layer_t& d = L[k];
+        const Bufs& b = B[k];
+        if (want_kl && Tz == 0) (void)hipMemcpyAsync(d.z_kl, b.zbuf1, (size_t)d.I * sizeof(float), hipMemcpyDeviceToDevice, s);
+        FinishArgs& fa = fb.l[k];
+        fa.ldz = b.ldz; fa.ldr = b.ldr; fa.lq0 = b.lq0; fa.zr = b.zbuf1; fa.ldf = b.ldf; fa.scal = d.scal;
+        fa.nblk = b.nblk; fa.nblk_i = b.nblk_i; fa.Tz = Tz; fa.Tr = want_kl ? Tr : 0; fa.I = d.I; fa.want_kl = want_kl;
+    }
+    hipLaunchKernelGGL(dense_finish_kernel, dim3(n), dim3(64), 0, s, fb);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lbbnn_layers_dense_flows(const lbbnn_dense_layer_t* layers, int n, const uint64_t* rng, void* stream) {
+    return dense_flows_impl(layers, n, rng, stream);
+}
+
 extern "C" int lbbnn_mnf_flow_dense(const float* q0_mean, const float* q0_log_var,
                                     const lbbnn_dense_transform_t* zt, int Tz,
                                     const lbbnn_dense_transform_t* rt, int Tr,
@@ -174,51 +261,9 @@ extern "C" int lbbnn_mnf_flow_dense(const float* q0_mean, const float* q0_log_va
                                     const uint64_t* rng, uint32_t layer_id,
                                     float* z_fwd, float* z_kl, float* scal, float* work,
                                     int I, int want_kl, void* stream) {
-    if (!q0_mean || !q0_log_var || !z_fwd || !scal || !work) return LBBNN_E_NULL;
-    if (I <= 0 || Tz < 0 || Tz > LBBNN_MAX_FLOW_T || Tr < 0 || Tr > LBBNN_MAX_FLOW_T) return LBBNN_E_SHAPE;
-    if (want_kl && !z_kl) return LBBNN_E_NULL;
-    if ((!eps_fwd || (want_kl && !eps_kl)) && !rng) return LBBNN_E_NOISE;
-    if ((Tz && !zt) || (want_kl && Tr && !rt)) return LBBNN_E_NULL;
-    for (int t = 0; t < Tz; ++t) if (!transform_ok(zt[t], true, want_kl != 0)) return LBBNN_E_NULL;
-    if (want_kl) for (int t = 0; t < Tr; ++t) if (!transform_ok(rt[t], false, true)) return LBBNN_E_NULL;
-
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const int nblk = (I + CB - 1) / CB, nblk_i = (I + 255) / 256;
-    const int npaths = want_kl ? 2 : 1;
-    float* zbuf0 = work;                 // path 0 works directly in a scratch row, copied to z_fwd at the end
-    float* zbuf1 = work + I;
-    float* h0 = work + 2 * (size_t)I;
-    float* h1 = h0 + HMAX;
-    float* lq0 = h1 + HMAX;
-    float* ldf = lq0 + nblk_i;
-    float* ldz = ldf + (size_t)LBBNN_MAX_FLOW_T * nblk;
-    float* ldr = ldz + (size_t)LBBNN_MAX_FLOW_T * nblk;
-    (void)zbuf0;
-
-    InitArgs ia;
-    ia.q0_mean = q0_mean; ia.q0_log_var = q0_log_var; ia.eps[0] = eps_fwd; ia.eps[1] = eps_kl; ia.rng = rng;
-    ia.z[0] = z_fwd; ia.z[1] = zbuf1; ia.lq0_part = lq0; ia.I = I; ia.layer = layer_id & 63u; ia.npaths = npaths;
-    hipLaunchKernelGGL(dense_init_kernel, dim3(nblk_i, npaths), dim3(256), 0, s, ia);
-
-    for (int t = 0; t < Tz + (want_kl ? Tr : 0); ++t) {
-        const bool zphase = t < Tz;
-        StageArgs sa;
-        sa.tr = zphase ? zt[t] : rt[t - Tz];
-        sa.z[0] = z_fwd; sa.z[1] = zbuf1; sa.h[0] = h0; sa.h[1] = h1;
-        sa.zcopy = (zphase && want_kl && t == Tz - 1) ? z_kl : nullptr;
-        sa.ld_part[0] = ldf + (size_t)t * nblk;
-        sa.ld_part[1] = zphase ? ldz + (size_t)t * nblk : ldr + (size_t)(t - Tz) * nblk;
-        sa.I = I;
-        sa.path_lo = zphase ? 0 : 1;
-        sa.npaths = zphase ? npaths : 1;
-        hipLaunchKernelGGL(dense_stage_a_kernel, dim3((sa.tr.hidden + 3) / 4, sa.npaths), dim3(256), 0, s, sa);
-        hipLaunchKernelGGL(dense_stage_c_kernel, dim3(nblk, sa.npaths), dim3(CB), 0, s, sa);
-    }
-    if (want_kl && Tz == 0) (void)hipMemcpyAsync(z_kl, zbuf1, (size_t)I * sizeof(float), hipMemcpyDeviceToDevice, s);
-
-    FinishArgs fa;
-    fa.ldz = ldz; fa.ldr = ldr; fa.lq0 = lq0; fa.zr = zbuf1; fa.ldf = ldf; fa.scal = scal;
-    fa.nblk = nblk; fa.nblk_i = nblk_i; fa.Tz = Tz; fa.Tr = want_kl ? Tr : 0; fa.I = I; fa.want_kl = want_kl;
-    hipLaunchKernelGGL(dense_finish_kernel, dim3(1), dim3(64), 0, s, fa);
-    return (int)hipGetLastError();
+    lbbnn_dense_layer_t d{};
+    d.q0_mean = q0_mean; d.q0_log_var = q0_log_var; d.zt = zt; d.rt = rt; d.Tz = Tz; d.Tr = Tr;
+    d.eps_fwd = eps_fwd; d.eps_kl = eps_kl; d.layer_id = layer_id; d.z_fwd = z_fwd; d.z_kl = z_kl; d.scal = scal; d.work = work;
+    d.I = I; d.want_kl = want_kl;
+    return dense_flows_impl(&d, 1, rng, stream);
 }

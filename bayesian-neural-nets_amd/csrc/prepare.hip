@@ -18,7 +18,9 @@ static int layers_prepare_impl(const lbbnn_layer_desc_t* L, int n, const uint64_
         if (!d.weight_mu || !d.weight_rho || !d.lambdal || !d.bias_mu || !d.bias_rho || !d.e_w || !d.bias_var) return LBBNN_E_NULL;
         if (d.stochastic && !d.var_w) return LBBNN_E_NULL;
         if (d.want_kl && (!d.kl_rows || !d.kl_layer)) return LBBNN_E_NULL;
-        if (mnf) {
+        if (mnf && d.flows_done) {
+            if (!d.z_fwd || (d.want_kl && (!d.z_kl || !d.scal || !d.r0_c || !d.r0_b1 || !d.r0_b2 || !d.act_mu || !d.act_var))) return LBBNN_E_NULL;
+        } else if (mnf) {
             if (!d.q0_log_var || !d.z_fwd) return LBBNN_E_NULL;
             if (d.I > LBBNN_MAX_FLOW_DIM || d.z_flow.T < 0 || d.z_flow.T > LBBNN_MAX_FLOW_T ||
                 d.r_flow.T < 0 || d.r_flow.T > LBBNN_MAX_FLOW_T) return LBBNN_E_SHAPE;

@@ -427,13 +427,19 @@ class MNFBayesianLinear(_BayesLinearBase):
         T = len(self.z_flow.transforms)
         dev, I = self.q0_mean.device, self.in_features
 
+        Tr = len(self.r_flow.transforms)
+        pool = []
+
         def draw(n):
-            return [torch.bernoulli(torch.full((I,), 0.5, device=dev)) for _ in range(n)]
+            # all Bernoulli(0.5) masks this call needs come from ONE device draw (2T + Tr rows), not one per mask
+            if not pool:
+                pool.extend((torch.rand(2 * T + Tr, I, device=dev) < 0.5).float().unbind(0))
+            return [pool.pop() for _ in range(n)]
         zm = [m[-1] if m.dim() == 2 else m for m in noise["zmask"]] if "zmask" in noise else draw(T)
         out = {"zmask": zm}
         if cfg[1]:
             out["zmask2"] = [m.reshape(-1) for m in noise["zmask2"]] if "zmask2" in noise else draw(T)
-            out["rmask"] = [m.reshape(-1) for m in noise["rmask"]] if "rmask" in noise else draw(len(self.r_flow.transforms))
+            out["rmask"] = [m.reshape(-1) for m in noise["rmask"]] if "rmask" in noise else draw(Tr)
         return out
 
     def sample_z(self, batch_size=1):
@@ -467,15 +473,16 @@ class MNFBayesianLinear(_BayesLinearBase):
         return ["eps_z"] + (["eps_out"] if cfg[0] else []) + (["eps_z2", "eps_act"] if cfg[1] else [])
 
     def _fusable(self):
-        return self._check_flows() == "planar"
+        return True            # planar: K3 inside lbbnn_layers_operands; dense / chain: flows first, then flows_done = 1
 
     def _fill_desc(self, d, cfg, kl_layer):
         ws, noise = super()._fill_desc(d, cfg, kl_layer)
         for name in ("q0_mean", "q0_log_var", "r0_c", "r0_b1", "r0_b2"):
             setattr(d, name, getattr(self, name).data_ptr())
+        planar = self._check_flows() == "planar"
         for fd, flow in ((d.z_flow, self.z_flow), (d.r_flow, self.r_flow)):
-            fd.T = len(flow.transforms)
-            for t, tr in enumerate(flow.transforms):
+            fd.T = len(flow.transforms) if planar else 0          # other flow kinds are run by the caller (flows_done)
+            for t, tr in enumerate(flow.transforms if planar else ()):
                 fd.u[t], fd.w[t], fd.b[t] = tr.u.data_ptr(), tr.w.data_ptr(), tr.bias.data_ptr()
         keep = []                                   # keep reshaped noise views alive until the launch
         eps_z = noise.get("eps_z")
@@ -492,7 +499,36 @@ class MNFBayesianLinear(_BayesLinearBase):
         d.eps_act = eps_act.data_ptr() if eps_act is not None else None
         d.z_fwd, d.z_kl, d.scal = ws.z_fwd.data_ptr(), ws.z_kl.data_ptr(), ws.scal.data_ptr()
         d.act_mu, d.act_var = ws.act_mu.data_ptr(), ws.act_var.data_ptr()
+        d.flows_done = 0 if self._check_flows() == "planar" else 1
         return keep
+
+    def _dense_layer_desc(self, dl, cfg, keep):
+        """Fill one lbbnn_dense_layer_t (K4 batched over layers); `keep` collects what must outlive the launch."""
+        ws = self._workspace()
+        want_kl = cfg[1]
+        masks = self._masks(cfg, 0)
+        self._last_masks = masks
+        zd, Tz, k1 = self.z_flow.dense_descs(masks["zmask"], masks.get("zmask2"))
+        rd, Tr, k2 = self.r_flow.dense_descs(None, masks.get("rmask")) if want_kl else (None, 0, None)
+        if getattr(ws, "flow_work", None) is None:
+            ws.flow_work = torch.empty(ops.flow_dense_workspace(self.in_features), dtype=torch.float32,
+                                       device=self.q0_mean.device)
+        noise = self.noise or {}
+        eps_z, eps_z2 = noise.get("eps_z"), noise.get("eps_z2")
+        if eps_z is not None:
+            eps_z = (eps_z[-1] if eps_z.dim() == 2 else eps_z).contiguous()
+        if eps_z2 is not None:
+            eps_z2 = eps_z2.reshape(-1).contiguous()
+        keep.extend([zd, rd, k1, k2, masks, eps_z, eps_z2])
+        import ctypes as _ct
+        from . import _lib
+        dl.q0_mean, dl.q0_log_var = self.q0_mean.data_ptr(), self.q0_log_var.data_ptr()
+        dl.zt = _ct.cast(zd, _ct.POINTER(_lib.DenseTransform))
+        dl.rt = _ct.cast(rd, _ct.POINTER(_lib.DenseTransform)) if rd is not None else None
+        dl.eps_fwd = eps_z.data_ptr() if eps_z is not None else None
+        dl.eps_kl = eps_z2.data_ptr() if eps_z2 is not None else None
+        dl.z_fwd, dl.z_kl, dl.scal, dl.work = ws.z_fwd.data_ptr(), ws.z_kl.data_ptr(), ws.scal.data_ptr(), ws.flow_work.data_ptr()
+        dl.Tz, dl.Tr, dl.I, dl.want_kl, dl.layer_id = Tz, Tr, self.in_features, int(want_kl), self._layer_id
 
     def _uses_rng(self, cfg):
         noise = self.noise or {}
@@ -678,6 +714,28 @@ class _NetworkBase(nn.Module):
             l._split_now = l._split(x if i == 0 else None) and (i == 0 or layers[i - 1].out_features % 4 == 0)
             keep.append(l._fill_desc(descs[i], c, kls[i] if c[1] else None))
         stream = torch.cuda.current_stream(dev).cuda_stream
+        # flows that are not planar run first (K4 batched over the layers; 1-D chains per layer), then lbbnn_layers_operands
+        # runs K1 only for those layers (flows_done)
+        dense = [(l, c) for l, c in zip(layers, cfgs) if l._mnf and l._check_flows() == "dense"]
+        if dense:
+            same = len({(len(l.z_flow.transforms), len(l.r_flow.transforms), c[1]) for l, c in dense}) == 1
+            groups = [dense] if same else [[lc] for lc in dense]
+            for grp in groups:
+                dls = (_lib.DenseLayer * len(grp))()
+                for k, (l, c) in enumerate(grp):
+                    l._dense_layer_desc(dls[k], c, keep)
+                _lib.check(_lib.lib().lbbnn_layers_dense_flows(dls, len(grp), rng.data_ptr() if rng is not None else None, stream),
+                           "lbbnn_layers_dense_flows")
+        for l, c in zip(layers, cfgs):
+            if l._mnf and l._check_flows() == "chain":
+                noise = l.noise or {}
+                eps_z, eps_z2 = noise.get("eps_z"), noise.get("eps_z2")
+                if eps_z is not None:
+                    eps_z = (eps_z[-1] if eps_z.dim() == 2 else eps_z).contiguous()
+                if eps_z2 is not None:
+                    eps_z2 = eps_z2.reshape(-1).contiguous()
+                keep.extend([eps_z, eps_z2])
+                l._chain_flows(rng, eps_z, eps_z2, c[1])
         _lib.check(_lib.lib().lbbnn_layers_operands(descs, n, rng.data_ptr() if rng is not None else None, stream),
                    "lbbnn_layers_operands")
         for i, (l, c) in enumerate(zip(layers, cfgs)):

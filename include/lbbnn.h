@@ -182,6 +182,19 @@ int lbbnn_mnf_flow_dense(const float* q0_mean, const float* q0_log_var,
                          float* z_fwd, float* z_kl, float* scal, float* work,
                          int I, int want_kl, void* stream);
 
+/* The same for up to LBBNN_MAX_LAYERS layers at once (blockIdx.z = layer): 2 + 2*(Tz+Tr) launches for the whole network
+ * instead of that many per layer.  The layers must agree on Tz, Tr and want_kl (LBBNN_E_SHAPE otherwise). */
+typedef struct lbbnn_dense_layer {
+    const float *q0_mean, *q0_log_var;
+    const lbbnn_dense_transform_t *zt, *rt;
+    const float *eps_fwd, *eps_kl;
+    float *z_fwd, *z_kl, *scal, *work;          /* work: lbbnn_flow_dense_workspace(I) floats */
+    int Tz, Tr, I, want_kl;
+    uint32_t layer_id;
+} lbbnn_dense_layer_t;
+
+int lbbnn_layers_dense_flows(const lbbnn_dense_layer_t* layers, int n, const uint64_t* rng, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K5  lbbnn_kl_finalize -- the O(O+I) tail of the KL and the final scalar.
  *
@@ -234,6 +247,8 @@ typedef struct lbbnn_layer_desc {
     void *e_w, *var_w;                           /* [O][lbbnn_operand_ld(I)]     */
     float *kl_rows, *act_mu, *act_var, *bias_var;/* (O) each                     */
     float* kl_layer;                             /* 1 float: this layer's KL     */
+    int flows_done;          /* nonzero: z_fwd / z_kl / scal were already produced by the caller (lbbnn_layers_dense_flows,
+                                lbbnn_flow_chain): lbbnn_layers_operands then runs K1 only for this layer */
 } lbbnn_layer_desc_t;
 
 int lbbnn_layers_prepare(const lbbnn_layer_desc_t* layers, int n, const uint64_t* rng, void* stream);

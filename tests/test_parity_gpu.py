@@ -1202,3 +1202,36 @@ def test_dense_flow_hip_backward_vs_oracle_autograd(bnn, dev, kind, B, I, O, T, 
             assert prm.grad is None or float(prm.grad.abs().max()) < 1e-12, name
             continue
         assert rel_err(prm.grad.cpu().double(), ref) < 5e-4, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["RNVP", "MNF", "Householder"])
+def test_fused_network_forward_non_planar_flows_vs_oracle(bnn, dev, kind):
+    """No-grad network forward with dense (K4 batched over the layers) or 1-D chain flows, then K1 with flows_done:
+    outputs and KL against the oracle network with the same draws and masks."""
+    torch.manual_seed(31)
+    dims, B, T = (96, 72, 40, 10), 24, 2
+    net = bnn.mnf.BayesianNetwork(dims, T, z_flow_type=kind, r_flow_type=kind).to(dev).train()
+    g = torch.Generator().manual_seed(32)
+    x = torch.rand(B, dims[0], generator=g)
+    layers = [net.l1, net.l2, net.l3]
+    noises, P, zf, rf = [], [], [], []
+    for l in layers:
+        I, O = l.in_features, l.out_features
+        n = {"eps_z": torch.randn(1, I, generator=g), "eps_out": torch.randn(B, O, generator=g),
+             "eps_z2": torch.randn(1, I, generator=g), "eps_act": torch.randn(O, generator=g)}
+        if kind in ("RNVP", "MNF"):
+            bern = lambda: torch.bernoulli(torch.full((I,), 0.5), generator=g)
+            n.update(zmask=[bern() for _ in range(T)], zmask2=[bern() for _ in range(T)], rmask=[bern() for _ in range(T)])
+        noises.append(n)
+        l.noise = {k: ([m.to(dev) for m in v] if isinstance(v, list) else v.to(dev)) for k, v in n.items()}
+        sd = {k: v.detach().cpu() for k, v in l.state_dict().items()}
+        P.append(sd)
+        zf.append(orc.flow_from_state("z_flow", kind, sd, len(l.z_flow.transforms)))
+        rf.append(orc.flow_from_state("r_flow", kind, sd, len(l.r_flow.transforms)))
+    with torch.no_grad():
+        out = net(x.to(dev), sample=True)
+        kl = net.kl()
+    ref_out, ref_kl = orc.mnf_network_forward(x, P, zf, rf, noises)
+    assert rel_err(out.cpu(), ref_out) < TOL
+    assert abs(float(kl) - float(ref_kl)) / abs(float(ref_kl)) < TOL
