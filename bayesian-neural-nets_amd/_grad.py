@@ -196,6 +196,32 @@ import os as _os
 _DENSE_HIP = _os.environ.get("LBBNN_DENSE_HIP_BWD", "0") == "1"
 
 
+def _dense_pair(za, zb, kind, tr, masks_a, masks_b):
+    """The same dense flow applied to TWO vectors (the forward draw and the KL draw of the z flow) as one batch of two
+    rows: half the torch launches of two _dense calls.  Returns (za', zb', logdet_b)."""
+    Z = torch.stack((za, zb))                                   # (2, I)
+    ld = Z.new_zeros(())
+    for t, ma, mb in zip(tr, masks_a, masks_b):
+        M = torch.stack((ma.reshape(-1), mb.reshape(-1)))
+        if kind == "RNVP":
+            Y = M * Z
+            for li, idx in enumerate((0, 2, 4, 6)):
+                Y = Y @ t["network.%d.weight" % idx].T + t["network.%d.bias" % idx]
+                if li < 3:
+                    Y = _leaky(Y)
+            shift = Y @ t["t.weight"].T + t["t.bias"]
+            gate = torch.sigmoid(Y @ t["s.weight"].T + t["s.bias"])
+            Z = ((1 - M) * Z) * gate + (1 - gate) * shift + M * Z
+            ld = ld + ((1 - M[1]) * gate[1].log()).sum()
+        else:
+            H = torch.tanh((M * Z) @ t["f.weight"].T + t["f.bias"])
+            mu = H @ t["g.weight"].T + t["g.bias"]
+            sig = torch.sigmoid(H @ t["k.weight"].T + t["k.bias"])
+            Z = M * Z + (1 - M) * (Z * sig + (1 - sig) * mu)
+            ld = ld + ((1 - M[1]) * sig[1].log()).sum()
+    return Z[0], Z[1], ld
+
+
 def _flow(z, spec, masks):
     kind, tr = spec
     if kind == "Planar":
@@ -266,12 +292,18 @@ def mnf_vector_graph(P, zf, rf, noise, act_mu, act_var, *, stochastic, want_kl, 
     the bias terms, as functions of the vector parameters and of the auxiliary activations act_mu / act_var
     (leaves here: their dependence on the weights is differentiated by lbbnn_weight_pass_backward)."""
     q0_std = P["q0_log_var"].exp().sqrt()
-    z_k, _ = _flow(P["q0_mean"] + q0_std * noise["eps_z"], zf, noise.get("zmask"))
+    pair = want_kl and zf[0] in ("RNVP", "MNF") and not _DENSE_HIP
+    if pair:                                                   # both draws through the coupling MLPs as one 2-row batch
+        z0 = P["q0_mean"] + q0_std * noise["eps_z2"]
+        z_k, z2, log_det_q = _dense_pair(P["q0_mean"] + q0_std * noise["eps_z"], z0, zf[0], zf[1], noise["zmask"], noise["zmask2"])
+    else:
+        z_k, _ = _flow(P["q0_mean"] + q0_std * noise["eps_z"], zf, noise.get("zmask"))
     g = {"z_k": z_k, "z2": None, "bmean": P["bias_mu"],
          "bvar": _sigma(P["bias_rho"]) ** 2 if stochastic else None, "kl": None}
     if want_kl:
-        z0 = P["q0_mean"] + q0_std * noise["eps_z2"]
-        z2, log_det_q = _flow(z0, zf, noise.get("zmask2"))
+        if not pair:
+            z0 = P["q0_mean"] + q0_std * noise["eps_z2"]
+            z2, log_det_q = _flow(z0, zf, noise.get("zmask2"))
         log_q0 = (-0.5 * math.log(math.pi) - 0.5 * P["q0_log_var"]
                   - 0.5 * ((z0 - P["q0_mean"]) ** 2 / P["q0_log_var"].exp())).sum()
         act = torch.tanh(act_mu + act_var.sqrt() * noise["eps_act"])
