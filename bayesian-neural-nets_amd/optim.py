@@ -55,19 +55,31 @@ class Adam(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             keep = []
             chunks = [ps[i:i + _lib.ADAM_MAX_TENSORS] for i in range(0, len(ps), _lib.ADAM_MAX_TENSORS)] or [[]]
+            cache = self.__dict__.setdefault("_lists", {}).setdefault(id(group), {})    # not in param_groups: state_dict() stays plain
             for ci, chunk in enumerate(chunks):
-                lst = _lib.AdamList()
-                lst.n = len(chunk)
-                for k, p in enumerate(chunk):
+                gs = []
+                for p in chunk:
                     g = override.get(id(p), p.grad)
                     if g.is_sparse:
                         raise RuntimeError("bnn_amd.optim.Adam does not support sparse gradients")
                     if not g.is_contiguous() or g.dtype != torch.float32:
                         g = g.contiguous().float()
                         keep.append(g)
-                    s = self.state[p]
-                    lst.p[k], lst.g[k] = p.data_ptr(), g.data_ptr()
-                    lst.m[k], lst.v[k], lst.numel[k] = s["exp_avg"].data_ptr(), s["exp_avg_sq"].data_ptr(), p.numel()
+                    gs.append(g)
+                # the kernel-argument list is rebuilt only when a pointer changed (gradients living in a flat bucket, or
+                # accumulated in place, keep their addresses: 5 ctypes stores per tensor saved on every step)
+                key = (tuple(p.data_ptr() for p in chunk), tuple(g.data_ptr() for g in gs))
+                hit = cache.get(ci)
+                if hit is None or hit[0] != key:
+                    lst = _lib.AdamList()
+                    lst.n = len(chunk)
+                    for k, (p, g) in enumerate(zip(chunk, gs)):
+                        st = self.state[p]
+                        lst.p[k], lst.g[k] = p.data_ptr(), g.data_ptr()
+                        lst.m[k], lst.v[k], lst.numel[k] = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
+                    cache[ci] = (key, lst)
+                else:
+                    lst = hit[1]
                 rc = _lib.lib().lbbnn_adam_step(ctypes.byref(lst), group["lr"], b1, b2, group["eps"], group["weight_decay"],
                                                 step.data_ptr(), 1 if ci == len(chunks) - 1 else 0, stream)
                 _lib.check(rc, "lbbnn_adam_step")
