@@ -1235,3 +1235,15 @@ def test_fused_network_forward_non_planar_flows_vs_oracle(bnn, dev, kind):
     ref_out, ref_kl = orc.mnf_network_forward(x, P, zf, rf, noises)
     assert rel_err(out.cpu(), ref_out) < TOL
     assert abs(float(kl) - float(ref_kl)) / abs(float(ref_kl)) < TOL
+
+
+@pytest.mark.gpu
+def test_gemm_random_shape_sweep():
+    """tools/gemm_fuzz.py: 40 random (B, I, O) shapes through K1 + the dual-moment GEMM in both precisions against fp64
+    (tails in every dimension, clamped rows, split eligibility boundaries)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gemm_fuzz.py"), "3", "40"], capture_output=True, text=True,
+                       timeout=600, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "random shapes ok" in r.stdout
