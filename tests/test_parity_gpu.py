@@ -1247,3 +1247,15 @@ def test_gemm_random_shape_sweep():
                        timeout=600, cwd=root)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     assert "random shapes ok" in r.stdout
+
+
+@pytest.mark.gpu
+def test_layer_random_shape_sweep():
+    """tools/layer_fuzz.py: 16 random planar MNF layers (unaligned B / I / O, 1-3 flow steps, both precisions, ReLU on/off):
+    output, KL and every gradient of the all-HIP backward against fp64 autograd of the oracle, tolerance 2e-4 relative."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "layer_fuzz.py"), "5", "16"], capture_output=True, text=True,
+                       timeout=600, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "random layers ok" in r.stdout
