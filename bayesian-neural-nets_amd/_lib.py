@@ -92,7 +92,7 @@ class DenseLayer(ctypes.Structure):
     """lbbnn_dense_layer_t"""
     _fields_ = [("q0_mean", c_p), ("q0_log_var", c_p), ("zt", ctypes.POINTER(DenseTransform)), ("rt", ctypes.POINTER(DenseTransform)),
                 ("eps_fwd", c_p), ("eps_kl", c_p), ("z_fwd", c_p), ("z_kl", c_p), ("scal", c_p), ("work", c_p),
-                ("Tz", c_i), ("Tr", c_i), ("I", c_i), ("want_kl", c_i), ("layer_id", c_u32)]
+                ("Tz", c_i), ("Tr", c_i), ("I", c_i), ("want_kl", c_i), ("layer_id", c_u32), ("save", c_p)]
 
 
 class DenseGrad(ctypes.Structure):
@@ -135,6 +135,16 @@ class FlowBwdArgs(ctypes.Structure):
                 ("rng", c_p), ("layer_id", c_u32)]
 
 
+class DenseBwdArgs(ctypes.Structure):
+    """lbbnn_dense_bwd_args_t"""
+    _fields_ = [(n, c_p) for n in ("q0_mean", "q0_log_var", "eps_fwd", "eps_kl", "r0_b1", "r0_b2", "aux",
+                                   "dz_fwd", "dz_kl", "g_kl", "bias_mu", "bias_rho", "g_sum", "gv_sum")] + \
+               [("zt", ctypes.POINTER(DenseTransform)), ("rt", ctypes.POINTER(DenseTransform)),
+                ("d_zt", ctypes.POINTER(DenseGrad)), ("d_rt", ctypes.POINTER(DenseGrad)), ("priors", Priors)] + \
+               [(n, c_p) for n in ("d_q0_mean", "d_q0_log_var", "d_r0_b1", "d_r0_b2", "d_bias_mu", "d_bias_rho", "save", "work")] + \
+               [("Tz", c_i), ("Tr", c_i), ("O", c_i), ("I", c_i), ("rng", c_p), ("layer_id", c_u32)]
+
+
 # name -> (restype, argtypes); must list every symbol include/lbbnn.h declares
 SIGNATURES = {
     "lbbnn_abi_version": (c_i, []),
@@ -150,6 +160,9 @@ SIGNATURES = {
     "lbbnn_weight_pass_backward_workspace": (c_i64, [c_i, c_i]),
     "lbbnn_weight_pass_backward": (c_i, [ctypes.POINTER(WpbArgs), c_p]),
     "lbbnn_layers_dense_flows": (c_i, [ctypes.POINTER(DenseLayer), c_i, c_p, c_p]),
+    "lbbnn_flow_dense_save_size": (c_i64, [c_i, c_i, c_i]),
+    "lbbnn_mnf_flow_dense_backward_workspace": (c_i64, [c_i]),
+    "lbbnn_mnf_flow_dense_backward": (c_i, [ctypes.POINTER(DenseBwdArgs), c_p]),
     "lbbnn_flow_dense_apply_workspace": (c_i64, [c_i, c_i]),
     "lbbnn_flow_dense_apply": (c_i, [ctypes.POINTER(DenseTransform), c_i, c_i, c_p, c_i, c_p, c_p, c_p]),
     "lbbnn_flow_dense_apply_backward": (c_i, [ctypes.POINTER(DenseTransform), ctypes.POINTER(DenseGrad), c_i, c_i, c_p, c_p,

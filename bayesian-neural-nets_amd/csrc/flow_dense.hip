@@ -12,7 +12,8 @@ namespace {
 using namespace lbbnn;
 
 constexpr int HMAX = LBBNN_MAX_HIDDEN;
-constexpr int CB = 256;            // outputs per workgroup in the output stage
+constexpr int CB = 64;             // outputs per workgroup in the output stage (4 waves x 16 rows)
+constexpr int NTC = 256;           // threads of the output stage
 
 struct InitArgs {
     const float* q0_mean; const float* q0_log_var; const float* eps[2]; const uint64_t* rng;
@@ -55,11 +56,17 @@ __global__ __launch_bounds__(256) void dense_init_kernel(const InitBatch bt) {
 
 struct StageArgs {
     lbbnn_dense_transform_t tr;
-    float* z[2];          // current z of each path (updated in place by the output stage)
-    float* h[2];          // hidden activations of stage A, HMAX floats per path
-    float* zcopy;         // if non-NULL: path 1 also stores its new z here (z_kl, after the last z_flow transform)
+    const float* zin[2];  // current z of each path ...
+    float* zout[2];       // ... and where the output stage puts the new one (== zin: in place; the next slot when the
+                          // intermediates are kept for the backward, lbbnn_dense_layer_t::save)
+    float* h[2];          // hidden activations of stage A, HMAX floats per path (slot 0 of the kept 4 x HMAX block)
+    int keep_chain;       // workgroup 0 of the output stage also stores h2 | h3 | head input behind h[path]
+    float* zcopy[2];      // if non-NULL: the path also stores its new z here (z_fwd / z_kl after the last z_flow transform)
     float* ld_part[2];    // per-workgroup log-det partials of this transform
     int I; int path_lo, npaths;   // paths handled: path_lo .. path_lo + npaths - 1
+#ifdef LAB_STAMPS             // tools/lab diagnostic build only: phase times of the output stage (10 ns units) into scal[5..7]
+    float* lab;
+#endif
 };
 
 // Stage A: one wave per hidden unit j: h[j] = act( sum_i W_in[j,i] * (m_i z_i) + b_in[j] )
@@ -73,7 +80,7 @@ __global__ __launch_bounds__(256) void dense_stage_a_kernel(const StageBatch bt)
     const int lane = threadIdx.x & 63;
     if (j >= a.tr.hidden) return;
     const float* __restrict__ w = a.tr.w_in + (size_t)j * a.I;
-    const float* __restrict__ z = a.z[path];
+    const float* __restrict__ z = a.zin[path];
     const float* __restrict__ m = path ? a.tr.mask_kl : a.tr.mask_fwd;
     float s = 0.f;
     for (int i = lane; i < a.I; i += 64) s += w[i] * (m[i] * z[i]);
@@ -86,50 +93,120 @@ __global__ __launch_bounds__(256) void dense_stage_a_kernel(const StageBatch bt)
 
 // Output stage: (RNVP) finish the MLP chain h1 -> h4 in LDS, then per output i the two H-long dots,
 // the gate and the coupling update, plus this workgroup's log-det partial.
-__global__ __launch_bounds__(CB) void dense_stage_c_kernel(const StageBatch bt) {
+__global__ __launch_bounds__(NTC) void dense_stage_c_kernel(const StageBatch bt, int use_lds) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];      // the three H x H middle matrices (use_lds)
     __shared__ float hs[2][HMAX];
     __shared__ double scratch[4];
     const LBBNN_CONST_AS StageArgs& a = kernarg_as<StageBatch>()->l[blockIdx.z];
     if (blockIdx.x * CB >= a.I) return;                                             // grid sized for the widest layer
     const int path = a.path_lo + blockIdx.y;
     const int H = a.tr.hidden, tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const bool c0 = lane < H, c1 = lane + 64 < H;
+    const bool rnvp = a.tr.kind == LBBNN_FLOW_RNVP;
+#ifdef LAB_STAMPS
+    const uint64_t lab_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // Everything this workgroup reads from global memory is requested up front, so the kernel pays ONE memory latency
+    // instead of one per phase (it is a chain of tiny dependent steps: measured 21 us with the loads where they are used):
+    //  - the rows of the two head matrices of this wave's 16 outputs -> registers
+    //  - the three middle matrices -> LDS (coalesced copy; rows of H = 75 floats are an odd number of banks apart, so
+    //    the row walk below is conflict-free)
+    constexpr int RPW = CB / 4;                                                  // rows per wave
+    const int row0 = blockIdx.x * CB, last = a.I - 1;
+    float ra0[RPW], ra1[RPW], rb0[RPW], rb1[RPW], bav[RPW], bbv[RPW], mv[RPW], zv[RPW];
+    const float* __restrict__ mask = path ? a.tr.mask_kl : a.tr.mask_fwd;
+    const float* __restrict__ zin = a.zin[path];
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const int i = min(row0 + wv + 4 * j, last);                               // clamped: rows past the end are not stored
+        const float* __restrict__ ra = a.tr.w_a + (size_t)i * H;
+        const float* __restrict__ rb = a.tr.w_b + (size_t)i * H;
+        ra0[j] = c0 ? ra[lane] : 0.f; ra1[j] = c1 ? ra[lane + 64] : 0.f;
+        rb0[j] = c0 ? rb[lane] : 0.f; rb1[j] = c1 ? rb[lane + 64] : 0.f;
+        bav[j] = a.tr.b_a[i]; bbv[j] = a.tr.b_b[i]; mv[j] = mask[i]; zv[j] = zin[i];
+    }
+    if (rnvp && use_lds) {
+        const int HH = H * H;
+        // explicit batches of 24 loads per thread before the first LDS write: left as a plain copy loop the compiler
+        // waited for each load (or small group) before issuing the next, 22 x 3 memory round trips per workgroup
+        constexpr int NB = 24;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            const float* __restrict__ wg = a.tr.w_mid[l];
+            for (int base = tid; base < HH; base += NTC * NB) {
+                float v[NB];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) { const int e = base + j * NTC; v[j] = e < HH ? wg[e] : 0.f; }
+#pragma unroll
+                for (int j = 0; j < NB; ++j) { const int e = base + j * NTC; if (e < HH) wl[l * HH + e] = v[j]; }
+            }
+        }
+    }
+    float bm[3] = {0.f, 0.f, 0.f};                                               // middle-layer biases: requested with the rest
+    if (rnvp && tid < H) {
+#pragma unroll
+        for (int l = 0; l < 3; ++l) bm[l] = a.tr.b_mid[l][tid];
+    }
     if (tid < H) hs[0][tid] = a.h[path][tid];
     __syncthreads();
+#ifdef LAB_STAMPS
+    if (blockIdx.x == 0 && tid == 0) a.lab[0] = (float)(__builtin_amdgcn_s_memrealtime() - lab_t0);
+#endif
     int cur = 0;
-    if (a.tr.kind == LBBNN_FLOW_RNVP) {
-#pragma unroll 1
+    if (rnvp) {
+#pragma unroll
         for (int l = 0; l < 3; ++l) {
             if (tid < H) {
-                const float* __restrict__ w = a.tr.w_mid[l] + (size_t)tid * H;
-                float s = 0.f;
-                for (int k = 0; k < H; ++k) s += w[k] * hs[cur][k];
-                s += a.tr.b_mid[l][tid];
-                hs[cur ^ 1][tid] = (l < 2) ? (s >= 0.f ? s : 0.1f * s) : s;      // last LeakyReLU dropped (:185)
+                // four independent partial sums: a single accumulator made this a chain of H dependent LDS round trips
+                const float* hv = hs[cur];
+                auto dot = [&](const float* w) {
+                    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                    int k = 0;
+                    for (; k + 4 <= H; k += 4) { s0 += w[k] * hv[k]; s1 += w[k + 1] * hv[k + 1]; s2 += w[k + 2] * hv[k + 2]; s3 += w[k + 3] * hv[k + 3]; }
+                    for (; k < H; ++k) s0 += w[k] * hv[k];
+                    return (s0 + s1) + (s2 + s3);
+                };
+                float s = use_lds ? dot(wl + l * H * H + tid * H) : dot(a.tr.w_mid[l] + (size_t)tid * H);   // LDS | global walk
+                s += bm[l];
+                s = (l < 2) ? (s >= 0.f ? s : 0.1f * s) : s;                       // last LeakyReLU dropped (:185)
+                hs[cur ^ 1][tid] = s;
+                if (a.keep_chain && blockIdx.x == 0) a.h[path][(l + 1) * HMAX + tid] = s;
             }
             __syncthreads();
             cur ^= 1;
         }
-    }
-    const int i = blockIdx.x * CB + tid;
-    double ld = 0.0;
-    if (i < a.I) {
-        const float* __restrict__ wa = a.tr.w_a + (size_t)i * H;
-        const float* __restrict__ wb = a.tr.w_b + (size_t)i * H;
-        float sa = 0.f, sb = 0.f;
-        for (int k = 0; k < H; ++k) { const float hk = hs[cur][k]; sa += wa[k] * hk; sb += wb[k] * hk; }
-        sa += a.tr.b_a[i]; sb += a.tr.b_b[i];
-        const float m = (path ? a.tr.mask_kl : a.tr.mask_fwd)[i];
-        const float z = a.z[path][i];
+    } else if (a.keep_chain && blockIdx.x == 0 && tid < H) a.h[path][3 * HMAX + tid] = hs[0][tid];
+#ifdef LAB_STAMPS
+    if (blockIdx.x == 0 && tid == 0) a.lab[1] = (float)(__builtin_amdgcn_s_memrealtime() - lab_t0);
+#endif
+    // heads: one WAVE per output row i, lanes over the H columns (coalesced 4*H-byte rows of the two head matrices)
+    const float y0 = c0 ? hs[cur][lane] : 0.f, y1 = c1 ? hs[cur][lane + 64] : 0.f;
+    float ldw = 0.f;
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const int i = row0 + wv + 4 * j;
+        const float sa = wave_sum(ra0[j] * y0 + ra1[j] * y1) + bav[j];
+        const float sb = wave_sum(rb0[j] * y0 + rb1[j] * y1) + bbv[j];
+        const float m = mv[j], z = zv[j];
         const float g = 1.f / (1.f + expf(-sb));                               // sigmoid: gate (:214) / sigma (:237)
         float zn;
-        if (a.tr.kind == LBBNN_FLOW_RNVP) zn = ((1.f - m) * z) * g + (1.f - g) * sa + m * z;       // :215
-        else zn = m * z + (1.f - m) * (z * g + (1.f - g) * sa);                                     // :238
-        a.z[path][i] = zn;
-        if (path == 1 && a.zcopy) a.zcopy[i] = zn;
-        ld = (double)((1.f - m) * logf(g));                                     // :219 / :241
+        if (rnvp) zn = ((1.f - m) * z) * g + (1.f - g) * sa + m * z;           // :215
+        else zn = m * z + (1.f - m) * (z * g + (1.f - g) * sa);                 // :238
+        if (i <= last) {
+            if (lane == 0) {
+                a.zout[path][i] = zn;
+                if (a.zcopy[path]) a.zcopy[path][i] = zn;
+            }
+            ldw += (1.f - m) * logf(g);                                         // :219 / :241 (wave-uniform)
+        }
     }
-    ld = block_sum<double, 4>(ld, scratch);
-    if (tid == 0) a.ld_part[path][blockIdx.x] = (float)ld;
+    if (lane == 0) scratch[wv] = (double)ldw;
+    __syncthreads();
+    if (tid == 0) a.ld_part[path][blockIdx.x] = (float)((scratch[0] + scratch[1]) + (scratch[2] + scratch[3]));
+#ifdef LAB_STAMPS
+    if (blockIdx.x == 0 && tid == 0) a.lab[2] = (float)(__builtin_amdgcn_s_memrealtime() - lab_t0);
+#endif
 }
 
 struct FinishArgs {
@@ -140,23 +217,19 @@ struct FinishArgs {
 // scal[0] = log_det_q, [1] = log_q0, [2] = log_det_r, [3] = r_flow(z2)[-1], [4] = forward-draw log-det
 struct FinishBatch { FinishArgs l[LBBNN_MAX_LAYERS]; };
 
-__global__ void dense_finish_kernel(const FinishBatch bt) {
+__global__ __launch_bounds__(64) void dense_finish_kernel(const FinishBatch bt) {
     const LBBNN_CONST_AS FinishArgs& a = kernarg_as<FinishBatch>()->l[blockIdx.x];
-    if (threadIdx.x != 0) return;
-    float s = 0.f;
-    for (int t = 0; t < a.Tz * a.nblk; ++t) s += a.ldf[t];
-    a.scal[4] = s;
+    const int lane = threadIdx.x;
+    auto total = [&](const float* v, int n) {                                  // fixed order: strided partials, wave tree
+        float s = 0.f;
+        for (int t = lane; t < n; t += 64) s += v[t];
+        return wave_sum(s);
+    };
+    const float ldf = total(a.ldf, a.Tz * a.nblk);
+    if (lane == 0) a.scal[4] = ldf;
     if (!a.want_kl) return;
-    s = 0.f;
-    for (int t = 0; t < a.Tz * a.nblk; ++t) s += a.ldz[t];
-    a.scal[0] = s;
-    s = 0.f;
-    for (int t = 0; t < a.nblk_i; ++t) s += a.lq0[t];
-    a.scal[1] = s;
-    s = 0.f;
-    for (int t = 0; t < a.Tr * a.nblk; ++t) s += a.ldr[t];
-    a.scal[2] = s;
-    a.scal[3] = a.zr[a.I - 1];
+    const float ldz = total(a.ldz, a.Tz * a.nblk), lq0 = total(a.lq0, a.nblk_i), ldr = total(a.ldr, a.Tr * a.nblk);
+    if (lane == 0) { a.scal[0] = ldz; a.scal[1] = lq0; a.scal[2] = ldr; a.scal[3] = a.zr[a.I - 1]; }
 }
 
 bool transform_ok(const lbbnn_dense_transform_t& t, bool need_fwd, bool need_kl) {
@@ -177,6 +250,12 @@ extern "C" int64_t lbbnn_flow_dense_workspace(int I) {
     if (I <= 0) return 0;
     const int64_t nblk = (I + CB - 1) / CB, nblk_i = (I + 255) / 256;
     return 2 * (int64_t)I + 2 * HMAX + nblk_i + 3 * (int64_t)LBBNN_MAX_FLOW_T * nblk + 64;
+}
+
+// kept intermediates (floats): ZF[Tz+1][I] | ZK[Tz+1][I] | ZR[Tr][I] | per (transform, path): h1 | h2 | h3 | head input
+extern "C" int64_t lbbnn_flow_dense_save_size(int I, int Tz, int Tr) {
+    if (I <= 0 || Tz < 0 || Tr < 0) return 0;
+    return (int64_t)I * (2 * (Tz + 1) + Tr) + (int64_t)(Tz + Tr) * 2 * 4 * HMAX;
 }
 
 // K4 of n layers in 2 + 2*(Tz+Tr) launches (blockIdx.z = layer); the layers must agree on Tz, Tr and want_kl
@@ -200,7 +279,7 @@ static int dense_flows_impl(const lbbnn_dense_layer_t* L, int n, const uint64_t*
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int npaths = want_kl ? 2 : 1;
     const int gblk = (maxI + CB - 1) / CB, gblk_i = (maxI + 255) / 256;
-    struct Bufs { float *zbuf1, *h0, *h1, *lq0, *ldf, *ldz, *ldr; int nblk, nblk_i; } B[LBBNN_MAX_LAYERS];
+    struct Bufs { float *zbuf1, *h0, *h1, *lq0, *ldf, *ldz, *ldr, *ZF, *ZK, *ZR, *HS; int nblk, nblk_i; } B[LBBNN_MAX_LAYERS];
     InitBatch ib{};
     for (int k = 0; k < n; ++k) {
         const lbbnn_dense_layer_t& d = L[k];
@@ -211,9 +290,12 @@ static int dense_flows_impl(const lbbnn_dense_layer_t* L, int n, const uint64_t*
         b.ldf = b.lq0 + b.nblk_i;
         b.ldz = b.ldf + (size_t)LBBNN_MAX_FLOW_T * b.nblk;
         b.ldr = b.ldz + (size_t)LBBNN_MAX_FLOW_T * b.nblk;
+        b.ZF = d.save; b.ZK = d.save ? b.ZF + (size_t)(Tz + 1) * d.I : nullptr;
+        b.ZR = d.save ? b.ZK + (size_t)(Tz + 1) * d.I : nullptr;
+        b.HS = d.save ? b.ZR + (size_t)d.Tr * d.I : nullptr;
         InitArgs& ia = ib.l[k];
         ia.q0_mean = d.q0_mean; ia.q0_log_var = d.q0_log_var; ia.eps[0] = d.eps_fwd; ia.eps[1] = d.eps_kl; ia.rng = rng;
-        ia.z[0] = d.z_fwd; ia.z[1] = b.zbuf1; ia.lq0_part = b.lq0; ia.I = d.I; ia.layer = d.layer_id & 63u; ia.npaths = npaths;
+        ia.z[0] = d.save ? b.ZF : d.z_fwd; ia.z[1] = d.save ? b.ZK : b.zbuf1; ia.lq0_part = b.lq0; ia.I = d.I; ia.layer = d.layer_id & 63u; ia.npaths = npaths;
     }
     hipLaunchKernelGGL(dense_init_kernel, dim3(gblk_i, npaths, n), dim3(256), 0, s, ib);
 
@@ -225,25 +307,51 @@ static int dense_flows_impl(const lbbnn_dense_layer_t* L, int n, const uint64_t*
             const Bufs& b = B[k];
             StageArgs& sa = sb.l[k];
             sa.tr = zphase ? d.zt[t] : d.rt[t - Tz];
-            sa.z[0] = d.z_fwd; sa.z[1] = b.zbuf1; sa.h[0] = b.h0; sa.h[1] = b.h1;
-            sa.zcopy = (zphase && want_kl && t == Tz - 1) ? d.z_kl : nullptr;
+            if (d.save) {
+                const int tr_ = zphase ? t : t - Tz;
+                sa.zin[0] = b.ZF + (size_t)t * d.I; sa.zout[0] = b.ZF + (size_t)(t + 1) * d.I;       // path 0: z phase only
+                sa.zin[1] = zphase ? b.ZK + (size_t)t * d.I : (tr_ == 0 ? b.ZK + (size_t)Tz * d.I : b.ZR + (size_t)(tr_ - 1) * d.I);
+                sa.zout[1] = zphase ? b.ZK + (size_t)(t + 1) * d.I : b.ZR + (size_t)tr_ * d.I;
+                sa.h[0] = b.HS + ((size_t)t * 2 + 0) * 4 * HMAX; sa.h[1] = b.HS + ((size_t)t * 2 + 1) * 4 * HMAX;
+                sa.keep_chain = 1;
+                sa.zcopy[0] = (zphase && t == Tz - 1) ? d.z_fwd : nullptr;
+            } else {
+                sa.zin[0] = sa.zout[0] = d.z_fwd; sa.zin[1] = sa.zout[1] = b.zbuf1; sa.h[0] = b.h0; sa.h[1] = b.h1;
+                sa.keep_chain = 0;
+                sa.zcopy[0] = nullptr;
+            }
+            sa.zcopy[1] = (zphase && want_kl && t == Tz - 1) ? d.z_kl : nullptr;
             sa.ld_part[0] = b.ldf + (size_t)t * b.nblk;
             sa.ld_part[1] = zphase ? b.ldz + (size_t)t * b.nblk : b.ldr + (size_t)(t - Tz) * b.nblk;
             sa.I = d.I;
+#ifdef LAB_STAMPS
+            sa.lab = d.scal + 5;
+#endif
             sa.path_lo = zphase ? 0 : 1;
             sa.npaths = zphase ? npaths : 1;
         }
         const int np = zphase ? npaths : 1;
         hipLaunchKernelGGL(dense_stage_a_kernel, dim3((maxH + 3) / 4, np, n), dim3(256), 0, s, sb);
-        hipLaunchKernelGGL(dense_stage_c_kernel, dim3(gblk, np, n), dim3(CB), 0, s, sb);
+        // the three middle matrices of a transform in LDS: 66 KB for the reference's H = 75, 117 KB for H = 100
+        const size_t wl_bytes = (size_t)3 * maxH * maxH * sizeof(float);
+        int use_lds = wl_bytes <= 144 * 1024 ? 1 : 0;
+        static size_t raised = 0;
+        if (use_lds && wl_bytes > 48 * 1024 && wl_bytes > raised) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(dense_stage_c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)wl_bytes) == hipSuccess) raised = wl_bytes;
+            else use_lds = 0;
+        }
+        hipLaunchKernelGGL(dense_stage_c_kernel, dim3(gblk, np, n), dim3(NTC), use_lds ? wl_bytes : 0, s, sb, use_lds);
     }
     FinishBatch fb{};
     for (int k = 0; k < n; ++k) {
         const lbbnn_dense_layer_t& d = L[k];
         const Bufs& b = B[k];
-        if (want_kl && Tz == 0) (void)hipMemcpyAsync(d.z_kl, b.zbuf1, (size_t)d.I * sizeof(float), hipMemcpyDeviceToDevice, s);
+        if (want_kl && Tz == 0) (void)hipMemcpyAsync(d.z_kl, d.save ? b.ZK : b.zbuf1, (size_t)d.I * sizeof(float), hipMemcpyDeviceToDevice, s);
+        if (d.save && Tz == 0) (void)hipMemcpyAsync(d.z_fwd, b.ZF, (size_t)d.I * sizeof(float), hipMemcpyDeviceToDevice, s);
         FinishArgs& fa = fb.l[k];
-        fa.ldz = b.ldz; fa.ldr = b.ldr; fa.lq0 = b.lq0; fa.zr = b.zbuf1; fa.ldf = b.ldf; fa.scal = d.scal;
+        fa.ldz = b.ldz; fa.ldr = b.ldr; fa.lq0 = b.lq0;
+        fa.zr = !d.save ? b.zbuf1 : ((want_kl && Tr > 0) ? b.ZR + (size_t)(Tr - 1) * d.I : b.ZK + (size_t)Tz * d.I); fa.ldf = b.ldf; fa.scal = d.scal;
         fa.nblk = b.nblk; fa.nblk_i = b.nblk_i; fa.Tz = Tz; fa.Tr = want_kl ? Tr : 0; fa.I = d.I; fa.want_kl = want_kl;
     }
     hipLaunchKernelGGL(dense_finish_kernel, dim3(n), dim3(64), 0, s, fb);
@@ -264,6 +372,6 @@ extern "C" int lbbnn_mnf_flow_dense(const float* q0_mean, const float* q0_log_va
     lbbnn_dense_layer_t d{};
     d.q0_mean = q0_mean; d.q0_log_var = q0_log_var; d.zt = zt; d.rt = rt; d.Tz = Tz; d.Tr = Tr;
     d.eps_fwd = eps_fwd; d.eps_kl = eps_kl; d.layer_id = layer_id; d.z_fwd = z_fwd; d.z_kl = z_kl; d.scal = scal; d.work = work;
-    d.I = I; d.want_kl = want_kl;
+    d.I = I; d.want_kl = want_kl; d.save = nullptr;
     return dense_flows_impl(&d, 1, rng, stream);
 }

@@ -30,6 +30,11 @@ from ._lib import Priors
 from .distributions import Bernoulli, Gaussian
 from .flows import PropagateFlow
 
+import os as _os
+# LBBNN_DENSE_TORCH_BWD=1: differentiate the dense (RNVP / MNF-type) flows with torch autograd on the GPU vectors, as
+# before lbbnn_mnf_flow_dense_backward existed (kept for A/B timing and as a second opinion in the tests)
+_DENSE_HIP_BWD = _os.environ.get("LBBNN_DENSE_TORCH_BWD", "0") != "1"
+
 _layer_ids = itertools.count()
 
 
@@ -50,7 +55,14 @@ class _BayesLinearFn(torch.autograd.Function):
             ws = layer._workspace()
             for name in ("z_fwd", "z_kl", "scal", "act_mu", "act_var"):
                 setattr(ws, name, torch.empty_like(getattr(ws, name)))
-        out, kl, saved = layer._forward_hip(x, cfg, save_rng=True, want_std=cfg[0])
+        dense = layer._mnf and layer._check_flows() == "dense" and _DENSE_HIP_BWD
+        layer._keep_dense = dense
+        try:
+            out, kl, saved = layer._forward_hip(x, cfg, save_rng=True, want_std=cfg[0])
+        finally:
+            layer._keep_dense = False
+        if dense:
+            saved["dense_save"], layer._last_dense_save = layer._last_dense_save, None
         if layer._mnf:
             saved["z_fwd"] = ws.z_fwd
             if cfg[1]:
@@ -81,13 +93,14 @@ class _BayesLinearFn(torch.autograd.Function):
             rng=ctx.saved.get("rng"), rng_stream=ops.STREAM_EPS_OUT * 64 + layer._layer_id, row_offset=layer.row_offset,
             relu=relu)
         planar = layer._mnf and layer._check_flows() == "planar"
-        # planar MNF layers re-create their small draws inside V1 / V2; the torch-graph paths need them as tensors
+        dense = layer._mnf and ctx.saved.get("dense_save") is not None
+        # planar / dense MNF layers re-create their small draws inside V1 / V2; the torch-graph paths need them as tensors
         rng_snap = ctx.saved.get("rng")
-        in_kernel = planar and not explicit and rng_snap is not None
+        in_kernel = (planar or dense) and not explicit and rng_snap is not None
         noise = {} if in_kernel else layer._noise_for_backward(ctx.saved, B, need_out=False)
         g_kl = g_kl.contiguous() if want_kl else None
         da_mu = da_var = aux = r0_c = vg = None
-        if planar:
+        if planar or dense:
             # ---- all-HIP chain: V1 (aux activations) -> GEMMs -> K1b -> V2 (flows, q0, r0_b, bias)
             P = dict(zip(layer._vec_names, params[3:3 + len(layer._vec_names)]))
             z_k = ctx.saved["z_fwd"]
@@ -142,6 +155,26 @@ class _BayesLinearFn(torch.autograd.Function):
                 for g3 in G[key]:
                     vgrads += list(g3)
             return (None, gx, None, dmu, drho, dlam, *vgrads)
+        if dense:
+            masks = ctx.saved["masks"]
+            zd, Tz, k1 = layer.z_flow.dense_descs(masks["zmask"], masks.get("zmask2"))
+            # no KL branch: the forward ran (and laid out what it kept) with Tr = 0; the r-flow gradients are zeros
+            rd, Tr, k2 = layer.r_flow.dense_descs(None, masks.get("rmask")) if want_kl else (None, 0, None)
+            rest = list(params[len(layer._names):])
+            nz = len(list(layer.z_flow.parameters()))
+            G = ops.mnf_flow_dense_backward(
+                P["q0_mean"], P["q0_log_var"], zd, Tz, 0 if layer.z_flow.kind == "RNVP" else 1, rest[:nz],
+                rd, Tr, 0 if layer.r_flow.kind == "RNVP" else 1, rest[nz:], save=ctx.saved["dense_save"],
+                eps_fwd=None if in_kernel else noise["eps_z"].contiguous(),
+                eps_kl=noise["eps_z2"].contiguous() if (want_kl and not in_kernel) else None,
+                rng=rng_snap, layer_id=layer._layer_id, r0_b1=P["r0_b1"], r0_b2=P["r0_b2"], aux=aux,
+                dz_fwd=dz_k, dz_kl=dz2, g_kl=g_kl, bias_mu=P["bias_mu"], bias_rho=P["bias_rho"], g_sum=g_sum,
+                gv_sum=gv_sum, priors=layer.priors)
+            del k1, k2
+            G["r0_c"] = dr0c if dr0c is not None else torch.zeros_like(P["q0_mean"])
+            if not want_kl:
+                G["r_flow"] = [torch.zeros_like(p) for p in rest[nz:]]
+            return (None, gx, None, dmu, drho, dlam, *[G[n] for n in layer._vec_names], *G["z_flow"], *G["r_flow"])
         outs, gouts = [vg["bmean"]], [g_sum]
         if stochastic:
             outs.append(vg["bvar"]); gouts.append(gv_sum)
@@ -202,6 +235,8 @@ class _BayesLinearBase(nn.Module):
         self._layer_id = next(_layer_ids) % 64
         self._ws = None
         self._split_now = False        # decided per forward (prep and GEMM must agree on the operand format)
+        self._keep_dense = False       # set by the autograd forward: dense flows keep their intermediates
+        self._last_dense_save = None
         self._last_masks = None
 
     # reference keeps the prior tensors as attributes; expose them lazily with the same names
@@ -561,17 +596,20 @@ class MNFBayesianLinear(_BayesLinearBase):
         elif family == "chain":
             self._chain_flows(rng, eps_z, eps_z2, want_kl)
         else:
-            masks = self._masks(cfg, 0)
-            self._last_masks = masks
-            zd, Tz, k1 = self.z_flow.dense_descs(masks["zmask"], masks.get("zmask2"))
-            rd, Tr, k2 = self.r_flow.dense_descs(None, masks.get("rmask")) if want_kl else (None, 0, None)
-            if getattr(ws, "flow_work", None) is None:
-                ws.flow_work = torch.empty(ops.flow_dense_workspace(self.in_features), dtype=torch.float32,
-                                           device=self.q0_mean.device)
-            ops.mnf_flow_dense(self.q0_mean, self.q0_log_var, zd, Tz, rd, Tr, eps_fwd=eps_z, eps_kl=eps_z2,
-                               rng=rng, layer_id=self._layer_id, z_fwd=ws.z_fwd, z_kl=ws.z_kl, scal=ws.scal,
-                               work=ws.flow_work, want_kl=want_kl)
-            del k1, k2
+            from . import _lib
+            dl, keep = (_lib.DenseLayer * 1)(), []
+            self._dense_layer_desc(dl[0], cfg, keep)
+            self._last_dense_save = None
+            if self._keep_dense:
+                # training: the forward keeps every transform's input and the coupling MLPs' hidden activations for
+                # lbbnn_mnf_flow_dense_backward (a fresh buffer per call: it belongs to this call's autograd node)
+                self._last_dense_save = torch.empty(ops.flow_dense_save_size(self.in_features, dl[0].Tz, dl[0].Tr),
+                                                    dtype=torch.float32, device=self.q0_mean.device)
+                dl[0].save = self._last_dense_save.data_ptr()
+            _lib.check(_lib.lib().lbbnn_layers_dense_flows(dl, 1, rng.data_ptr() if rng is not None else None,
+                                                           torch.cuda.current_stream(self.q0_mean.device).cuda_stream),
+                       "lbbnn_layers_dense_flows")
+            del keep
         ops.weight_pass(self.weight_mu, self.weight_rho, self.lambdal, z_fwd=ws.z_fwd,
                         z_kl=ws.z_kl if want_kl else None, r0_c=self.r0_c if want_kl else None,
                         bias_rho=self.bias_rho, priors=self.priors, e_w=ws.e_w,

@@ -395,6 +395,63 @@ def mnf_flow_planar_backward(q0_mean, q0_log_var, z_params, r_params, *, eps_fwd
     return out
 
 
+_DENSE_GRAD_FIELDS = {0: ("w_in", "b_in", ("w_mid", 0), ("b_mid", 0), ("w_mid", 1), ("b_mid", 1), ("w_mid", 2), ("b_mid", 2),
+                          "w_a", "b_a", "w_b", "b_b"),
+                      1: ("w_in", "b_in", "w_a", "b_a", "w_b", "b_b")}
+
+
+def _dense_grad_array(kind_id, params, T):
+    """lbbnn_dense_grad_t array + fresh gradient tensors for T transforms whose parameters come in module order
+    (RNVP: network.0/2/4/6 weight, bias, t, s; MNF type: f, g, k -- the order dense_descs reads them in)."""
+    fields = _DENSE_GRAD_FIELDS[kind_id]
+    n = len(fields)
+    arr = (_lib.DenseGrad * max(T, 1))()
+    grads = [torch.empty_like(p) for p in params[:T * n]]
+    for t in range(T):
+        for f, g in zip(fields, grads[t * n:(t + 1) * n]):
+            if isinstance(f, tuple):
+                getattr(arr[t], f[0])[f[1]] = g.data_ptr()
+            else:
+                setattr(arr[t], f, g.data_ptr())
+    return arr, grads
+
+
+def mnf_flow_dense_backward(q0_mean, q0_log_var, z_descs, Tz, z_kind, z_params, r_descs, Tr, r_kind, r_params, *, save,
+                            eps_fwd=None, eps_kl=None, r0_b1=None, r0_b2=None, aux=None, dz_fwd=None, dz_kl=None, g_kl=None,
+                            bias_mu, bias_rho, g_sum, gv_sum=None, priors: Priors, rng=None, layer_id: int = 0):
+    """lbbnn_mnf_flow_dense_backward.  z_descs / r_descs: the forward's lbbnn_dense_transform_t arrays (same masks);
+    z_params / r_params: the flows' parameter tensors in module order (shapes of the gradients).  Returns a dict:
+    q0_mean, q0_log_var, r0_b1, r0_b2, bias_mu, bias_rho and z_flow / r_flow = flat gradient lists in parameter order."""
+    I, O = q0_mean.shape[0], bias_mu.shape[0]
+    a = _lib.DenseBwdArgs()
+    for name, t in (("q0_mean", q0_mean), ("q0_log_var", q0_log_var), ("eps_fwd", eps_fwd), ("eps_kl", eps_kl),
+                    ("r0_b1", r0_b1), ("r0_b2", r0_b2), ("aux", aux), ("dz_fwd", dz_fwd), ("dz_kl", dz_kl),
+                    ("g_kl", g_kl), ("bias_mu", bias_mu), ("bias_rho", bias_rho), ("g_sum", g_sum), ("gv_sum", gv_sum),
+                    ("save", save)):
+        setattr(a, name, _ptr(t, name))
+    a.priors = priors
+    f = dict(dtype=torch.float32, device=q0_mean.device)
+    out = {n: torch.empty(I, **f) for n in ("q0_mean", "q0_log_var", "r0_b1", "r0_b2")}
+    out["bias_mu"], out["bias_rho"] = torch.empty(O, **f), torch.empty(O, **f)
+    for n in ("q0_mean", "q0_log_var", "r0_b1", "r0_b2", "bias_mu", "bias_rho"):
+        setattr(a, "d_" + n, out[n].data_ptr())
+    gz, out["z_flow"] = _dense_grad_array(z_kind, z_params, Tz)
+    gr, out["r_flow"] = _dense_grad_array(r_kind, r_params, Tr)
+    a.zt = ctypes.cast(z_descs, ctypes.POINTER(_lib.DenseTransform))
+    a.rt = ctypes.cast(r_descs, ctypes.POINTER(_lib.DenseTransform)) if r_descs is not None else None
+    a.d_zt = ctypes.cast(gz, ctypes.POINTER(_lib.DenseGrad))
+    a.d_rt = ctypes.cast(gr, ctypes.POINTER(_lib.DenseGrad))
+    work = torch.empty(_lib.lib().lbbnn_mnf_flow_dense_backward_workspace(I), **f)
+    a.work, a.Tz, a.Tr, a.O, a.I = work.data_ptr(), Tz, Tr, O, I
+    a.rng, a.layer_id = (rng.data_ptr() if rng is not None else None), layer_id
+    _lib.check(_lib.lib().lbbnn_mnf_flow_dense_backward(ctypes.byref(a), _stream()), "lbbnn_mnf_flow_dense_backward")
+    return out
+
+
+def flow_dense_save_size(I: int, Tz: int, Tr: int) -> int:
+    return int(_lib.lib().lbbnn_flow_dense_save_size(I, Tz, Tr))
+
+
 # ----------------------------------------------------------------------------------------- K4
 def mnf_flow_dense(q0_mean, q0_log_var, z_descs, Tz, r_descs, Tr, *, eps_fwd=None, eps_kl=None,
                    rng: Optional[torch.Tensor] = None, layer_id: int = 0, z_fwd, z_kl=None, scal=None, work=None,

@@ -191,8 +191,12 @@ typedef struct lbbnn_dense_layer {
     float *z_fwd, *z_kl, *scal, *work;          /* work: lbbnn_flow_dense_workspace(I) floats */
     int Tz, Tr, I, want_kl;
     uint32_t layer_id;
+    float *save;                                 /* NULL, or lbbnn_flow_dense_save_size(I, Tz, Tr) floats: the forward keeps the
+                                                    input of every transform and the hidden activations of the coupling MLPs
+                                                    there for lbbnn_mnf_flow_dense_backward */
 } lbbnn_dense_layer_t;
 
+int64_t lbbnn_flow_dense_save_size(int I, int Tz, int Tr);
 int lbbnn_layers_dense_flows(const lbbnn_dense_layer_t* layers, int n, const uint64_t* rng, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -532,6 +536,38 @@ int lbbnn_flow_dense_apply(const lbbnn_dense_transform_t* tr, int T, int which_m
 int lbbnn_flow_dense_apply_backward(const lbbnn_dense_transform_t* tr, const lbbnn_dense_grad_t* grads, int T,
                                     int which_mask, const float* z_in, const float* d_zout, const float* d_logdet, int I,
                                     float* dz_in, float* work, void* stream);
+
+/* lbbnn_mnf_flow_dense_backward -- the vector-sized backward (cf. lbbnn_mnf_flow_planar_backward) for a layer whose flows are dense coupling flows
+ * (RNVP / MNF type, flows2.py:188-241; the reference's default).  Inputs as lbbnn_mnf_flow_planar_backward; the
+ * transforms (with the masks of the forward call) in zt / rt, their gradient destinations in d_zt / d_rt (host arrays),
+ * and `save` = what the forward kept (lbbnn_dense_layer_t::save).  2 + 3*(Tz+Tr) launches spread over workgroups: per
+ * transform, walking backwards, the two I x H heads (outer-product gradients, share of dy), the H x H chain in one
+ * workgroup, the H x I input layer.  Both draws of the z flow are handled together and the SUM of their parameter
+ * gradients is written once; every reduction has a fixed order (deterministic).  g_kl NULL: no KL branch, r-flow and
+ * r0_b gradients are zero-filled.  Tz / Tr must be the values the forward ran with (they fix the layout of `save`).
+ * work: lbbnn_mnf_flow_dense_backward_workspace(I) floats.
+ */
+typedef struct lbbnn_dense_bwd_args {
+    const float *q0_mean, *q0_log_var, *eps_fwd, *eps_kl;   /* (I); eps NULL: re-created from rng / layer_id          */
+    const float *r0_b1, *r0_b2;                              /* (I)                                                   */
+    const float *aux;                                        /* aux[0] = m from lbbnn_mnf_aux_backward                */
+    const float *dz_fwd, *dz_kl;                             /* (I) upstream from K1b, either may be NULL (= 0)       */
+    const float *g_kl;                                       /* device scalar or NULL                                 */
+    const float *bias_mu, *bias_rho, *g_sum, *gv_sum;        /* (O)                                                   */
+    const lbbnn_dense_transform_t *zt, *rt;
+    const lbbnn_dense_grad_t *d_zt, *d_rt;
+    lbbnn_priors_t priors;
+    float *d_q0_mean, *d_q0_log_var, *d_r0_b1, *d_r0_b2;     /* (I) outputs                                           */
+    float *d_bias_mu, *d_bias_rho;                           /* (O) outputs                                           */
+    const float *save;
+    float *work;
+    int Tz, Tr, O, I;
+    const uint64_t* rng;
+    uint32_t layer_id;
+} lbbnn_dense_bwd_args_t;
+
+int64_t lbbnn_mnf_flow_dense_backward_workspace(int I);
+int lbbnn_mnf_flow_dense_backward(const lbbnn_dense_bwd_args_t* args, void* stream);
 
 #ifdef __cplusplus
 }

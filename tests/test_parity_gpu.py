@@ -1162,13 +1162,15 @@ def test_bench_contract_json_line():
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,B,I,O,T", [("RNVP", 16, 96, 40, 2), ("MNF", 16, 96, 40, 2), ("RNVP", 32, 1200, 64, 2),
                                           ("MNF", 8, 1200, 32, 1)])
-@pytest.mark.parametrize("hip_mlp", [True, False])
-def test_dense_flow_hip_backward_vs_oracle_autograd(bnn, dev, kind, B, I, O, T, hip_mlp, monkeypatch):
+@pytest.mark.parametrize("mode", ["layer_hip", "single_wg", "torch"])
+def test_dense_flow_hip_backward_vs_oracle_autograd(bnn, dev, kind, B, I, O, T, mode, monkeypatch):
     """MNF layer with RNVP / MNF-type flows: forward, KL and every gradient against fp64 autograd of the oracle, with the
-    coupling MLPs' backward either as one HIP launch per flow application (lbbnn_flow_dense_apply[_backward], opt-in:
-    correct but slower than torch on one CU) or as the default torch formulas on the vector-sized chain."""
-    from bnn_amd import _grad
-    monkeypatch.setattr(_grad, "_DENSE_HIP", hip_mlp)
+    vector-sized chain differentiated by (layer_hip, the default) lbbnn_mnf_flow_dense_backward on the intermediates the
+    forward kept, (single_wg) torch plus one HIP launch per flow application (lbbnn_flow_dense_apply[_backward]), or
+    (torch) torch formulas only."""
+    from bnn_amd import _grad, layers
+    monkeypatch.setattr(layers, "_DENSE_HIP_BWD", mode == "layer_hip")
+    monkeypatch.setattr(_grad, "_DENSE_HIP", mode == "single_wg")
     torch.manual_seed(21)
     layer = bnn.mnf.BayesianLinear(I, O, T, z_flow_type=kind, r_flow_type=kind)
     with torch.no_grad():
@@ -1235,6 +1237,37 @@ def test_fused_network_forward_non_planar_flows_vs_oracle(bnn, dev, kind):
     ref_out, ref_kl = orc.mnf_network_forward(x, P, zf, rf, noises)
     assert rel_err(out.cpu(), ref_out) < TOL
     assert abs(float(kl) - float(ref_kl)) / abs(float(ref_kl)) < TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,want_kl", [("RNVP", True), ("MNF", True), ("RNVP", False)])
+def test_dense_flow_hip_backward_in_kernel_noise(bnn, dev, kind, want_kl, monkeypatch):
+    """In-kernel Philox draws + device-drawn masks: lbbnn_mnf_flow_dense_backward (draws re-created in the kernel) against
+    the torch-autograd chain on the same draws (re-created as tensors), same seeds; eval-mode sample=True has no KL branch
+    (r-flow gradients zero-filled)."""
+    from bnn_amd import layers
+    B, I, O, T = 24, 200, 48, 2
+    torch.manual_seed(5)
+    layer = bnn.mnf.BayesianLinear(I, O, T, z_flow_type=kind, r_flow_type=kind).to(dev)
+    layer.train(want_kl)
+    x = torch.rand(B, I, device=dev)
+    grads = {}
+    for mode in ("hip", "torch"):
+        monkeypatch.setattr(layers, "_DENSE_HIP_BWD", mode == "hip")
+        bnn.manual_seed(77, 3)
+        torch.manual_seed(9)                                  # the masks come from torch's device generator
+        layer.zero_grad(set_to_none=True)
+        xg = x.clone().requires_grad_(True)
+        out = layer(xg, sample=True)
+        loss = out.pow(2).sum() + (layer.kl / 60 if want_kl else 0)
+        loss.backward()
+        grads[mode] = {"x": xg.grad.clone(), **{n: (p.grad.clone() if p.grad is not None else None) for n, p in layer.named_parameters()}}
+    for n, g in grads["hip"].items():
+        ref = grads["torch"][n]
+        if ref is None or float(ref.abs().max()) == 0.0:
+            assert g is None or float(g.abs().max()) == 0.0, n
+            continue
+        assert rel_err(g.cpu(), ref.cpu()) < 1e-4, n
 
 
 @pytest.mark.gpu
