@@ -53,16 +53,21 @@ class _BayesLinearFn(torch.autograd.Function):
             # the backward needs this call's K3 / K1 by-products: give the call fresh output vectors instead of
             # copying them out of the (reused) workspace afterwards
             ws = layer._workspace()
-            for name in ("z_fwd", "z_kl", "scal", "act_mu", "act_var"):
+            # (the network may already have run this call's dense flows for all layers at once: _preflow_dense)
+            fresh = ("act_mu", "act_var") if layer._preflow is not None else ("z_fwd", "z_kl", "scal", "act_mu", "act_var")
+            for name in fresh:
                 setattr(ws, name, torch.empty_like(getattr(ws, name)))
         dense = layer._mnf and layer._check_flows() == "dense" and _DENSE_HIP_BWD
         layer._keep_dense = dense
+        layer._last_flow_rng = None
         try:
-            out, kl, saved = layer._forward_hip(x, cfg, save_rng=True, want_std=cfg[0])
+            out, kl, saved = layer._forward_hip(x, cfg, advance=layer._advance_rng, save_rng=True, want_std=cfg[0])
         finally:
             layer._keep_dense = False
+            layer._preflow = None
         if dense:
             saved["dense_save"], layer._last_dense_save = layer._last_dense_save, None
+            saved["rng_flow"], layer._last_flow_rng = layer._last_flow_rng, None
         if layer._mnf:
             saved["z_fwd"] = ws.z_fwd
             if cfg[1]:
@@ -167,7 +172,8 @@ class _BayesLinearFn(torch.autograd.Function):
                 rd, Tr, 0 if layer.r_flow.kind == "RNVP" else 1, rest[nz:], save=ctx.saved["dense_save"],
                 eps_fwd=None if in_kernel else noise["eps_z"].contiguous(),
                 eps_kl=noise["eps_z2"].contiguous() if (want_kl and not in_kernel) else None,
-                rng=rng_snap, layer_id=layer._layer_id, r0_b1=P["r0_b1"], r0_b2=P["r0_b2"], aux=aux,
+                rng=ctx.saved.get("rng_flow") if ctx.saved.get("rng_flow") is not None else rng_snap,
+                layer_id=layer._layer_id, r0_b1=P["r0_b1"], r0_b2=P["r0_b2"], aux=aux,
                 dz_fwd=dz_k, dz_kl=dz2, g_kl=g_kl, bias_mu=P["bias_mu"], bias_rho=P["bias_rho"], g_sum=g_sum,
                 gv_sum=gv_sum, priors=layer.priors)
             del k1, k2
@@ -237,6 +243,9 @@ class _BayesLinearBase(nn.Module):
         self._split_now = False        # decided per forward (prep and GEMM must agree on the operand format)
         self._keep_dense = False       # set by the autograd forward: dense flows keep their intermediates
         self._last_dense_save = None
+        self._preflow = None           # dense flows of this call already run by the network (batched over its layers)
+        self._advance_rng = True       # False while a network drives the layers: it advances the shared offset once
+        self._last_flow_rng = None
         self._last_masks = None
 
     # reference keeps the prior tensors as attributes; expose them lazily with the same names
@@ -329,10 +338,14 @@ class _BayesLinearBase(nn.Module):
         cfg = (bool(self.training or sample), bool(self.training or calculate_log_probs), bool(_relu))
         x = input if input.dtype == torch.float32 else input.float()
         params = self._param_list()
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
-            out, kl = _BayesLinearFn.apply(self, x, cfg, *params)
-        else:
-            out, kl, _ = self._forward_hip(x, cfg)
+        try:
+            if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
+                out, kl = _BayesLinearFn.apply(self, x, cfg, *params)
+            else:
+                self._preflow = None
+                out, kl, _ = self._forward_hip(x, cfg, advance=self._advance_rng)
+        finally:
+            self._preflow = None
         self.kl = kl if cfg[1] else 0
         return out
 
@@ -597,19 +610,24 @@ class MNFBayesianLinear(_BayesLinearBase):
             self._chain_flows(rng, eps_z, eps_z2, want_kl)
         else:
             from . import _lib
-            dl, keep = (_lib.DenseLayer * 1)(), []
-            self._dense_layer_desc(dl[0], cfg, keep)
-            self._last_dense_save = None
-            if self._keep_dense:
-                # training: the forward keeps every transform's input and the coupling MLPs' hidden activations for
-                # lbbnn_mnf_flow_dense_backward (a fresh buffer per call: it belongs to this call's autograd node)
-                self._last_dense_save = torch.empty(ops.flow_dense_save_size(self.in_features, dl[0].Tz, dl[0].Tr),
-                                                    dtype=torch.float32, device=self.q0_mean.device)
-                dl[0].save = self._last_dense_save.data_ptr()
-            _lib.check(_lib.lib().lbbnn_layers_dense_flows(dl, 1, rng.data_ptr() if rng is not None else None,
-                                                           torch.cuda.current_stream(self.q0_mean.device).cuda_stream),
-                       "lbbnn_layers_dense_flows")
-            del keep
+            pre = self._preflow
+            if pre is not None and self._keep_dense and pre["cfg"][:2] == tuple(cfg[:2]):
+                # z_fwd / z_kl / scal of this call are already in the workspace (one batched launch sequence for the net)
+                self._last_masks, self._last_dense_save, self._last_flow_rng = pre["masks"], pre["save"], pre["rng"]
+            else:
+                dl, keep = (_lib.DenseLayer * 1)(), []
+                self._dense_layer_desc(dl[0], cfg, keep)
+                self._last_dense_save = None
+                if self._keep_dense:
+                    # training: the forward keeps every transform's input and the coupling MLPs' hidden activations for
+                    # lbbnn_mnf_flow_dense_backward (a fresh buffer per call: it belongs to this call's autograd node)
+                    self._last_dense_save = torch.empty(ops.flow_dense_save_size(self.in_features, dl[0].Tz, dl[0].Tr),
+                                                        dtype=torch.float32, device=self.q0_mean.device)
+                    dl[0].save = self._last_dense_save.data_ptr()
+                _lib.check(_lib.lib().lbbnn_layers_dense_flows(dl, 1, rng.data_ptr() if rng is not None else None,
+                                                               torch.cuda.current_stream(self.q0_mean.device).cuda_stream),
+                           "lbbnn_layers_dense_flows")
+                del keep
         ops.weight_pass(self.weight_mu, self.weight_rho, self.lambdal, z_fwd=ws.z_fwd,
                         z_kl=ws.z_kl if want_kl else None, r0_c=self.r0_c if want_kl else None,
                         bias_rho=self.bias_rho, priors=self.priors, e_w=ws.e_w,
@@ -720,10 +738,51 @@ class _NetworkBase(nn.Module):
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
         if needs_grad or not x.is_cuda or not all(l._fusable() for l in layers):
             self._kl_total = None
-            for i, l in enumerate(layers):
-                x = l.forward(x, sample, _relu=(i < 2))               # F.relu fused into the GEMM epilogue
+            shared = needs_grad and x.is_cuda
+            if shared:
+                # as in the fused no-grad path the three layers share ONE RNG offset (their Philox streams differ by
+                # layer id), advanced once after the last layer
+                self._preflow_dense(layers, sample)
+            try:
+                for i, l in enumerate(layers):
+                    l._advance_rng = not shared
+                    x = l.forward(x, sample, _relu=(i < 2))           # F.relu fused into the GEMM epilogue
+            finally:
+                for l in layers:
+                    l._advance_rng = True
+            if shared:
+                ops.RngState.get(x.device).advance(1)
             return F.log_softmax(x, dim=1)                            # …LRT.py:210
         return self._forward_streams(x.float(), sample)
+
+    def _preflow_dense(self, layers, sample):
+        """Training forward of a net whose layers all use dense (RNVP / MNF-type) flows: the flows depend on parameters
+        only, so all layers' z draws + flows run here in ONE batched launch sequence (lbbnn_layers_dense_flows, 10 launches
+        for the net instead of 10 per layer), each keeping its intermediates for lbbnn_mnf_flow_dense_backward; the
+        per-layer autograd forward then starts at the weight pass."""
+        from . import _lib
+        if not _DENSE_HIP_BWD or not all(l._mnf and l._check_flows() == "dense" for l in layers):
+            return
+        cfgs = [(bool(l.training or sample), bool(l.training), False) for l in layers]
+        if len({(len(l.z_flow.transforms), len(l.r_flow.transforms), c[1]) for l, c in zip(layers, cfgs)}) != 1:
+            return
+        if len(layers) > 4:
+            return
+        dev = layers[0].q0_mean.device
+        rng = ops.RngState.get(dev).t if any(l._uses_rng(c) for l, c in zip(layers, cfgs)) else None
+        snap = rng.clone() if rng is not None else None
+        dls, keep = (_lib.DenseLayer * len(layers))(), []
+        for k, (l, c) in enumerate(zip(layers, cfgs)):
+            ws = l._workspace()
+            for name in ("z_fwd", "z_kl", "scal"):
+                setattr(ws, name, torch.empty_like(getattr(ws, name)))
+            l._dense_layer_desc(dls[k], c, keep)
+            save = torch.empty(ops.flow_dense_save_size(l.in_features, dls[k].Tz, dls[k].Tr), dtype=torch.float32, device=dev)
+            dls[k].save = save.data_ptr()
+            l._preflow = {"cfg": c, "masks": l._last_masks, "save": save, "rng": snap}
+        _lib.check(_lib.lib().lbbnn_layers_dense_flows(dls, len(layers), rng.data_ptr() if rng is not None else None,
+                                                       torch.cuda.current_stream(dev).cuda_stream), "lbbnn_layers_dense_flows")
+        del keep
 
     def _forward_streams(self, x, sample):
         """Fused no-grad forward: ONE stream, 2 + 3 + 1 launches.

@@ -1254,8 +1254,7 @@ def test_dense_flow_hip_backward_in_kernel_noise(bnn, dev, kind, want_kl, monkey
     grads = {}
     for mode in ("hip", "torch"):
         monkeypatch.setattr(layers, "_DENSE_HIP_BWD", mode == "hip")
-        bnn.manual_seed(77, 3)
-        torch.manual_seed(9)                                  # the masks come from torch's device generator
+        bnn.manual_seed(77, 3)                                # also seeds torch's device generator (the masks)
         layer.zero_grad(set_to_none=True)
         xg = x.clone().requires_grad_(True)
         out = layer(xg, sample=True)
@@ -1268,6 +1267,33 @@ def test_dense_flow_hip_backward_in_kernel_noise(bnn, dev, kind, want_kl, monkey
             assert g is None or float(g.abs().max()) == 0.0, n
             continue
         assert rel_err(g.cpu(), ref.cpu()) < 1e-4, n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["RNVP", "MNF"])
+def test_dense_network_training_forward_batched_flows(bnn, dev, kind, monkeypatch):
+    """Training step of a 3-layer net with dense flows, in-kernel noise: the default path (all layers' flows in one batched
+    launch sequence before the per-layer autograd forwards, lbbnn_mnf_flow_dense_backward on what they kept) against the
+    per-layer torch-autograd chain on the same draws (shared RNG offset, same seeds): loss and every gradient."""
+    from bnn_amd import layers
+    torch.manual_seed(3)
+    net = bnn.mnf.BayesianNetwork((40, 56, 24, 10), 2, z_flow_type=kind, r_flow_type=kind).to(dev).train()
+    x = torch.rand(32, 40, device=dev)
+    y = torch.randint(0, 10, (32,), device=dev)
+    res = {}
+    for mode in ("hip", "torch"):
+        monkeypatch.setattr(layers, "_DENSE_HIP_BWD", mode == "hip")
+        bnn.manual_seed(13, 5)                                 # also seeds torch's generator (the masks)
+        net.zero_grad(set_to_none=True)
+        out = net(x, sample=True)
+        loss = torch.nn.functional.nll_loss(out, y, reduction="sum") + net.kl() / 10
+        loss.backward()
+        res[mode] = (float(loss.detach()), {n: p.grad.clone() for n, p in net.named_parameters()})
+        off = int(bnn.ops.RngState.get(dev).t[1])
+        assert off == 6, off                                   # one shared offset, advanced once per network forward
+    assert abs(res["hip"][0] - res["torch"][0]) / abs(res["torch"][0]) < 1e-5
+    for n, g in res["hip"][1].items():
+        assert rel_err(g.cpu(), res["torch"][1][n].cpu()) < 2e-4, n
 
 
 @pytest.mark.gpu
