@@ -40,6 +40,9 @@ struct FinalizeArgs {
     float bias_mu_prior, bias_sigma_prior;
 };
 
+// K5 of up to LBBNN_MAX_LAYERS layers + their total, as carried by a GEMM launch (lbbnn_lrt_gemm_finalize)
+struct FinalizePiggy { FinalizeArgs l[LBBNN_MAX_LAYERS]; int active[LBBNN_MAX_LAYERS]; int n; float* total; };
+
 // Select element `idx` of a by-value kernel-argument array WITHOUT dynamic indexing: a runtime index into a
 // kernarg struct array makes hipcc copy the array to scratch memory (measured: 64 B/lane of scratch in K1);
 // a chain of uniform compares keeps every field a constant-offset scalar load.
@@ -58,10 +61,13 @@ LBBNN_HIDDEN int make_weight_pass_args(WeightPassArgs& a, const float* mu, const
                                        const lbbnn_priors_t* priors, void* e_w, void* var_w, int ld,
                                        float* kl_rows, float* act_mu, float* act_var, float* bias_var, int O, int I,
                                        int split = 0);
-LBBNN_HIDDEN int launch_weight_pass(const WeightPassArgs* a, int n, hipStream_t s);
+LBBNN_HIDDEN int launch_weight_pass(const WeightPassArgs* a, int n, hipStream_t s, uint64_t* rng = nullptr,
+                                    uint64_t* rng_snap = nullptr, uint64_t advance = 0);
 LBBNN_HIDDEN int launch_flow_planar(const FlowArgs* a, int n, hipStream_t s);
 LBBNN_HIDDEN int launch_kl_finalize_all(const FinalizeArgs* a, const int* active, int n, uint64_t* rng, uint64_t advance,
                                         float* kl_total, hipStream_t s);
 LBBNN_HIDDEN int launch_kl_finalize(const FinalizeArgs* a, int n, hipStream_t s);
+// FinalizeArgs of every layer of a network from its descriptors (validation as lbbnn_layers_finalize)
+LBBNN_HIDDEN int fill_finalize_args(const lbbnn_layer_desc_t* L, int n, const uint64_t* rng, FinalizeArgs* ka, int* active);
 
 }  // namespace lbbnn

@@ -22,6 +22,8 @@
 //  * Roofline for this path: fp32 matrix peak 157.3 TFLOP/s (MI355X_MICROARCH.md).
 #include <cstdlib>
 #include "lbbnn_device.h"
+#include "lbbnn_internal.h"
+#include "kl_piggy.h"
 #include "../../include/lbbnn.h"
 
 namespace {
@@ -44,6 +46,9 @@ struct GemmArgs {
     int relu, log_softmax;
     int kchunk;              // split-K (bf16x3 kernel only): workgroup z contracts k in [z*kchunk, (z+1)*kchunk), 0 = off
     long long split_stride;  // ... and writes its partial product to out + z*split_stride
+    // lbbnn_lrt_gemm_finalize: fin.n > 0 => the grid has one extra row of workgroups (blockIdx.y == gridDim.y - 1) whose
+    // first workgroup does the KL finalize of the network (kl_piggy.h) while the tiles are computed; the rest of the row exits
+    FinalizePiggy fin;
 };
 
 // XCD-aware tile assignment (cdna guide T1).  Workgroups are dealt round-robin over the 8 XCDs, each with
@@ -51,8 +56,8 @@ struct GemmArgs {
 // Remap the linear id so that each XCD owns a contiguous run of tiles in (b-tile major, o-tile minor)
 // order: an XCD then works on ~4 x tiles x all W tiles and every x tile is fetched into ONE L2.
 // Bijective when the grid size is a multiple of 8 (identity otherwise).  Speed only, never correctness.
-__device__ __forceinline__ void tile_of_block(int& ox, int& by) {
-    const int nx = gridDim.x, n = gridDim.x * gridDim.y;
+__device__ __forceinline__ void tile_of_block(int& ox, int& by, int extra_rows = 0) {
+    const int nx = gridDim.x, n = gridDim.x * (gridDim.y - extra_rows);
     int t = blockIdx.y * nx + blockIdx.x;
     if ((n & 7) == 0) t = (t & 7) * (n >> 3) + (t >> 3);
     ox = t % nx; by = t / nx;
@@ -344,8 +349,14 @@ __global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_f32_dma_kernel(const Gemm
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, q = lane >> 4;
+    if constexpr (WB == 4) {
+        if (a.fin.n > 0 && blockIdx.y == gridDim.y - 1) {                      // the finalize row (uniform per workgroup)
+            if (blockIdx.x == 0) kl_finalize_piggy(kernarg_as<GemmArgs>()->fin, smem);
+            return;
+        }
+    }
     int tox, tby;
-    tile_of_block(tox, tby);
+    tile_of_block(tox, tby, (WB == 4 && a.fin.n > 0) ? 1 : 0);
     const int o0 = tox * BN;
     const int b0 = tby * BM;
 
@@ -503,8 +514,14 @@ __global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_bf16x3_kernel(const GemmA
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, q = lane >> 4;
+    if constexpr (WB == 4) {
+        if (a.fin.n > 0 && blockIdx.y == gridDim.y - 1) {                      // the finalize row (uniform per workgroup)
+            if (blockIdx.x == 0) kl_finalize_piggy(kernarg_as<GemmArgs>()->fin, reinterpret_cast<float*>(smc));
+            return;
+        }
+    }
     int tox, tby;
-    tile_of_block(tox, tby);
+    tile_of_block(tox, tby, (WB == 4 && a.fin.n > 0) ? 1 : 0);
     const int o0 = tox * BN;
     const int b0 = tby * BM;
     // split-K: this workgroup's k range (kbeg is a multiple of 32, so every alignment below is unchanged)
@@ -804,16 +821,25 @@ inline int launch_one(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s
     return (int)hipGetLastError();
 }
 
+// *hosted (if non-NULL, and a.fin.n > 0): set to true when the launch carries the finalize row; otherwise the caller
+// runs the finalize as a launch of its own
 template <int TO, int TB, int WB>
-int launch_cfg(const GemmArgs& a, bool mean_only, bool xvec, hipStream_t s) {
+int launch_cfg(GemmArgs& a, bool mean_only, bool xvec, hipStream_t s, bool* hosted) {
     constexpr int BN = TO * 16, BM = TB * WB * 16;
     dim3 grid((a.O + BN - 1) / BN, (a.B + BM - 1) / BM);
     dim3 block(WB * 64);
     const long nblocks = (long)grid.x * grid.y;
     static const bool no_dma = getenv("LBBNN_GEMM_NO_DMA") != nullptr;     // A/B knob for bench sweeps
+    const int fin_n = a.fin.n;
+    a.fin.n = 0;
     if (xvec && (a.I % BK) == 0 && !no_dma) {
         const size_t l_full = lds_request(2u * (BM + 2 * BN) * DROW * sizeof(float), nblocks);
         const size_t l_mean = lds_request(2u * (BM + BN) * DROW * sizeof(float), nblocks);
+        if (WB == 4 && fin_n > 0 && hosted) {
+            a.fin.n = fin_n;
+            if (piggy_lds_bytes(a.fin) <= (mean_only ? l_mean : l_full)) { grid.y += 1; *hosted = true; }
+            else a.fin.n = 0;
+        }
         if (mean_only) return launch_one(lrt_gemm_f32_dma_kernel<TO, TB, WB, true>, grid, block, l_mean, s, a);
         return launch_one(lrt_gemm_f32_dma_kernel<TO, TB, WB, false>, grid, block, l_full, s, a);
     }
@@ -828,24 +854,31 @@ int launch_cfg(const GemmArgs& a, bool mean_only, bool xvec, hipStream_t s) {
 }
 
 template <int TO, int TB, int WB>
-int launch_split_cfg(const GemmArgs& a, bool mean_only, hipStream_t s) {
+int launch_split_cfg(GemmArgs& a, bool mean_only, hipStream_t s, bool* hosted) {
     constexpr int BN = TO * 16, BM = TB * WB * 16;
     dim3 grid((a.O + BN - 1) / BN, (a.B + BM - 1) / BM, a.kchunk ? (a.I + a.kchunk - 1) / a.kchunk : 1);
     dim3 block(WB * 64);
     const long nblocks = (long)grid.x * grid.y * grid.z;
     const size_t l_full = lds_request(2u * (BM * 128 + 2 * BN * 128), nblocks);
     const size_t l_mean = lds_request(2u * (BM * 128 + 1 * BN * 128), nblocks);
+    const int fin_n = a.fin.n;
+    a.fin.n = 0;
+    if (WB == 4 && fin_n > 0 && hosted && !a.kchunk) {
+        a.fin.n = fin_n;
+        if (piggy_lds_bytes(a.fin) <= (mean_only ? l_mean : l_full)) { grid.y += 1; *hosted = true; }
+        else a.fin.n = 0;
+    }
     if (mean_only) return launch_one(lrt_gemm_bf16x3_kernel<TO, TB, WB, true>, grid, block, l_mean, s, a);
     return launch_one(lrt_gemm_bf16x3_kernel<TO, TB, WB, false>, grid, block, l_full, s, a);
 }
 
-int launch_split(const GemmArgs& a, bool mean_only, hipStream_t s) {
+int launch_split(GemmArgs& a, bool mean_only, hipStream_t s, bool* hosted) {
     // 128x80 tile, 2 workgroups/CU, 2 LDS stages.  Variants measured and dropped: 256x80 3-stage ring
     // (one workgroup/CU), 128x160 with 4 or 8 waves, x split once per tile through LDS, x delivered pre-split.
     const long nz = a.kchunk ? (a.I + a.kchunk - 1) / a.kchunk : 1;
     const long blocks_big = (long)((a.O + 79) / 80) * ((a.B + 127) / 128) * nz;
-    if (blocks_big >= 256 && a.B >= 96) return launch_split_cfg<5, 2, 4>(a, mean_only, s);
-    return launch_split_cfg<5, 1, 2>(a, mean_only, s);
+    if (blocks_big >= 256 && a.B >= 96) return launch_split_cfg<5, 2, 4>(a, mean_only, s, hosted);
+    return launch_split_cfg<5, 1, 2>(a, mean_only, s, hosted);
 }
 
 }  // namespace
@@ -853,7 +886,8 @@ int launch_split(const GemmArgs& a, bool mean_only, hipStream_t s) {
 static int lrt_gemm_impl(const float* x, int ldx, const void* e_w, const void* var_w, int ld,
                          const float* bias_mean, const float* bias_var, const float* var_scale,
                          const float* eps, const uint64_t* rng, uint32_t rng_stream, int64_t row_offset,
-                         float* out, int ldo, float* std_out, int B, int I, int O, int flags, void* stream, int kchunk = 0) {
+                         float* out, int ldo, float* std_out, int B, int I, int O, int flags, void* stream, int kchunk = 0,
+                         const FinalizePiggy* fin = nullptr, bool* hosted = nullptr) {
     if (B == 0 && I > 0 && O > 0) return 0;        // empty batch (torch.mm of 0 rows, LBBNN-GP-MF-LRT.py:172): nothing to do
     if (!x || !e_w || !out) return LBBNN_E_NULL;
     if (B <= 0 || I <= 0 || O <= 0 || ldx < I || ldo < O) return LBBNN_E_SHAPE;
@@ -874,6 +908,7 @@ static int lrt_gemm_impl(const float* x, int ldx, const void* e_w, const void* v
     a.rng_stream = rng_stream; a.relu = (flags & LBBNN_F_RELU) ? 1 : 0;
     a.log_softmax = (flags & LBBNN_F_LOG_SOFTMAX) ? 1 : 0;
     a.kchunk = kchunk; a.split_stride = (long long)B * ldo;
+    if (fin) a.fin = *fin; else a.fin = FinalizePiggy{};
 
     const bool xvec = ((I & 3) == 0) && ((ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0);
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -886,9 +921,10 @@ static int lrt_gemm_impl(const float* x, int ldx, const void* e_w, const void* v
         if (!xvec || (I & 7) || O <= 16 || (tail && (ld - I) < 8)) return LBBNN_E_ALIGN;
         // the split kernel addresses x and the operands through 32-bit buffer offsets
         if (((size_t)(B - 1) * ldx + I) * 4 >= 0x7FFFFFF0u || (size_t)O * ld * 4 >= 0x7FFFFFF0u) return LBBNN_E_SHAPE;
-        return launch_split(a, mean_only, s);
+        return launch_split(a, mean_only, s, hosted);
     }
     if (O <= 16) {
+        a.fin.n = 0;
         dim3 grid((B + 15) / 16), block(SK_WAVES * 64);
         if (mean_only) {
             if (xvec) hipLaunchKernelGGL((lrt_gemm_skinny_kernel<true, true>), grid, block, 0, s, a);
@@ -900,8 +936,8 @@ static int lrt_gemm_impl(const float* x, int ldx, const void* e_w, const void* v
         return (int)hipGetLastError();
     }
     const long blocks_big = (long)((O + 79) / 80) * ((B + 127) / 128);
-    if (blocks_big >= 256) return launch_cfg<5, 2, 4>(a, mean_only, xvec, s);
-    return launch_cfg<5, 1, 2>(a, mean_only, xvec, s);
+    if (blocks_big >= 256) return launch_cfg<5, 2, 4>(a, mean_only, xvec, s, hosted);
+    return launch_cfg<5, 1, 2>(a, mean_only, xvec, s, hosted);
 }
 
 extern "C" int lbbnn_lrt_gemm(const float* x, int ldx, const void* e_w, const void* var_w, int ld,
@@ -920,6 +956,26 @@ extern "C" int lbbnn_lrt_gemm_train(const float* x, int ldx, const void* e_w, co
     if ((flags & LBBNN_F_LOG_SOFTMAX) && std_out) return LBBNN_E_FLAGS;
     return lrt_gemm_impl(x, ldx, e_w, var_w, ld, bias_mean, bias_var, var_scale, eps, rng, rng_stream, row_offset,
                          out, ldo, std_out, B, I, O, flags, stream);
+}
+
+// lbbnn_lrt_gemm with the KL finalize of a whole network carried by one extra workgroup of the same launch (include/lbbnn.h)
+extern "C" int lbbnn_lrt_gemm_finalize(const float* x, int ldx, const void* e_w, const void* var_w, int ld,
+                                       const float* bias_mean, const float* bias_var, const float* var_scale,
+                                       const float* eps, const uint64_t* rng, uint32_t rng_stream, int64_t row_offset,
+                                       float* out, int ldo, int B, int I, int O, int flags,
+                                       const lbbnn_layer_desc_t* layers, int n, const uint64_t* fin_rng, float* kl_total,
+                                       void* stream) {
+    FinalizePiggy fin{};
+    if (const int rc = fill_finalize_args(layers, n, fin_rng, fin.l, fin.active)) return rc;
+    if (kl_total) for (int i = 0; i < n; ++i) if (!fin.active[i]) return LBBNN_E_NULL;   // a total needs every layer's KL
+    fin.n = n; fin.total = kl_total;
+    bool hosted = false;
+    const int rc = lrt_gemm_impl(x, ldx, e_w, var_w, ld, bias_mean, bias_var, var_scale, eps, rng, rng_stream, row_offset,
+                                 out, ldo, nullptr, B, I, O, flags, stream, 0, &fin, &hosted);
+    if (rc) return rc;
+    if (hosted) return 0;
+    // this GEMM's kernel cannot host the extra workgroup (small tile configuration, skinny output, LDS): same work, own launch
+    return launch_kl_finalize_all(fin.l, fin.active, n, nullptr, 0, kl_total, static_cast<hipStream_t>(stream));
 }
 
 // Split-K plain product on the bf16x3 kernel: out[z] = x[:, Kz] . w[:, Kz]^T for the k ranges Kz = [z*kchunk, (z+1)*kchunk).

@@ -5,7 +5,8 @@
 
 using namespace lbbnn;
 
-static int layers_prepare_impl(const lbbnn_layer_desc_t* L, int n, const uint64_t* rng, void* stream, bool with_k5) {
+static int layers_prepare_impl(const lbbnn_layer_desc_t* L, int n, const uint64_t* rng, void* stream, bool with_k5,
+                               uint64_t* rng_live = nullptr, uint64_t* rng_snap = nullptr, uint64_t advance = 0) {
     if (!L) return LBBNN_E_NULL;
     if (n <= 0 || n > LBBNN_MAX_LAYERS) return LBBNN_E_SHAPE;
     FlowArgs fa[LBBNN_MAX_LAYERS];
@@ -54,7 +55,7 @@ static int layers_prepare_impl(const lbbnn_layer_desc_t* L, int n, const uint64_
     hipStream_t s = static_cast<hipStream_t>(stream);
     int rc = 0;
     if (nf) { rc = launch_flow_planar(fa, nf, s); if (rc) return rc; }
-    rc = launch_weight_pass(wa, n, s); if (rc) return rc;
+    rc = launch_weight_pass(wa, n, s, rng_live, rng_snap, advance); if (rc) return rc;
     if (nk && with_k5) { rc = launch_kl_finalize(ka, nk, s); if (rc) return rc; }
     return 0;
 }
@@ -67,12 +68,15 @@ extern "C" int lbbnn_layers_operands(const lbbnn_layer_desc_t* L, int n, const u
     return layers_prepare_impl(L, n, rng, stream, false);
 }
 
-extern "C" int lbbnn_layers_finalize(const lbbnn_layer_desc_t* L, int n, uint64_t* rng, uint64_t advance, float* kl_total,
-                                     void* stream) {
+extern "C" int lbbnn_layers_operands_snap(const lbbnn_layer_desc_t* L, int n, uint64_t* rng, uint64_t* rng_snap,
+                                          uint64_t advance, void* stream) {
+    if (rng && !rng_snap) return LBBNN_E_NULL;
+    return layers_prepare_impl(L, n, rng, stream, false, rng, rng_snap, advance);
+}
+
+int lbbnn::fill_finalize_args(const lbbnn_layer_desc_t* L, int n, const uint64_t* rng, FinalizeArgs* ka, int* active) {
     if (!L) return LBBNN_E_NULL;
     if (n <= 0 || n > LBBNN_MAX_LAYERS) return LBBNN_E_SHAPE;
-    FinalizeArgs ka[LBBNN_MAX_LAYERS];
-    int active[LBBNN_MAX_LAYERS];
     for (int i = 0; i < n; ++i) {
         const lbbnn_layer_desc_t& d = L[i];
         const bool mnf = d.q0_mean != nullptr;
@@ -89,6 +93,14 @@ extern "C" int lbbnn_layers_finalize(const lbbnn_layer_desc_t* L, int n, uint64_
         k.kl_out = nullptr; k.kl_layer = d.kl_layer; k.O = d.O; k.I = d.I; k.accum = 0; k.layer = d.layer_id & 63u;
         k.bias_mu_prior = d.priors.bias_mu_prior; k.bias_sigma_prior = d.priors.bias_sigma_prior;
     }
+    return 0;
+}
+
+extern "C" int lbbnn_layers_finalize(const lbbnn_layer_desc_t* L, int n, uint64_t* rng, uint64_t advance, float* kl_total,
+                                     void* stream) {
+    FinalizeArgs ka[LBBNN_MAX_LAYERS];
+    int active[LBBNN_MAX_LAYERS];
+    if (const int rc = fill_finalize_args(L, n, rng, ka, active)) return rc;
     if (kl_total) for (int i = 0; i < n; ++i) if (!active[i]) return LBBNN_E_NULL;   // a total needs every layer's KL
     return launch_kl_finalize_all(ka, active, n, rng, advance, kl_total, static_cast<hipStream_t>(stream));
 }

@@ -17,7 +17,8 @@ namespace {
 
 using namespace lbbnn;
 
-struct WeightPassBatch { WeightPassArgs l[LBBNN_MAX_LAYERS]; int row_end[LBBNN_MAX_LAYERS]; int n; };
+struct WeightPassBatch { WeightPassArgs l[LBBNN_MAX_LAYERS]; int row_end[LBBNN_MAX_LAYERS]; int n;
+                         uint64_t* rng; uint64_t* rng_snap; uint64_t advance; };   // see launch_weight_pass
 
 struct Elem { float ew, vw, kl, amu, avar; };
 
@@ -85,6 +86,14 @@ __device__ __forceinline__ Elem weight_elem(float mu, float rho, float lam, floa
 // grid.x = total rows of all layers in the batch; a block finds its layer by the row prefix ends.
 __global__ __launch_bounds__(256) void weight_pass_kernel(const WeightPassBatch bt) {
     __shared__ float red[3][4];
+    // RNG bookkeeping of a fused forward (lbbnn_layers_operands_snap): this launch follows the last kernel that reads the
+    // live {seed, offset}; it copies the pair to rng_snap -- what every later kernel of the forward reads -- and advances
+    // the live offset, so no launch of its own is needed for that at the end of the forward.
+    if (bt.rng_snap && blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint64_t sd = bt.rng[0], of = bt.rng[1];
+        bt.rng_snap[0] = sd; bt.rng_snap[1] = of;
+        bt.rng[1] = of + bt.advance;
+    }
     int li = 0;
 #pragma unroll
     for (int t = 0; t < LBBNN_MAX_LAYERS - 1; ++t) if (t + 1 < bt.n && (int)blockIdx.x >= bt.row_end[t]) li = t + 1;
@@ -219,8 +228,9 @@ int make_weight_pass_args(WeightPassArgs& a, const float* mu, const float* rho, 
     return 0;
 }
 
-int launch_weight_pass(const WeightPassArgs* a, int n, hipStream_t s) {
+int launch_weight_pass(const WeightPassArgs* a, int n, hipStream_t s, uint64_t* rng, uint64_t* rng_snap, uint64_t advance) {
     WeightPassBatch bt;
+    bt.rng = rng; bt.rng_snap = (rng && rng_snap) ? rng_snap : nullptr; bt.advance = advance;
     int rows = 0;
     for (int i = 0; i < n; ++i) { bt.l[i] = a[i]; rows += a[i].O; bt.row_end[i] = rows; }
     for (int i = n; i < LBBNN_MAX_LAYERS; ++i) bt.row_end[i] = rows;

@@ -380,7 +380,7 @@ class LRTBayesianLinear(_BayesLinearBase):
         ops.kl_finalize(ws.kl_rows, self.bias_mu, self.bias_rho, priors=self.priors, kl_layer=kl_layer,
                         kl_out=kl_total, accumulate=accumulate)
 
-    def _gemm(self, x, cfg, rng, log_softmax=False, std_out=None):
+    def _gemm(self, x, cfg, rng, log_softmax=False, std_out=None, finalize=None):
         stochastic, _, relu = cfg
         ws = self._workspace()
         eps = (self.noise or {}).get("eps_out")
@@ -388,7 +388,7 @@ class LRTBayesianLinear(_BayesLinearBase):
                             bias_mean=self.bias_mu, bias_var=ws.bias_var, eps=eps, rng=rng,
                             rng_stream=ops.STREAM_EPS_OUT * 64 + self._layer_id, row_offset=self.row_offset,
                             relu=relu, mean_only=not stochastic, log_softmax=log_softmax, split=self._split_now,
-                            std_out=std_out)
+                            std_out=std_out, finalize=finalize)
 
     def _noise_for_backward(self, saved, B, need_out=True):
         if saved.get("noise") and "eps_out" in saved["noise"]:
@@ -645,14 +645,14 @@ class MNFBayesianLinear(_BayesLinearBase):
                         r0_b1=self.r0_b1, r0_b2=self.r0_b2, scal=ws.scal, rng=rng,
                         layer_id=self._layer_id, kl_layer=kl_layer, kl_out=kl_total, accumulate=accumulate)
 
-    def _gemm(self, x, cfg, rng, log_softmax=False, std_out=None):
+    def _gemm(self, x, cfg, rng, log_softmax=False, std_out=None, finalize=None):
         stochastic, _, relu = cfg
         ws = self._workspace()
         return ops.lrt_gemm(x, ws.e_w, ws.var_w, I=self.in_features, O=self.out_features,
                             bias_mean=self.bias_mu, bias_var=ws.bias_var, eps=(self.noise or {}).get("eps_out"),
                             rng=rng, rng_stream=ops.STREAM_EPS_OUT * 64 + self._layer_id,
                             row_offset=self.row_offset, relu=relu, mean_only=not stochastic,
-                            log_softmax=log_softmax, split=self._split_now, std_out=std_out)
+                            log_softmax=log_softmax, split=self._split_now, std_out=std_out, finalize=finalize)
 
     def _noise_for_backward(self, saved, B, need_out=True):
         masks = saved.get("masks") or {}
@@ -721,9 +721,10 @@ class MNFBayesianLinear(_BayesLinearBase):
 class _NetworkBase(nn.Module):
     """3-layer MLP of Bayesian layers: ReLU, ReLU, log_softmax (LBBNN-GP-MF-LRT.py:206-214).
 
-    Without autograd the forward is ONE stream and 7 launches (``_forward_streams``): the x-independent kernels of
-    all layers batched into one launch per kind (flows, weight pass, KL finalize), the three GEMMs with ReLU /
-    log_softmax fused into their epilogues, and one finish kernel (KL total, RNG offset += 1).  The three layers
+    Without autograd the forward is ONE stream and 5 launches (``_forward_streams``): the x-independent kernels of
+    all layers batched into one launch per kind (flows, weight pass), and the three GEMMs with ReLU / log_softmax fused
+    into their epilogues; the KL finalize of all layers rides in the first GEMM's launch and the RNG offset is advanced
+    by the weight-pass launch.  The three layers
     share one RNG offset (their Philox streams differ by layer id).  No host synchronisation: HIP-graph capturable.
     With autograd each layer goes through ``_BayesLinearFn`` (HIP forward + HIP backward).
     """
@@ -785,11 +786,13 @@ class _NetworkBase(nn.Module):
         del keep
 
     def _forward_streams(self, x, sample):
-        """Fused no-grad forward: ONE stream, 2 + 3 + 1 launches.
+        """Fused no-grad forward: ONE stream, 2 + 3 launches.
 
-        lbbnn_layers_operands runs the x-independent kernels the GEMMs need for all layers (flows, weight pass: one
-        launch per kind), then the three GEMMs run back to back (ReLU / log_softmax in their epilogues), then
-        lbbnn_layers_finalize finishes every layer's KL, sums them and advances the RNG offset in one launch.
+        lbbnn_layers_operands_snap runs the x-independent kernels the GEMMs need for all layers (flows, weight pass: one
+        launch per kind); the weight-pass launch also copies the Philox state for the rest of this forward and advances
+        the live offset.  Then the three GEMMs run back to back (ReLU / log_softmax in their epilogues); the first one
+        carries every layer's KL tail + the network total as one extra workgroup (lbbnn_lrt_gemm_finalize) -- the KL
+        depends on parameters only, so it needs neither a launch of its own nor a place on the critical path.
         (A two-stream schedule was measured first: every cross-stream dependency cost 13-15 us on
         the critical path and the side-stream kernels were starved by the GEMM -- see DESIGN.md.)
         """
@@ -833,17 +836,20 @@ class _NetworkBase(nn.Module):
                     eps_z2 = eps_z2.reshape(-1).contiguous()
                 keep.extend([eps_z, eps_z2])
                 l._chain_flows(rng, eps_z, eps_z2, c[1])
-        _lib.check(_lib.lib().lbbnn_layers_operands(descs, n, rng.data_ptr() if rng is not None else None, stream),
-                   "lbbnn_layers_operands")
+        # K1 of every layer (+ K3 of the planar ones); its launch also snapshots the Philox state for the rest of this
+        # forward and advances the live offset, so the forward ends with the last GEMM
+        snap = st.t[2:4] if st is not None else None
+        _lib.check(_lib.lib().lbbnn_layers_operands_snap(descs, n, rng.data_ptr() if rng is not None else None,
+                                                         snap.data_ptr() if snap is not None else None, 1, stream),
+                   "lbbnn_layers_operands_snap")
+        all_kl = want_kl and all(c[1] for c in cfgs)
         for i, (l, c) in enumerate(zip(layers, cfgs)):
-            x = l._gemm(x, c, rng, log_softmax=(i == n - 1 and l.out_features <= 16))
+            # the KL finalize of all layers (parameters only) rides in the first GEMM's launch as one extra workgroup
+            fin = (descs, n, snap.data_ptr() if snap is not None else None, kls[n:].data_ptr() if all_kl else None) \
+                if (i == 0 and want_kl) else None
+            x = l._gemm(x, c, snap, log_softmax=(i == n - 1 and l.out_features <= 16), finalize=fin)
         if layers[-1].out_features > 16:
             x = F.log_softmax(x, dim=1)
-        if want_kl or st is not None:
-            all_kl = want_kl and all(c[1] for c in cfgs)
-            _lib.check(_lib.lib().lbbnn_layers_finalize(descs, n, rng.data_ptr() if st is not None else None, 1,
-                                                        kls[n:].data_ptr() if all_kl else None, stream),
-                       "lbbnn_layers_finalize")
         for i, (l, c) in enumerate(zip(layers, cfgs)):
             l.kl = kls[i] if c[1] else 0
         self._kl_total = kls[n] if (want_kl and all(c[1] for c in cfgs)) else None

@@ -89,7 +89,9 @@ class RngState:
     def __init__(self, device: torch.device):
         self.device = device
         self.seed = None
-        self.t = torch.zeros(2, dtype=torch.int64, device=device)
+        # words 0-1: the live {seed, offset}; words 2-3: the copy a fused forward's later kernels read
+        # (lbbnn_layers_operands_snap)
+        self.t = torch.zeros(4, dtype=torch.int64, device=device)
         self.reseed(torch.initial_seed())
 
     def reseed(self, seed: int, offset: int = 0):
@@ -97,7 +99,7 @@ class RngState:
         s = self.seed & 0xFFFFFFFFFFFFFFFF
         if s >= 1 << 63:
             s -= 1 << 64
-        self.t.copy_(torch.tensor([s, int(offset)], dtype=torch.int64))
+        self.t[:2].copy_(torch.tensor([s, int(offset)], dtype=torch.int64))
 
     @classmethod
     def get(cls, device: torch.device) -> "RngState":
@@ -261,8 +263,11 @@ GEMM_EVENTS = None
 def lrt_gemm(x, e_w, var_w, *, I: int, O: int, bias_mean=None, bias_var=None, var_scale=None,
              eps=None, rng: Optional[torch.Tensor] = None, rng_stream: int = 0, row_offset: int = 0,
              relu: bool = False, mean_only: bool = False, log_softmax: bool = False,
-             split: bool = False, out: Optional[torch.Tensor] = None, std_out: Optional[torch.Tensor] = None):
-    """lbbnn_lrt_gemm: out = x.e_w^T + b [+ sqrt(x^2.var_w^T + bv) * eps] [ReLU]."""
+             split: bool = False, out: Optional[torch.Tensor] = None, std_out: Optional[torch.Tensor] = None,
+             finalize=None):
+    """lbbnn_lrt_gemm: out = x.e_w^T + b [+ sqrt(x^2.var_w^T + bv) * eps] [ReLU].
+    finalize = (layer descriptors, n, rng pointer for K5, kl_total pointer): lbbnn_lrt_gemm_finalize -- the KL finalize of
+    the whole network rides in this launch."""
     if x.dim() != 2 or x.shape[1] != I:
         raise RuntimeError("bnn_amd: input must be (B,%d), got %s" % (I, tuple(x.shape)))
     B = x.shape[0]
@@ -272,14 +277,20 @@ def lrt_gemm(x, e_w, var_w, *, I: int, O: int, bias_mean=None, bias_var=None, va
         raise RuntimeError("bnn_amd: eps must be (%d,%d), got %s" % (B, O, tuple(eps.shape)))
     flags = ((F_RELU if relu else 0) | (F_MEAN_ONLY if mean_only else 0) | (F_LOG_SOFTMAX if log_softmax else 0)
              | (F_SPLIT16 if split else 0))
-    if B == 0:                     # empty batch: (0,O) activations, as torch.mm gives; the KL side is unaffected
+    if B == 0 and finalize is None:    # empty batch: (0,O) activations, as torch.mm gives; the KL side is unaffected
         return out
     if x.stride(1) != 1 or (x.stride(0) < I):
         x = x.contiguous()
     ev = GEMM_EVENTS.take() if GEMM_EVENTS is not None else None
     if ev is not None:
         ev[0].record()
-    if std_out is None:
+    if finalize is not None:
+        rc = _lib.lib().lbbnn_lrt_gemm_finalize(
+            _ptr_rows(x, "input"), x.stride(0), _ptr(e_w), _ptr(var_w), operand_ld(I),
+            _ptr(bias_mean), _ptr(bias_var), _ptr(var_scale), _ptr(eps, "eps"),
+            rng.data_ptr() if rng is not None else None, rng_stream, row_offset,
+            out.data_ptr(), out.stride(0), B, I, O, flags, finalize[0], finalize[1], finalize[2], finalize[3], _stream())
+    elif std_out is None:
         rc = _lib.lib().lbbnn_lrt_gemm(
             _ptr_rows(x, "input"), x.stride(0), _ptr(e_w), _ptr(var_w), operand_ld(I),
             _ptr(bias_mean), _ptr(bias_var), _ptr(var_scale), _ptr(eps, "eps"),

@@ -264,6 +264,30 @@ int lbbnn_layers_operands(const lbbnn_layer_desc_t* layers, int n, const uint64_
 int lbbnn_layers_finalize(const lbbnn_layer_desc_t* layers, int n, uint64_t* rng, uint64_t advance, float* kl_total,
                           void* stream);
 
+/* The same forward with two launches fewer (what BayesianNetwork.forward uses):
+ *
+ * lbbnn_layers_operands_snap = lbbnn_layers_operands, and the weight-pass launch also copies the live Philox state
+ *   {seed, offset} to rng_snap (2 words) and adds `advance` to the live offset.  It follows the last kernel of the
+ *   forward that reads the live state (the flow kernels), so every LATER kernel of this forward -- the GEMMs, the KL
+ *   finalize -- must be given rng_snap as its `rng`.  rng == NULL: no RNG in use, nothing is copied.
+ *
+ * lbbnn_lrt_gemm_finalize = lbbnn_lrt_gemm (same arguments up to `flags`) + the work of lbbnn_layers_finalize
+ *   (every layer's KL tail from its descriptor, kl_layer outputs, *kl_total if non-NULL; no RNG advance) for the n
+ *   layers, computed by ONE extra workgroup of the same launch while the tiles are computed: the KL tail depends on
+ *   parameters only, so it needs no launch of its own after the last GEMM.  fin_rng: the state K5 draws eps_act from
+ *   (rng_snap above).  When the GEMM kernel selected for this shape cannot host the extra workgroup (small-tile
+ *   configuration, O <= 16, not enough dynamic LDS) the finalize runs as a launch of its own after the GEMM: same
+ *   results either way.
+ */
+int lbbnn_layers_operands_snap(const lbbnn_layer_desc_t* layers, int n, uint64_t* rng, uint64_t* rng_snap,
+                               uint64_t advance, void* stream);
+int lbbnn_lrt_gemm_finalize(const float* x, int ldx, const void* e_w, const void* var_w, int ld,
+                            const float* bias_mean, const float* bias_var, const float* var_scale,
+                            const float* eps, const uint64_t* rng, uint32_t rng_stream, int64_t row_offset,
+                            float* out, int ldo, int B, int I, int O, int flags,
+                            const lbbnn_layer_desc_t* layers, int n, const uint64_t* fin_rng, float* kl_total,
+                            void* stream);
+
 /* End of a network forward: *kl_total = sum_l *kl_layers[l] (fixed order; BayesianNetwork.kl(),
  * …LRT.py:213-214) and rng[1] += advance, one tiny launch.  kl_total may be NULL (n ignored). */
 int lbbnn_forward_finish(uint64_t* rng, uint64_t advance, const float* const* kl_layers, int n,
