@@ -2,8 +2,11 @@
 //
 // All work is GEMV-shaped and small (I*H + 3*H*H + 2*H*I MACs per transform, H = 75/100), so the design
 // goal is latency: the two I-long stages are spread over many workgroups, the H x H chain (17 k MACs) is
-// recomputed by every output workgroup instead of costing a launch, and both paths of a layer (forward
-// draw | KL branch) ride in the same launches (blockIdx.y = path).
+// recomputed by every output workgroup instead of costing a launch, both paths of a layer (forward
+// draw | KL branch) ride in the same launches (blockIdx.y = path), and the I-long input GEMV of transform t+1 is
+// folded into the output stage of transform t: each output workgroup adds its 64 rows' share of the next hidden
+// pre-activations (NextA / partial_a) and every workgroup of the next launch sums the per-workgroup partials in a fixed
+// order -- ONE launch per transform, no atomics.
 #include "lbbnn_device.h"
 #include "lbbnn_internal.h"
 
@@ -15,43 +18,93 @@ constexpr int HMAX = LBBNN_MAX_HIDDEN;
 constexpr int CB = 64;             // outputs per workgroup in the output stage (4 waves x 16 rows)
 constexpr int NTC = 256;           // threads of the output stage
 
+// what a launch computes for the NEXT transform: P[path][wg][j] = sum over the workgroup's rows of W_in[j,i] * (m_i z_i)
+struct NextA {
+    const float* w_in;        // (H,I) of the next transform, NULL: nothing follows
+    const float* mask[2];     // its mask per path
+    float* P;                 // [2][nwg][HMAX]
+    int hidden, path_lo, npaths;
+};
+
+// Two halves so that the loads can be requested at the top of a kernel, with everything else it reads, and the
+// reduction run at its end: rows r = wv, wv+4, ... of W_in for this lane's column, and the lane's mask value.
+constexpr int RJ = HMAX / 4;
+struct PartialRegs { float w[RJ]; float m; bool on; };
+
+__device__ __forceinline__ void partial_a_load(const LBBNN_CONST_AS NextA& nx, int path, int row0, int I, PartialRegs& r) {
+    r.on = nx.w_in && path >= nx.path_lo && path < nx.path_lo + nx.npaths;            // uniform
+    r.m = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < RJ; ++jj) r.w[jj] = 0.f;
+    if (!r.on) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, H = nx.hidden;
+    const int i = row0 + lane;
+    if (i >= I) return;
+    r.m = nx.mask[path][i];
+#pragma unroll
+    for (int jj = 0; jj < RJ; ++jj) { const int j = wv + 4 * jj; if (j < H) r.w[jj] = nx.w_in[(size_t)j * I + i]; }
+}
+
+// znew: LDS, the new z of this workgroup's CB rows (lane = row; 0 past the end of the vector)
+__device__ __forceinline__ void partial_a_reduce(const LBBNN_CONST_AS NextA& nx, int path, const float* znew, int nwg, const PartialRegs& r) {
+    if (!r.on) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, H = nx.hidden;
+    const float mz = r.m * znew[lane];
+    float* dst = nx.P + ((size_t)path * nwg + blockIdx.x) * HMAX;
+#pragma unroll
+    for (int jj = 0; jj < RJ; ++jj) {
+        const int j = wv + 4 * jj;
+        if (j >= H) break;                                                           // uniform
+        const float sum = wave_sum(r.w[jj] * mz);
+        if (lane == 0) dst[j] = sum;
+    }
+}
+
 struct InitArgs {
     const float* q0_mean; const float* q0_log_var; const float* eps[2]; const uint64_t* rng;
-    float* z[2]; float* lq0_part;   // per-block partials of log_q0 (KL path)
+    float* z[2]; float* lq0_part;   // per-workgroup partials of log_q0 (KL path)
+    NextA nx;
     int I; uint32_t layer; int npaths;
 };
 
-// z0 = q0_mean + exp(q0_log_var)^.5 * eps  (LBBNN-GP-MF-MNF.py:183-185) for both paths; log_q0 partials (:213-214)
+// z0 = q0_mean + exp(q0_log_var)^.5 * eps  (LBBNN-GP-MF-MNF.py:183-185) for both paths; log_q0 partials (:213-214);
+// the first transform's partial pre-activations
 struct InitBatch { InitArgs l[LBBNN_MAX_LAYERS]; };
 
-__global__ __launch_bounds__(256) void dense_init_kernel(const InitBatch bt) {
-    __shared__ double scratch[4];
+__global__ __launch_bounds__(NTC) void dense_init_kernel(const InitBatch bt) {
+    __shared__ float znew[CB];
     const LBBNN_CONST_AS InitArgs& a = kernarg_as<InitBatch>()->l[blockIdx.z];      // layer = blockIdx.z, no scratch copy
     const int path = blockIdx.y;
-    if (blockIdx.x * 256 >= a.I) return;                                            // grid sized for the widest layer
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    double lq = 0.0;
-    if (i < a.I) {
-        float e;
-        if (a.eps[path]) e = a.eps[path][i];
-        else {
-            float n[4];
-            philox_normal4(a.rng[0], a.rng[1], (path ? LBBNN_STREAM_EPS_Z2 : LBBNN_STREAM_EPS_Z) * 64u + a.layer, (uint64_t)(i >> 2), 0u, n);
-            e = n[i & 3];
-        }
-        const float lv = a.q0_log_var[i], qm = a.q0_mean[i];
-        const float ev = expf(lv);
-        const float z0 = qm + sqrtf(ev) * e;
-        a.z[path][i] = z0;
-        if (path == 1) {
+    if (blockIdx.x * CB >= a.I) return;                                             // grid sized for the widest layer
+    const int row0 = blockIdx.x * CB, tid = threadIdx.x;
+    PartialRegs pr;
+    partial_a_load(a.nx, path, row0, a.I, pr);
+    if (tid < CB) {                                                                 // wave 0: one row per lane
+        const int i = row0 + tid;
+        float lq = 0.f, z0 = 0.f;
+        if (i < a.I) {
+            float e;
+            if (a.eps[path]) e = a.eps[path][i];
+            else {
+                float n[4];
+                philox_normal4(a.rng[0], a.rng[1], (path ? LBBNN_STREAM_EPS_Z2 : LBBNN_STREAM_EPS_Z) * 64u + a.layer, (uint64_t)(i >> 2), 0u, n);
+                e = n[i & 3];
+            }
+            const float lv = a.q0_log_var[i], qm = a.q0_mean[i];
+            const float ev = expf(lv);
+            z0 = qm + sqrtf(ev) * e;
+            a.z[path][i] = z0;
             const float d = z0 - qm;
-            lq = (double)(-0.5f * 1.1447298858494002f - 0.5f * lv - 0.5f * ((d * d) / ev));
+            lq = -0.5f * 1.1447298858494002f - 0.5f * lv - 0.5f * ((d * d) / ev);
+        }
+        znew[tid] = z0;
+        if (path == 1) {
+            const double s = wave_sum((double)lq);
+            if (tid == 0) a.lq0_part[blockIdx.x] = (float)s;
         }
     }
-    if (path == 1) {
-        lq = block_sum<double, 4>(lq, scratch);
-        if (threadIdx.x == 0) a.lq0_part[blockIdx.x] = (float)lq;
-    }
+    __syncthreads();
+    partial_a_reduce(a.nx, path, znew, (a.I + CB - 1) / CB, pr);
 }
 
 struct StageArgs {
@@ -64,39 +117,24 @@ struct StageArgs {
     float* zcopy[2];      // if non-NULL: the path also stores its new z here (z_fwd / z_kl after the last z_flow transform)
     float* ld_part[2];    // per-workgroup log-det partials of this transform
     int I; int path_lo, npaths;   // paths handled: path_lo .. path_lo + npaths - 1
+    const float* Pin;     // [2][nwg][HMAX]: this transform's hidden pre-activation partials, written by the previous launch
+    NextA nx;
 #ifdef LAB_STAMPS             // tools/lab diagnostic build only: phase times of the output stage (10 ns units) into scal[5..7]
     float* lab;
 #endif
 };
 
-// Stage A: one wave per hidden unit j: h[j] = act( sum_i W_in[j,i] * (m_i z_i) + b_in[j] )
-//   RNVP: LeakyReLU(0.1) (flows2.py:176-185,212)   MNF: tanh (flows2.py:235)
 struct StageBatch { StageArgs l[LBBNN_MAX_LAYERS]; };
 
-__global__ __launch_bounds__(256) void dense_stage_a_kernel(const StageBatch bt) {
-    const LBBNN_CONST_AS StageArgs& a = kernarg_as<StageBatch>()->l[blockIdx.z];
-    const int path = a.path_lo + blockIdx.y;
-    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (j >= a.tr.hidden) return;
-    const float* __restrict__ w = a.tr.w_in + (size_t)j * a.I;
-    const float* __restrict__ z = a.zin[path];
-    const float* __restrict__ m = path ? a.tr.mask_kl : a.tr.mask_fwd;
-    float s = 0.f;
-    for (int i = lane; i < a.I; i += 64) s += w[i] * (m[i] * z[i]);
-    s = wave_sum(s);
-    if (lane == 0) {
-        const float v = s + a.tr.b_in[j];
-        a.h[path][j] = a.tr.kind == LBBNN_FLOW_RNVP ? (v >= 0.f ? v : 0.1f * v) : tanhf(v);
-    }
-}
-
-// Output stage: (RNVP) finish the MLP chain h1 -> h4 in LDS, then per output i the two H-long dots,
-// the gate and the coupling update, plus this workgroup's log-det partial.
+// One launch per transform.  Every workgroup: h1 = act(sum of the previous launch's partials + b_in)
+//   (RNVP: LeakyReLU(0.1), flows2.py:176-185,212; MNF type: tanh, flows2.py:235), (RNVP) the MLP chain h1 -> h4 in LDS,
+// then for its 64 outputs the two H-long dots, the gate and the coupling update, its log-det partial, and its rows' share
+// of the next transform's hidden pre-activations.
 __global__ __launch_bounds__(NTC) void dense_stage_c_kernel(const StageBatch bt, int use_lds) {
     extern __shared__ __attribute__((aligned(16))) float wl[];      // the three H x H middle matrices (use_lds)
     __shared__ float hs[2][HMAX];
     __shared__ double scratch[4];
+    __shared__ float znew[CB];
     const LBBNN_CONST_AS StageArgs& a = kernarg_as<StageBatch>()->l[blockIdx.z];
     if (blockIdx.x * CB >= a.I) return;                                             // grid sized for the widest layer
     const int path = a.path_lo + blockIdx.y;
@@ -126,6 +164,8 @@ __global__ __launch_bounds__(NTC) void dense_stage_c_kernel(const StageBatch bt,
         rb0[j] = c0 ? rb[lane] : 0.f; rb1[j] = c1 ? rb[lane + 64] : 0.f;
         bav[j] = a.tr.b_a[i]; bbv[j] = a.tr.b_b[i]; mv[j] = mask[i]; zv[j] = zin[i];
     }
+    PartialRegs pr;
+    partial_a_load(a.nx, path, row0, a.I, pr);
     if (rnvp && use_lds) {
         const int HH = H * H;
         // explicit batches of 24 loads per thread before the first LDS write: left as a plain copy loop the compiler
@@ -148,7 +188,22 @@ __global__ __launch_bounds__(NTC) void dense_stage_c_kernel(const StageBatch bt,
 #pragma unroll
         for (int l = 0; l < 3; ++l) bm[l] = a.tr.b_mid[l][tid];
     }
-    if (tid < H) hs[0][tid] = a.h[path][tid];
+    const int nwg = (a.I + CB - 1) / CB;
+    if (tid < H) {
+        // h1: the partials of the previous launch's workgroups in a fixed order (4 loads in flight per trip)
+        const float* src = a.Pin + (size_t)path * nwg * HMAX + tid;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int w = 0;
+        for (; w + 4 <= nwg; w += 4) {
+            const float v0 = src[(size_t)w * HMAX], v1 = src[(size_t)(w + 1) * HMAX], v2 = src[(size_t)(w + 2) * HMAX], v3 = src[(size_t)(w + 3) * HMAX];
+            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        }
+        for (; w < nwg; ++w) a0 += src[(size_t)w * HMAX];
+        const float v = ((a0 + a1) + (a2 + a3)) + a.tr.b_in[tid];
+        const float h1 = rnvp ? (v >= 0.f ? v : 0.1f * v) : tanhf(v);
+        hs[0][tid] = h1;
+        if (a.keep_chain && blockIdx.x == 0) a.h[path][tid] = h1;
+    }
     __syncthreads();
 #ifdef LAB_STAMPS
     if (blockIdx.x == 0 && tid == 0) a.lab[0] = (float)(__builtin_amdgcn_s_memrealtime() - lab_t0);
@@ -193,6 +248,7 @@ __global__ __launch_bounds__(NTC) void dense_stage_c_kernel(const StageBatch bt,
         float zn;
         if (rnvp) zn = ((1.f - m) * z) * g + (1.f - g) * sa + m * z;           // :215
         else zn = m * z + (1.f - m) * (z * g + (1.f - g) * sa);                 // :238
+        if (lane == 0) znew[wv + 4 * j] = (i <= last) ? zn : 0.f;
         if (i <= last) {
             if (lane == 0) {
                 a.zout[path][i] = zn;
@@ -204,6 +260,7 @@ __global__ __launch_bounds__(NTC) void dense_stage_c_kernel(const StageBatch bt,
     if (lane == 0) scratch[wv] = (double)ldw;
     __syncthreads();
     if (tid == 0) a.ld_part[path][blockIdx.x] = (float)((scratch[0] + scratch[1]) + (scratch[2] + scratch[3]));
+    partial_a_reduce(a.nx, path, znew, nwg, pr);                                // (znew complete: the barrier above)
 #ifdef LAB_STAMPS
     if (blockIdx.x == 0 && tid == 0) a.lab[2] = (float)(__builtin_amdgcn_s_memrealtime() - lab_t0);
 #endif
@@ -245,11 +302,12 @@ bool transform_ok(const lbbnn_dense_transform_t& t, bool need_fwd, bool need_kl)
 
 }  // namespace
 
-// workspace (floats): z[2][I] | h[2][HMAX] | lq0[nblk_i] | ld_fwd[T*nblk] | ld_z[T*nblk] | ld_r[T*nblk], T <= LBBNN_MAX_FLOW_T
+// workspace (floats): z[2][I] | h[2][HMAX] | lq0[nblk] | ld_fwd[T*nblk] | ld_z[T*nblk] | ld_r[T*nblk] | P[2 (ping-pong)][2][nblk][HMAX],
+// T <= LBBNN_MAX_FLOW_T
 extern "C" int64_t lbbnn_flow_dense_workspace(int I) {
     if (I <= 0) return 0;
-    const int64_t nblk = (I + CB - 1) / CB, nblk_i = (I + 255) / 256;
-    return 2 * (int64_t)I + 2 * HMAX + nblk_i + 3 * (int64_t)LBBNN_MAX_FLOW_T * nblk + 64;
+    const int64_t nblk = (I + CB - 1) / CB;
+    return 2 * (int64_t)I + 2 * HMAX + nblk + 3 * (int64_t)LBBNN_MAX_FLOW_T * nblk + 4 * nblk * HMAX + 64;
 }
 
 // kept intermediates (floats): ZF[Tz+1][I] | ZK[Tz+1][I] | ZR[Tr][I] | per (transform, path): h1 | h2 | h3 | head input
@@ -278,28 +336,41 @@ static int dense_flows_impl(const lbbnn_dense_layer_t* L, int n, const uint64_t*
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int npaths = want_kl ? 2 : 1;
-    const int gblk = (maxI + CB - 1) / CB, gblk_i = (maxI + 255) / 256;
-    struct Bufs { float *zbuf1, *h0, *h1, *lq0, *ldf, *ldz, *ldr, *ZF, *ZK, *ZR, *HS; int nblk, nblk_i; } B[LBBNN_MAX_LAYERS];
+    const int gblk = (maxI + CB - 1) / CB;
+    const int S = Tz + (want_kl ? Tr : 0);                                        // launches after the init: one per transform
+    struct Bufs { float *zbuf1, *h0, *h1, *lq0, *ldf, *ldz, *ldr, *ZF, *ZK, *ZR, *HS, *P[2]; int nblk, nblk_i; } B[LBBNN_MAX_LAYERS];
+    // what launch s-1 (s = 0: the init) prepares for transform s: its rows' share of W_in (m z), for the paths transform s runs on
+    auto next_of = [&](const lbbnn_dense_layer_t& d, const Bufs& b, int sidx) {
+        NextA nx{};
+        if (sidx >= S) return nx;
+        const bool zph = sidx < Tz;
+        const lbbnn_dense_transform_t& t = zph ? d.zt[sidx] : d.rt[sidx - Tz];
+        nx.w_in = t.w_in; nx.mask[0] = t.mask_fwd; nx.mask[1] = t.mask_kl; nx.P = b.P[sidx & 1]; nx.hidden = t.hidden;
+        nx.path_lo = zph ? 0 : 1; nx.npaths = zph ? npaths : 1;
+        return nx;
+    };
     InitBatch ib{};
     for (int k = 0; k < n; ++k) {
         const lbbnn_dense_layer_t& d = L[k];
         Bufs& b = B[k];
-        b.nblk = (d.I + CB - 1) / CB; b.nblk_i = (d.I + 255) / 256;
+        b.nblk = (d.I + CB - 1) / CB; b.nblk_i = b.nblk;
         b.zbuf1 = d.work + d.I;                  // (work[0..I) was the path-0 scratch row of an earlier version)
         b.h0 = d.work + 2 * (size_t)d.I; b.h1 = b.h0 + HMAX; b.lq0 = b.h1 + HMAX;
         b.ldf = b.lq0 + b.nblk_i;
         b.ldz = b.ldf + (size_t)LBBNN_MAX_FLOW_T * b.nblk;
         b.ldr = b.ldz + (size_t)LBBNN_MAX_FLOW_T * b.nblk;
+        b.P[0] = b.ldr + (size_t)LBBNN_MAX_FLOW_T * b.nblk; b.P[1] = b.P[0] + (size_t)2 * b.nblk * HMAX;
         b.ZF = d.save; b.ZK = d.save ? b.ZF + (size_t)(Tz + 1) * d.I : nullptr;
         b.ZR = d.save ? b.ZK + (size_t)(Tz + 1) * d.I : nullptr;
         b.HS = d.save ? b.ZR + (size_t)d.Tr * d.I : nullptr;
         InitArgs& ia = ib.l[k];
         ia.q0_mean = d.q0_mean; ia.q0_log_var = d.q0_log_var; ia.eps[0] = d.eps_fwd; ia.eps[1] = d.eps_kl; ia.rng = rng;
         ia.z[0] = d.save ? b.ZF : d.z_fwd; ia.z[1] = d.save ? b.ZK : b.zbuf1; ia.lq0_part = b.lq0; ia.I = d.I; ia.layer = d.layer_id & 63u; ia.npaths = npaths;
+        ia.nx = next_of(d, b, 0);
     }
-    hipLaunchKernelGGL(dense_init_kernel, dim3(gblk_i, npaths, n), dim3(256), 0, s, ib);
+    hipLaunchKernelGGL(dense_init_kernel, dim3(gblk, npaths, n), dim3(NTC), 0, s, ib);
 
-    for (int t = 0; t < Tz + (want_kl ? Tr : 0); ++t) {
+    for (int t = 0; t < S; ++t) {
         const bool zphase = t < Tz;
         StageBatch sb{};
         for (int k = 0; k < n; ++k) {
@@ -324,6 +395,8 @@ static int dense_flows_impl(const lbbnn_dense_layer_t* L, int n, const uint64_t*
             sa.ld_part[0] = b.ldf + (size_t)t * b.nblk;
             sa.ld_part[1] = zphase ? b.ldz + (size_t)t * b.nblk : b.ldr + (size_t)(t - Tz) * b.nblk;
             sa.I = d.I;
+            sa.Pin = b.P[t & 1];
+            sa.nx = next_of(d, b, t + 1);
 #ifdef LAB_STAMPS
             sa.lab = d.scal + 5;
 #endif
@@ -331,7 +404,6 @@ static int dense_flows_impl(const lbbnn_dense_layer_t* L, int n, const uint64_t*
             sa.npaths = zphase ? npaths : 1;
         }
         const int np = zphase ? npaths : 1;
-        hipLaunchKernelGGL(dense_stage_a_kernel, dim3((maxH + 3) / 4, np, n), dim3(256), 0, s, sb);
         // the three middle matrices of a transform in LDS: 66 KB for the reference's H = 75, 117 KB for H = 100
         const size_t wl_bytes = (size_t)3 * maxH * maxH * sizeof(float);
         int use_lds = wl_bytes <= 144 * 1024 ? 1 : 0;

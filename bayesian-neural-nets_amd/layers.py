@@ -246,6 +246,7 @@ class _BayesLinearBase(nn.Module):
         self._preflow = None           # dense flows of this call already run by the network (batched over its layers)
         self._advance_rng = True       # False while a network drives the layers: it advances the shared offset once
         self._last_flow_rng = None
+        self._mask_pool = None         # Bernoulli masks pre-drawn by the network for this call (one launch for all layers)
         self._last_masks = None
 
     # reference keeps the prior tensors as attributes; expose them lazily with the same names
@@ -346,6 +347,7 @@ class _BayesLinearBase(nn.Module):
                 out, kl, _ = self._forward_hip(x, cfg, advance=self._advance_rng)
         finally:
             self._preflow = None
+            self._mask_pool = None
         self.kl = kl if cfg[1] else 0
         return out
 
@@ -479,9 +481,14 @@ class MNFBayesianLinear(_BayesLinearBase):
         pool = []
 
         def draw(n):
-            # all Bernoulli(0.5) masks this call needs come from ONE device draw (2T + Tr rows), not one per mask
+            # all Bernoulli(0.5) masks this call needs come from ONE device launch (2T + Tr rows, or the rows a network
+            # drew for all of its layers at once: _mask_pool), not one per mask
             if not pool:
-                pool.extend((torch.rand(2 * T + Tr, I, device=dev) < 0.5).float().unbind(0))
+                if self._mask_pool is not None:
+                    pool.extend(self._mask_pool)
+                    self._mask_pool = None
+                else:
+                    pool.extend(torch.empty(2 * T + Tr, I, device=dev).bernoulli_(0.5).unbind(0))
             return [pool.pop() for _ in range(n)]
         zm = [m[-1] if m.dim() == 2 else m for m in noise["zmask"]] if "zmask" in noise else draw(T)
         out = {"zmask": zm}
@@ -743,6 +750,7 @@ class _NetworkBase(nn.Module):
             if shared:
                 # as in the fused no-grad path the three layers share ONE RNG offset (their Philox streams differ by
                 # layer id), advanced once after the last layer
+                self._predraw_masks([l for l in layers if l._mnf and l._check_flows() == "dense"])
                 self._preflow_dense(layers, sample)
             try:
                 for i, l in enumerate(layers):
@@ -755,6 +763,21 @@ class _NetworkBase(nn.Module):
                 ops.RngState.get(x.device).advance(1)
             return F.log_softmax(x, dim=1)                            # …LRT.py:210
         return self._forward_streams(x.float(), sample)
+
+    @staticmethod
+    def _predraw_masks(dense_layers):
+        """One Bernoulli(0.5) launch for every mask the dense flows of these layers need in this forward."""
+        need = [l for l in dense_layers if not (l.noise and "zmask" in l.noise) and l._mask_pool is None]
+        if not need:
+            return
+        dev = need[0].q0_mean.device
+        rows = [2 * len(l.z_flow.transforms) + len(l.r_flow.transforms) for l in need]
+        width = max(l.in_features for l in need)
+        allm = torch.empty(sum(rows), width, device=dev).bernoulli_(0.5)
+        r0 = 0
+        for l, r in zip(need, rows):
+            l._mask_pool = [allm[r0 + k, :l.in_features] for k in range(r)]
+            r0 += r
 
     def _preflow_dense(self, layers, sample):
         """Training forward of a net whose layers all use dense (RNVP / MNF-type) flows: the flows depend on parameters
@@ -772,6 +795,7 @@ class _NetworkBase(nn.Module):
         dev = layers[0].q0_mean.device
         rng = ops.RngState.get(dev).t if any(l._uses_rng(c) for l, c in zip(layers, cfgs)) else None
         snap = rng.clone() if rng is not None else None
+        self._predraw_masks(layers)
         dls, keep = (_lib.DenseLayer * len(layers))(), []
         for k, (l, c) in enumerate(zip(layers, cfgs)):
             ws = l._workspace()
@@ -818,6 +842,7 @@ class _NetworkBase(nn.Module):
         # runs K1 only for those layers (flows_done)
         dense = [(l, c) for l, c in zip(layers, cfgs) if l._mnf and l._check_flows() == "dense"]
         if dense:
+            self._predraw_masks([l for l, _ in dense])
             same = len({(len(l.z_flow.transforms), len(l.r_flow.transforms), c[1]) for l, c in dense}) == 1
             groups = [dense] if same else [[lc] for lc in dense]
             for grp in groups:
