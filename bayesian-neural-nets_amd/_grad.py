@@ -1,10 +1,14 @@
-"""Interim backward pass: differentiable PyTorch-ROCm restatement of the layer arithmetic.
+"""Differentiable PyTorch-ROCm restatements of the VECTOR-sized layer arithmetic, on GPU tensors.
 
-The FORWARD of every layer runs in the hand-written HIP kernels.  Until the HIP backward
-kernels land, ``loss.backward()`` is served by recomputing the layer with
-the torch ops below *on the GPU tensors* under autograd, using exactly the noise the forward
-kernels drew (re-created with ``lbbnn_philox_normal``).  This module is only ever entered from
-``autograd.Function.backward``; nothing in the forward path calls it, and it never touches CPU.
+What still enters here from ``autograd.Function.backward`` (never from a forward, never on CPU):
+  * layers whose flows are 1-D chains (Radial / Householder / Sylvester / mixed): ``mnf_vector_graph`` over (I,) / (O,)
+    vectors, with the noise the forward kernels drew re-created by ``lbbnn_philox_normal``;
+  * the LRT layer's two bias terms (``lrt_vector_graph``);
+  * the baseline LBBNN and variational-dropout layers (``base_torch`` and friends);
+  * RNVP / MNF-type layers only when ``LBBNN_DENSE_TORCH_BWD=1`` asks for it (A/B timing, second opinion in tests).
+Everything (O,I)- or (B,O)-sized -- and, for planar and dense-flow MNF layers, every vector-sized gradient too -- is
+computed by the HIP kernels (``layers._BayesLinearFn.backward``).  The whole-layer functions at the end
+(``lrt_torch``, ``mnf_planar_torch``) are kept as cross-checks for the tests.
 """
 import math
 

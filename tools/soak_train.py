@@ -1,10 +1,11 @@
-import sys, torch
+import os, sys, torch
 sys.path.insert(0, ".")
 import bnn_amd
 dev = torch.device("cuda:0")
 bnn_amd.set_precision("bf16x3")
 torch.manual_seed(0)
-net = bnn_amd.mnf.BayesianNetwork((784, 1200, 1200, 10), 2, z_flow_type="Planar", r_flow_type="Planar").to(dev).train()
+FLOW = os.environ.get("FLOW", "Planar")       # Planar (headline) | RNVP (reference default) | MNF
+net = bnn_amd.mnf.BayesianNetwork((784, 1200, 1200, 10), 2, z_flow_type=FLOW, r_flow_type=FLOW).to(dev).train()
 opt = bnn_amd.optim.Adam(net.parameters(), lr=1e-3)
 # a learnable synthetic task: labels = argmax of a fixed random projection of the input
 g = torch.Generator(device=dev).manual_seed(1)
