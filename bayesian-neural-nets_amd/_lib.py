@@ -194,6 +194,7 @@ SIGNATURES = {
     "lbbnn_forward_finish": (c_i, [c_p, c_u64, c_p, c_i, c_p, c_p]),
     "lbbnn_gate_sample": (c_i, [ctypes.POINTER(GateArgs), c_p, c_p]),
     "lbbnn_vd_operands": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "lbbnn_weight_operands_t": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "lbbnn_rng_advance": (c_i, [c_p, c_u64, c_p]),
     "lbbnn_philox_normal": (c_i, [c_p, c_u32, c_i64, c_i64, c_i64, c_p, c_p]),
     "lbbnn_log_softmax_rows": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_p]),

@@ -149,6 +149,38 @@ __global__ __launch_bounds__(256) void vd_operands_kernel(const float* __restric
     }
 }
 
+// Backward operands of a Bayesian layer in ONE pass over its parameters: (e_w)^T = (mu * alpha * z)^T and
+// (var_w)^T = (sigma^2 alpha^2)^T as GEMM operands [I][ld(O)] (the dX products contract over O) -- instead of the weight
+// pass (fp32 operands) followed by two transposes.  Same tiling as K7; same elementwise forms as the weight pass.
+__global__ __launch_bounds__(256) void weight_operands_t_kernel(const float* __restrict__ mu, const float* __restrict__ rho,
+                                                                const float* __restrict__ lam, const float* __restrict__ z,
+                                                                void* e_t, void* v_t, int ld, int O, int I, int split) {
+    __shared__ float te[32][33], tv[32][33];
+    const int o0 = blockIdx.x * 32, i0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int o = o0 + ty + 8 * r, i = i0 + tx;
+        float e = 0.f, v = 0.f;
+        if (o < O && i < I) {
+            const size_t k = (size_t)o * I + i;
+            const float alpha = __frcp_rn(1.0f + __expf(-lam[k]));
+            e = mu[k] * alpha * (z ? z[i] : 1.f);
+            if (v_t) { const float sg = softplus_fast(rho[k]); v = sg * sg * alpha * alpha; }
+        }
+        te[ty + 8 * r][tx] = e; tv[ty + 8 * r][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + ty + 8 * r, o = o0 + tx;
+        if (i < I && o < ld) {                                   // zero for o >= O: keeps the operand tail zero-filled
+            store_operand(e_t, split, I, ld, i, o, te[tx][ty + 8 * r]);
+            if (v_t) store_operand(v_t, split, I, ld, i, o, tv[tx][ty + 8 * r]);
+        }
+    }
+}
+
 // generic (R,C) -> operand [C][ld] transpose, optional square (same tiling as K7)
 __global__ __launch_bounds__(256) void transpose_operand_kernel(const float* __restrict__ src, int R, int C, int lds_src,
                                                                 void* dst, int ld, int square, int split) {
@@ -180,6 +212,17 @@ extern "C" int lbbnn_transpose_operand(const float* src, int R, int C, int lds_s
     hipLaunchKernelGGL(transpose_operand_kernel, dim3((ld + 31) / 32, (C + 31) / 32), dim3(256), 0,
                        static_cast<hipStream_t>(stream), src, R, C, lds_src, dst, ld, square ? 1 : 0,
                        (flags & LBBNN_F_SPLIT16) ? 1 : 0);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lbbnn_weight_operands_t(const float* mu, const float* rho, const float* lambdal, const float* z,
+                                       void* e_t, void* v_t, int ld, int O, int I, int flags, void* stream) {
+    if (!mu || !lambdal || !e_t || (v_t && !rho)) return LBBNN_E_NULL;
+    if (O <= 0 || I <= 0) return LBBNN_E_SHAPE;
+    if (ld < O || (ld & 31)) return LBBNN_E_ALIGN;
+    if (flags & ~LBBNN_F_SPLIT16) return LBBNN_E_FLAGS;
+    hipLaunchKernelGGL(weight_operands_t_kernel, dim3((ld + 31) / 32, (I + 31) / 32), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), mu, rho, lambdal, z, e_t, v_t, ld, O, I, (flags & LBBNN_F_SPLIT16) ? 1 : 0);
     return (int)hipGetLastError();
 }
 

@@ -132,16 +132,35 @@ class _BayesLinearFn(torch.autograd.Function):
         # ---- the four big products on the HIP GEMM kernels
         gx = None
         if ctx.needs_input_grad[1]:
-            ws = layer._workspace()
-            bw = ws.backward_operands()
-            ops.weight_pass(mu, rho, lam, z_fwd=z_k, priors=layer.priors, e_w=bw[0],
-                            var_w=bw[1] if stochastic else None)
-            I = layer.in_features
-            gx = _hip_matmul_nt(g, ops.transpose_operand, bw[0][:, :I])
-            if stochastic:
-                gx = ops.dx_combine(gx, _hip_matmul_nt(g_v, ops.transpose_operand, bw[1][:, :I]), x)
-        dWm = _hip_matmul_nt(gT, ops.transpose_operand, x, allow_splitk=True)
-        dWv = _hip_matmul_nt(g_vT, ops.transpose_operand, x, square=True, allow_splitk=True) if stochastic else None
+            # (e_w z)^T and var_w^T straight from the parameters in one pass (lbbnn_weight_operands_t)
+            from . import _lib
+            O, I = layer.out_features, layer.in_features
+            split_m = _operand_split_ok(g, O, I)
+            split_v = _operand_split_ok(g_v, O, I) if stochastic else split_m
+            ld = ops.operand_ld(O)
+            e_t = torch.empty((I, ld), dtype=torch.float32, device=x.device)
+            v_t = torch.empty((I, ld), dtype=torch.float32, device=x.device) if stochastic else None
+            if split_m == split_v:
+                _lib.check(_lib.lib().lbbnn_weight_operands_t(
+                    mu.data_ptr(), rho.data_ptr(), lam.data_ptr(), z_k.data_ptr() if z_k is not None else None,
+                    e_t.data_ptr(), v_t.data_ptr() if v_t is not None else None, ld, O, I,
+                    ops.F_SPLIT16 if split_m else 0, torch.cuda.current_stream(x.device).cuda_stream), "lbbnn_weight_operands_t")
+                w_shape = torch.empty((O, I), device="meta")       # shape carrier for _hip_matmul_nt
+                gx = _hip_matmul_nt(g, None, w_shape, op=e_t)
+                if stochastic:
+                    gx = ops.dx_combine(gx, _hip_matmul_nt(g_v, None, w_shape, op=v_t), x)
+            else:
+                ws = layer._workspace()
+                bw = ws.backward_operands()
+                ops.weight_pass(mu, rho, lam, z_fwd=z_k, priors=layer.priors, e_w=bw[0],
+                                var_w=bw[1] if stochastic else None)
+                gx = _hip_matmul_nt(g, ops.transpose_operand, bw[0][:, :I])
+                if stochastic:
+                    gx = ops.dx_combine(gx, _hip_matmul_nt(g_v, ops.transpose_operand, bw[1][:, :I]), x)
+        pair = _x_operand_pair(x, gT, g_vT) if stochastic else None
+        dWm = _hip_matmul_nt(gT, ops.transpose_operand, x, allow_splitk=True, op=pair[0] if pair else None)
+        dWv = (_hip_matmul_nt(g_vT, ops.transpose_operand, x, square=True, allow_splitk=True, op=pair[1] if pair else None)
+               if stochastic else None)
         # ---- K1b: the whole (O,I) chain in one pass
         dmu, drho, dlam, dz_k, dz2, dr0c = ops.weight_pass_backward(
             mu, rho, lam, dWm, dWv, z_fwd=z_k, z_kl=z2, r0_c=r0_c, da_mu=da_mu, da_var=da_var, g_kl=g_kl,
@@ -197,17 +216,22 @@ class _BayesLinearFn(torch.autograd.Function):
         return (None, gx, None, dmu, drho, dlam, *vgrads)
 
 
-def _hip_matmul_nt(a, transpose_fn, w, square=False, allow_splitk=False):
+def _operand_split_ok(a, K, N):
+    return (ops.get_precision() == "bf16x3" and ops.split_eligible(K, N)
+            and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0)
+
+
+def _hip_matmul_nt(a, transpose_fn, w, square=False, allow_splitk=False, op=None):
     """a (M,K) @ f(w) (K,N) with f = identity or square, through lbbnn_lrt_gemm (mean-only):
-    the operand is f(w)^T = [N][ld(K)], built by lbbnn_transpose_operand.  With ``allow_splitk`` a long contraction
-    with few output tiles (the weight gradients: K = batch) is cut into k ranges that fill the chip; the result is
-    then (S,M,N) slabs for the consumer (lbbnn_weight_pass_backward) to add."""
+    the operand is f(w)^T = [N][ld(K)], built by lbbnn_transpose_operand (or handed in as ``op``).  With
+    ``allow_splitk`` a long contraction with few output tiles (the weight gradients: K = batch) is cut into k ranges
+    that fill the chip; the result is then (S,M,N) slabs for the consumer (lbbnn_weight_pass_backward) to add."""
     M, K = a.shape
     N = w.shape[1]
     assert w.shape[0] == K
-    split = (ops.get_precision() == "bf16x3" and ops.split_eligible(K, N)
-             and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0)
-    op = transpose_fn(w if w.stride(1) == 1 else w.contiguous(), square=square, split=split)
+    split = _operand_split_ok(a, K, N)
+    if op is None:
+        op = transpose_fn(w if w.stride(1) == 1 else w.contiguous(), square=square, split=split)
     if allow_splitk and split and K >= 1024:
         tiles = ((N + 79) // 80) * ((M + 127) // 128 if M >= 96 else (M + 31) // 32)
         S = max(1, min(16, (400 + tiles - 1) // tiles, K // 256))
@@ -215,6 +239,25 @@ def _hip_matmul_nt(a, transpose_fn, w, square=False, allow_splitk=False):
             kchunk = ((K + S - 1) // S + 31) // 32 * 32
             return ops.matmul_splitk(a, op, K=K, N=N, kchunk=kchunk)
     return ops.lrt_gemm(a, op, None, I=K, O=N, mean_only=True, split=split)
+
+
+def _x_operand_pair(x, gT, g_vT):
+    """x^T and (x^2)^T as GEMM operands from ONE pass over x (lbbnn_vd_operands: the variational-dropout kernel does
+    exactly this for theta) when both weight-gradient products use the same operand format; else None."""
+    from . import _lib
+    B, I = x.shape
+    if not x.is_contiguous():
+        return None
+    split = _operand_split_ok(gT, B, I)
+    if split != _operand_split_ok(g_vT, B, I):
+        return None
+    ld = ops.operand_ld(B)
+    xt = torch.empty((I, ld), dtype=torch.float32, device=x.device)
+    x2t = torch.empty((I, ld), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().lbbnn_vd_operands(x.data_ptr(), xt.data_ptr(), x2t.data_ptr(), ld, B, I,
+                                            ops.F_SPLIT16 if split else 0, torch.cuda.current_stream(x.device).cuda_stream),
+               "lbbnn_vd_operands")
+    return xt, x2t
 
 
 class _BayesLinearBase(nn.Module):

@@ -338,6 +338,13 @@ int lbbnn_gate_sample(const lbbnn_gate_args_t* args, const uint64_t* rng, void* 
  */
 int lbbnn_vd_operands(const float* theta, void* e_w, void* var_w, int ld, int I, int O, int flags, void* stream);
 
+/* Backward operands of a Bayesian layer from its parameters in one pass: e_t = (weight_mu * sigmoid(lambdal) * z)^T and
+ * v_t = (softplus(weight_rho)^2 sigmoid(lambdal)^2)^T as GEMM operands [I][ld] with ld = lbbnn_operand_ld(O), for the
+ * input-gradient products dX = G_m . W_m + 2 x (.) (G_v . W_v) (contraction over O).  z (I) NULL = LRT layer; v_t NULL =
+ * posterior-mean forward.  flags: LBBNN_F_SPLIT16 as elsewhere.  Replaces lbbnn_weight_pass + 2 x lbbnn_transpose_operand. */
+int lbbnn_weight_operands_t(const float* weight_mu, const float* weight_rho, const float* lambdal, const float* z,
+                            void* e_t, void* v_t, int ld, int O, int I, int flags, void* stream);
+
 
 /* ---------------------------------------------------------------------------------------------
  * Training support (the backward of loss.backward(), LBBNN-GP-MF-LRT.py:225).
