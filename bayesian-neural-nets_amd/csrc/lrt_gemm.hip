@@ -962,16 +962,17 @@ extern "C" int lbbnn_lrt_gemm_train(const float* x, int ldx, const void* e_w, co
 extern "C" int lbbnn_lrt_gemm_finalize(const float* x, int ldx, const void* e_w, const void* var_w, int ld,
                                        const float* bias_mean, const float* bias_var, const float* var_scale,
                                        const float* eps, const uint64_t* rng, uint32_t rng_stream, int64_t row_offset,
-                                       float* out, int ldo, int B, int I, int O, int flags,
+                                       float* out, int ldo, float* std_out, int B, int I, int O, int flags,
                                        const lbbnn_layer_desc_t* layers, int n, const uint64_t* fin_rng, float* kl_total,
                                        void* stream) {
+    if (((flags & LBBNN_F_MEAN_ONLY) || (flags & LBBNN_F_LOG_SOFTMAX)) && std_out) return LBBNN_E_FLAGS;
     FinalizePiggy fin{};
     if (const int rc = fill_finalize_args(layers, n, fin_rng, fin.l, fin.active)) return rc;
     if (kl_total) for (int i = 0; i < n; ++i) if (!fin.active[i]) return LBBNN_E_NULL;   // a total needs every layer's KL
     fin.n = n; fin.total = kl_total;
     bool hosted = false;
     const int rc = lrt_gemm_impl(x, ldx, e_w, var_w, ld, bias_mean, bias_var, var_scale, eps, rng, rng_stream, row_offset,
-                                 out, ldo, nullptr, B, I, O, flags, stream, 0, &fin, &hosted);
+                                 out, ldo, std_out, B, I, O, flags, stream, 0, &fin, &hosted);
     if (rc) return rc;
     if (hosted) return 0;
     // this GEMM's kernel cannot host the extra workgroup (small tile configuration, skinny output, LDS): same work, own launch

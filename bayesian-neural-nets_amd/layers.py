@@ -365,10 +365,20 @@ class _BayesLinearBase(nn.Module):
         kl = torch.empty((), dtype=torch.float32, device=x.device) if cfg[1] else None
         self._split_now = self._split(x)
         self._last_masks = None
-        self._prep(cfg, rng, kl_layer=kl)
+        # the layer's KL tail (K5) depends on parameters only: it rides in the GEMM's launch (lbbnn_lrt_gemm_finalize)
+        # instead of a launch of its own between the weight pass and the GEMM
+        fin = None
+        self._prep(cfg, rng, kl_layer=kl, finalize=not cfg[1])
+        if cfg[1]:
+            from . import _lib
+            desc = (_lib.LayerDesc * 1)()
+            keep = self._fill_desc(desc[0], cfg, kl)
+            fin = (desc, 1, rng.data_ptr() if rng is not None else None, None)
         saved["masks"] = self._last_masks
         std = torch.empty((x.shape[0], self.out_features), dtype=torch.float32, device=x.device) if want_std else None
-        out = self._gemm(x, cfg, rng, std_out=std)
+        out = self._gemm(x, cfg, rng, std_out=std, finalize=fin)
+        if cfg[1]:
+            del keep
         if std is not None:
             saved["std"] = std
         if st is not None and advance:

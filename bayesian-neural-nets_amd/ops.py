@@ -289,7 +289,8 @@ def lrt_gemm(x, e_w, var_w, *, I: int, O: int, bias_mean=None, bias_var=None, va
             _ptr_rows(x, "input"), x.stride(0), _ptr(e_w), _ptr(var_w), operand_ld(I),
             _ptr(bias_mean), _ptr(bias_var), _ptr(var_scale), _ptr(eps, "eps"),
             rng.data_ptr() if rng is not None else None, rng_stream, row_offset,
-            out.data_ptr(), out.stride(0), B, I, O, flags, finalize[0], finalize[1], finalize[2], finalize[3], _stream())
+            out.data_ptr(), out.stride(0), _ptr(std_out, "std_out"), B, I, O, flags,
+            finalize[0], finalize[1], finalize[2], finalize[3], _stream())
     elif std_out is None:
         rc = _lib.lib().lbbnn_lrt_gemm(
             _ptr_rows(x, "input"), x.stride(0), _ptr(e_w), _ptr(var_w), operand_ld(I),

@@ -271,7 +271,7 @@ int lbbnn_layers_finalize(const lbbnn_layer_desc_t* layers, int n, uint64_t* rng
  *   forward that reads the live state (the flow kernels), so every LATER kernel of this forward -- the GEMMs, the KL
  *   finalize -- must be given rng_snap as its `rng`.  rng == NULL: no RNG in use, nothing is copied.
  *
- * lbbnn_lrt_gemm_finalize = lbbnn_lrt_gemm (same arguments up to `flags`) + the work of lbbnn_layers_finalize
+ * lbbnn_lrt_gemm_finalize = lbbnn_lrt_gemm_train (same arguments up to `flags`; std_out may be NULL) + the work of lbbnn_layers_finalize
  *   (every layer's KL tail from its descriptor, kl_layer outputs, *kl_total if non-NULL; no RNG advance) for the n
  *   layers, computed by ONE extra workgroup of the same launch while the tiles are computed: the KL tail depends on
  *   parameters only, so it needs no launch of its own after the last GEMM.  fin_rng: the state K5 draws eps_act from
@@ -284,7 +284,7 @@ int lbbnn_layers_operands_snap(const lbbnn_layer_desc_t* layers, int n, uint64_t
 int lbbnn_lrt_gemm_finalize(const float* x, int ldx, const void* e_w, const void* var_w, int ld,
                             const float* bias_mean, const float* bias_var, const float* var_scale,
                             const float* eps, const uint64_t* rng, uint32_t rng_stream, int64_t row_offset,
-                            float* out, int ldo, int B, int I, int O, int flags,
+                            float* out, int ldo, float* std_out, int B, int I, int O, int flags,
                             const lbbnn_layer_desc_t* layers, int n, const uint64_t* fin_rng, float* kl_total,
                             void* stream);
 
