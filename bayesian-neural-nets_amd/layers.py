@@ -35,6 +35,68 @@ import os as _os
 # before lbbnn_mnf_flow_dense_backward existed (kept for A/B timing and as a second opinion in the tests)
 _DENSE_HIP_BWD = _os.environ.get("LBBNN_DENSE_TORCH_BWD", "0") != "1"
 
+# Optional overlap of the vector-sized backward chains (V2 / lbbnn_mnf_flow_dense_backward: latency-bound, a handful of
+# workgroups, feeding nothing but the optimizer) with the backward GEMMs of the other layers: they are issued on a side
+# stream forked after K1b.  OFF unless a caller that also JOINS before the optimizer step turns it on
+# (graphs.make_graphed_train_step, or `with layers.vector_backward_overlap(): loss.backward()`): the gradients such a
+# backward returns are only complete after join_vector_backward().
+_OVERLAP = {"on": False, "streams": {}, "pending": []}
+
+
+def _side_stream(dev):
+    key = (dev.type, dev.index)
+    st = _OVERLAP["streams"].get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=dev)
+        _OVERLAP["streams"][key] = st
+    return st
+
+
+def join_vector_backward():
+    """Make the current stream wait for the side-stream backward chains issued so far (no-op if there are none)."""
+    if not _OVERLAP["pending"]:
+        return
+    for dev in {t.device for grp in _OVERLAP["pending"] for t in grp if t is not None}:
+        torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
+    _OVERLAP["pending"].clear()
+
+
+class vector_backward_overlap:
+    """Context manager: backward passes inside run their vector-sized chains on a side stream; joined on exit."""
+
+    def __enter__(self):
+        self._was = _OVERLAP["on"]
+        _OVERLAP["on"] = True
+        return self
+
+    def __exit__(self, *exc):
+        _OVERLAP["on"] = self._was
+        join_vector_backward()
+        return False
+
+
+class _SideSection:
+    """Issue the enclosed launches on the side stream (after everything issued so far on the current one) and keep the
+    listed input tensors alive until the join -- or do nothing when the overlap is off."""
+
+    def __init__(self, dev, keep):
+        self.on = _OVERLAP["on"]
+        self.dev, self.keep, self.cm = dev, keep, None
+
+    def __enter__(self):
+        if self.on:
+            side = _side_stream(self.dev)
+            side.wait_stream(torch.cuda.current_stream(self.dev))
+            self.cm = torch.cuda.stream(side)
+            self.cm.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.cm.__exit__(*exc)
+            _OVERLAP["pending"].append(tuple(self.keep))
+        return False
+
 _layer_ids = itertools.count()
 
 
@@ -167,12 +229,14 @@ class _BayesLinearFn(torch.autograd.Function):
             priors=layer.priors)
         if planar:
             zp, rp = layer._planar_params_from(params)
-            G = ops.mnf_flow_planar_backward(
-                P["q0_mean"], P["q0_log_var"], zp, rp, eps_fwd=None if in_kernel else noise["eps_z"].contiguous(),
-                eps_kl=noise["eps_z2"].contiguous() if (want_kl and not in_kernel) else None,
-                rng=rng_snap, layer_id=layer._layer_id, r0_b1=P["r0_b1"], r0_b2=P["r0_b2"], aux=aux,
-                dz_fwd=dz_k, dz_kl=dz2, g_kl=g_kl, bias_mu=P["bias_mu"], bias_rho=P["bias_rho"], g_sum=g_sum,
-                gv_sum=gv_sum, priors=layer.priors)
+            e1 = None if in_kernel else noise["eps_z"].contiguous()
+            e2 = noise["eps_z2"].contiguous() if (want_kl and not in_kernel) else None
+            with _SideSection(x.device, (aux, dz_k, dz2, g_kl, g_sum, gv_sum, rng_snap, e1, e2)):
+                G = ops.mnf_flow_planar_backward(
+                    P["q0_mean"], P["q0_log_var"], zp, rp, eps_fwd=e1, eps_kl=e2,
+                    rng=rng_snap, layer_id=layer._layer_id, r0_b1=P["r0_b1"], r0_b2=P["r0_b2"], aux=aux,
+                    dz_fwd=dz_k, dz_kl=dz2, g_kl=g_kl, bias_mu=P["bias_mu"], bias_rho=P["bias_rho"], g_sum=g_sum,
+                    gv_sum=gv_sum, priors=layer.priors)
             G["r0_c"] = dr0c if dr0c is not None else torch.zeros_like(P["q0_mean"])
             vgrads = [G[n] for n in layer._vec_names]
             for key in ("z_flow", "r_flow"):
@@ -186,15 +250,17 @@ class _BayesLinearFn(torch.autograd.Function):
             rd, Tr, k2 = layer.r_flow.dense_descs(None, masks.get("rmask")) if want_kl else (None, 0, None)
             rest = list(params[len(layer._names):])
             nz = len(list(layer.z_flow.parameters()))
-            G = ops.mnf_flow_dense_backward(
-                P["q0_mean"], P["q0_log_var"], zd, Tz, 0 if layer.z_flow.kind == "RNVP" else 1, rest[:nz],
-                rd, Tr, 0 if layer.r_flow.kind == "RNVP" else 1, rest[nz:], save=ctx.saved["dense_save"],
-                eps_fwd=None if in_kernel else noise["eps_z"].contiguous(),
-                eps_kl=noise["eps_z2"].contiguous() if (want_kl and not in_kernel) else None,
-                rng=ctx.saved.get("rng_flow") if ctx.saved.get("rng_flow") is not None else rng_snap,
-                layer_id=layer._layer_id, r0_b1=P["r0_b1"], r0_b2=P["r0_b2"], aux=aux,
-                dz_fwd=dz_k, dz_kl=dz2, g_kl=g_kl, bias_mu=P["bias_mu"], bias_rho=P["bias_rho"], g_sum=g_sum,
-                gv_sum=gv_sum, priors=layer.priors)
+            e1 = None if in_kernel else noise["eps_z"].contiguous()
+            e2 = noise["eps_z2"].contiguous() if (want_kl and not in_kernel) else None
+            rng_f = ctx.saved.get("rng_flow") if ctx.saved.get("rng_flow") is not None else rng_snap
+            with _SideSection(x.device, (aux, dz_k, dz2, g_kl, g_sum, gv_sum, rng_f, e1, e2, ctx.saved["dense_save"],
+                                         *k1, *(k2 or ()))):
+                G = ops.mnf_flow_dense_backward(
+                    P["q0_mean"], P["q0_log_var"], zd, Tz, 0 if layer.z_flow.kind == "RNVP" else 1, rest[:nz],
+                    rd, Tr, 0 if layer.r_flow.kind == "RNVP" else 1, rest[nz:], save=ctx.saved["dense_save"],
+                    eps_fwd=e1, eps_kl=e2, rng=rng_f, layer_id=layer._layer_id, r0_b1=P["r0_b1"], r0_b2=P["r0_b2"], aux=aux,
+                    dz_fwd=dz_k, dz_kl=dz2, g_kl=g_kl, bias_mu=P["bias_mu"], bias_rho=P["bias_rho"], g_sum=g_sum,
+                    gv_sum=gv_sum, priors=layer.priors)
             del k1, k2
             G["r0_c"] = dr0c if dr0c is not None else torch.zeros_like(P["q0_mean"])
             if not want_kl:

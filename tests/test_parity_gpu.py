@@ -1297,6 +1297,32 @@ def test_dense_network_training_forward_batched_flows(bnn, dev, kind, monkeypatc
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["RNVP", "Planar"])
+def test_vector_backward_overlap_same_gradients(bnn, dev, kind):
+    """layers.vector_backward_overlap(): the vector-sized backward chains run on a side stream (forked after K1b, joined
+    on exit) -- same kernels, same inputs, so every gradient must be bitwise what the single-stream backward gives."""
+    from bnn_amd import layers
+    torch.manual_seed(4)
+    net = bnn.mnf.BayesianNetwork((48, 64, 40, 10), 2, z_flow_type=kind, r_flow_type=kind).to(dev).train()
+    x = torch.rand(64, 48, device=dev)
+    y = torch.randint(0, 10, (64,), device=dev)
+    res = []
+    for overlap in (False, True):
+        bnn.manual_seed(21, 2)
+        net.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.nll_loss(net(x, sample=True), y, reduction="sum") + net.kl() / 10
+        if overlap:
+            with layers.vector_backward_overlap():
+                loss.backward()
+        else:
+            loss.backward()
+        torch.cuda.synchronize()
+        res.append({n: p.grad.clone() for n, p in net.named_parameters()})
+    for n in res[0]:
+        assert torch.equal(res[0][n], res[1][n]), n
+
+
+@pytest.mark.gpu
 def test_gemm_random_shape_sweep():
     """tools/gemm_fuzz.py: 40 random (B, I, O) shapes through K1 + the dual-moment GEMM in both precisions against fp64
     (tails in every dimension, clamped rows, split eligibility boundaries)."""
