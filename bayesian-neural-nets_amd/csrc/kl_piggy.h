@@ -18,8 +18,11 @@ inline size_t piggy_lds_bytes(const FinalizePiggy& p) {
     return (size_t)mx * sizeof(float) + 3 * 4 * sizeof(double) + LBBNN_MAX_LAYERS * sizeof(float) + 16;
 }
 
-// blockDim.x == 256 (four waves); every thread of the workgroup must call it
+// blockDim.x == NW * 64 (NW = 2 or 4 waves); every thread of the workgroup must call it
+template <int NW>
 __device__ __forceinline__ void kl_finalize_piggy(const LBBNN_CONST_AS FinalizePiggy& A, float* sm) {
+    static_assert(NW >= 1 && NW <= 4, "scratch holds 4 partials per sum");
+    constexpr int NT = NW * 64;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     float total = 0.f;
     for (int g = 0; g < A.n; ++g) {                                              // uniform
@@ -48,7 +51,7 @@ __device__ __forceinline__ void kl_finalize_piggy(const LBBNN_CONST_AS FinalizeP
         const float log_sp = __logf(a.bias_sigma_prior);
         const float inv_2sp2 = 1.f / (2.f * a.bias_sigma_prior * a.bias_sigma_prior);
         double s_rows = 0.0, s_bias = 0.0, s_act = 0.0;
-        for (int o4 = 4 * t; o4 < O; o4 += 1024) {                               // 4 consecutive outputs share one Philox call
+        for (int o4 = 4 * t; o4 < O; o4 += 4 * NT) {                               // 4 consecutive outputs share one Philox call
             float n[4] = {0.f, 0.f, 0.f, 0.f};
             if (mnf && !a.eps_act) philox_normal4(seed, offs, LBBNN_STREAM_EPS_ACT * 64u + a.layer, (uint64_t)(o4 >> 2), 0u, n);
 #pragma unroll
@@ -66,6 +69,8 @@ __device__ __forceinline__ void kl_finalize_piggy(const LBBNN_CONST_AS FinalizeP
             }
         }
         s_rows = wave_sum(s_rows); s_bias = wave_sum(s_bias); s_act = wave_sum(s_act);
+        if (t < 12) scr[t] = 0.0;                                 // (waves beyond NW contribute nothing)
+        __syncthreads();
         if (lane == 0) { scr[w] = s_rows; scr[4 + w] = s_bias; scr[8 + w] = s_act; }
         __syncthreads();
         s_rows = (scr[0] + scr[1]) + (scr[2] + scr[3]);
@@ -75,13 +80,15 @@ __device__ __forceinline__ void kl_finalize_piggy(const LBBNN_CONST_AS FinalizeP
         if (mnf) {
             const float m = (float)(s_act / (double)O);          // outer(b, act).mean(-1) = b * mean(act)   :220-221
             double s_rb = 0.0;
-            for (int i = t; i < I; i += 256) {
+            for (int i = t; i < I; i += NT) {
                 const float mr = b1[i] * m, lv = b2[i] * m;
                 const float d = zb - mr;
                 s_rb += (double)(-0.5f * 1.1447298858494002f - 0.5f * lv - 0.5f * ((d * d) * __expf(-lv)));  // :223-224
             }
             s_rb = wave_sum(s_rb);
             __syncthreads();                                     // scr free again
+            if (t < 4) scr[t] = 0.0;
+            __syncthreads();
             if (lane == 0) scr[w] = s_rb;
             __syncthreads();
             s_rb = (scr[0] + scr[1]) + (scr[2] + scr[3]);

@@ -349,14 +349,12 @@ __global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_f32_dma_kernel(const Gemm
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, q = lane >> 4;
-    if constexpr (WB == 4) {
-        if (a.fin.n > 0 && blockIdx.y == gridDim.y - 1) {                      // the finalize row (uniform per workgroup)
-            if (blockIdx.x == 0) kl_finalize_piggy(kernarg_as<GemmArgs>()->fin, smem);
-            return;
-        }
+    if (a.fin.n > 0 && blockIdx.y == gridDim.y - 1) {                          // the finalize row (uniform per workgroup)
+        if (blockIdx.x == 0) kl_finalize_piggy<WB>(kernarg_as<GemmArgs>()->fin, smem);
+        return;
     }
     int tox, tby;
-    tile_of_block(tox, tby, (WB == 4 && a.fin.n > 0) ? 1 : 0);
+    tile_of_block(tox, tby, a.fin.n > 0 ? 1 : 0);
     const int o0 = tox * BN;
     const int b0 = tby * BM;
 
@@ -514,14 +512,12 @@ __global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_bf16x3_kernel(const GemmA
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, q = lane >> 4;
-    if constexpr (WB == 4) {
-        if (a.fin.n > 0 && blockIdx.y == gridDim.y - 1) {                      // the finalize row (uniform per workgroup)
-            if (blockIdx.x == 0) kl_finalize_piggy(kernarg_as<GemmArgs>()->fin, reinterpret_cast<float*>(smc));
-            return;
-        }
+    if (a.fin.n > 0 && blockIdx.y == gridDim.y - 1) {                          // the finalize row (uniform per workgroup)
+        if (blockIdx.x == 0) kl_finalize_piggy<WB>(kernarg_as<GemmArgs>()->fin, reinterpret_cast<float*>(smc));
+        return;
     }
     int tox, tby;
-    tile_of_block(tox, tby, (WB == 4 && a.fin.n > 0) ? 1 : 0);
+    tile_of_block(tox, tby, a.fin.n > 0 ? 1 : 0);
     const int o0 = tox * BN;
     const int b0 = tby * BM;
     // split-K: this workgroup's k range (kbeg is a multiple of 32, so every alignment below is unchanged)
@@ -835,7 +831,7 @@ int launch_cfg(GemmArgs& a, bool mean_only, bool xvec, hipStream_t s, bool* host
     if (xvec && (a.I % BK) == 0 && !no_dma) {
         const size_t l_full = lds_request(2u * (BM + 2 * BN) * DROW * sizeof(float), nblocks);
         const size_t l_mean = lds_request(2u * (BM + BN) * DROW * sizeof(float), nblocks);
-        if (WB == 4 && fin_n > 0 && hosted) {
+        if (fin_n > 0 && hosted) {
             a.fin.n = fin_n;
             if (piggy_lds_bytes(a.fin) <= (mean_only ? l_mean : l_full)) { grid.y += 1; *hosted = true; }
             else a.fin.n = 0;
@@ -863,7 +859,7 @@ int launch_split_cfg(GemmArgs& a, bool mean_only, hipStream_t s, bool* hosted) {
     const size_t l_mean = lds_request(2u * (BM * 128 + 1 * BN * 128), nblocks);
     const int fin_n = a.fin.n;
     a.fin.n = 0;
-    if (WB == 4 && fin_n > 0 && hosted && !a.kchunk) {
+    if (fin_n > 0 && hosted && !a.kchunk) {
         a.fin.n = fin_n;
         if (piggy_lds_bytes(a.fin) <= (mean_only ? l_mean : l_full)) { grid.y += 1; *hosted = true; }
         else a.fin.n = 0;
