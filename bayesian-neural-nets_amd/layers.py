@@ -117,6 +117,8 @@ class _BayesLinearFn(torch.autograd.Function):
             ws = layer._workspace()
             # (the network may already have run this call's dense flows for all layers at once: _preflow_dense)
             fresh = ("act_mu", "act_var") if layer._preflow is not None else ("z_fwd", "z_kl", "scal", "act_mu", "act_var")
+            if layer._preprep is not None:
+                fresh = ()                          # the network gave this call its buffers before it ran K3 / K1
             for name in fresh:
                 setattr(ws, name, torch.empty_like(getattr(ws, name)))
         dense = layer._mnf and layer._check_flows() == "dense" and _DENSE_HIP_BWD
@@ -127,6 +129,7 @@ class _BayesLinearFn(torch.autograd.Function):
         finally:
             layer._keep_dense = False
             layer._preflow = None
+            layer._preprep = None
         if dense:
             saved["dense_save"], layer._last_dense_save = layer._last_dense_save, None
             saved["rng_flow"], layer._last_flow_rng = layer._last_flow_rng, None
@@ -356,6 +359,7 @@ class _BayesLinearBase(nn.Module):
         self._advance_rng = True       # False while a network drives the layers: it advances the shared offset once
         self._last_flow_rng = None
         self._mask_pool = None         # Bernoulli masks pre-drawn by the network for this call (one launch for all layers)
+        self._preprep = None           # K3 / K1 of this call already run by the network (one launch per kind for all layers)
         self._last_masks = None
 
     # reference keeps the prior tensors as attributes; expose them lazily with the same names
@@ -434,7 +438,14 @@ class _BayesLinearBase(nn.Module):
         # the layer's KL tail (K5) depends on parameters only: it rides in the GEMM's launch (lbbnn_lrt_gemm_finalize)
         # instead of a launch of its own between the weight pass and the GEMM
         fin = None
-        self._prep(cfg, rng, kl_layer=kl, finalize=not cfg[1])
+        pre = self._preprep
+        if pre is not None and pre["cfg"][:2] == tuple(cfg[:2]) and pre["split"] == self._split_now:
+            # K3 / K1 of this call were run by the network for all layers at once (_NetworkBase._preprep_all)
+            if self._preflow is not None:
+                fl = self._preflow
+                self._last_masks, self._last_dense_save, self._last_flow_rng = fl["masks"], fl["save"], fl["rng"]
+        else:
+            self._prep(cfg, rng, kl_layer=kl, finalize=not cfg[1])
         if cfg[1]:
             from . import _lib
             desc = (_lib.LayerDesc * 1)()
@@ -466,6 +477,7 @@ class _BayesLinearBase(nn.Module):
                 out, kl, _ = self._forward_hip(x, cfg, advance=self._advance_rng)
         finally:
             self._preflow = None
+            self._preprep = None
             self._mask_pool = None
         self.kl = kl if cfg[1] else 0
         return out
@@ -871,6 +883,7 @@ class _NetworkBase(nn.Module):
                 # layer id), advanced once after the last layer
                 self._predraw_masks([l for l in layers if l._mnf and l._check_flows() == "dense"])
                 self._preflow_dense(layers, sample)
+                self._preprep_all(layers, sample, x)
             try:
                 for i, l in enumerate(layers):
                     l._advance_rng = not shared
@@ -926,6 +939,36 @@ class _NetworkBase(nn.Module):
             l._preflow = {"cfg": c, "masks": l._last_masks, "save": save, "rng": snap}
         _lib.check(_lib.lib().lbbnn_layers_dense_flows(dls, len(layers), rng.data_ptr() if rng is not None else None,
                                                        torch.cuda.current_stream(dev).cuda_stream), "lbbnn_layers_dense_flows")
+        del keep
+
+    def _preprep_all(self, layers, sample, x):
+        """Training forward: K3 (planar flows) and K1 (weight pass) depend on parameters only, so they run here for ALL
+        layers -- one launch per kind, lbbnn_layers_operands -- with fresh per-call output vectors; the per-layer autograd
+        forwards then consist of the GEMM (carrying the layer's KL tail) alone."""
+        from . import _lib
+        fams = [(l._check_flows() if l._mnf else "lrt") for l in layers]
+        if "chain" in fams or len(layers) > 4:
+            return
+        if any(f == "dense" and l._preflow is None for f, l in zip(fams, layers)):
+            return                                   # dense flows not run yet (torch-backward mode): per-layer path
+        cfgs = [(bool(l.training or sample), bool(l.training), False) for l in layers]
+        dev = x.device
+        xin = x if x.dtype == torch.float32 else x.float()
+        rng = ops.RngState.get(dev).t if any(l._uses_rng(c) for l, c in zip(layers, cfgs)) else None
+        descs, keep, kls = (_lib.LayerDesc * len(layers))(), [], []
+        for i, (l, c, f) in enumerate(zip(layers, cfgs, fams)):
+            ws = l._workspace()
+            if l._mnf:
+                for name in (("act_mu", "act_var") if f == "dense" else ("z_fwd", "z_kl", "scal", "act_mu", "act_var")):
+                    setattr(ws, name, torch.empty_like(getattr(ws, name)))
+            l._split_now = l._split(xin if i == 0 else None) and (i == 0 or layers[i - 1].out_features % 4 == 0)
+            kl = torch.empty((), dtype=torch.float32, device=dev) if c[1] else None
+            kls.append(kl)
+            keep.append(l._fill_desc(descs[i], c, kl))
+        _lib.check(_lib.lib().lbbnn_layers_operands(descs, len(layers), rng.data_ptr() if rng is not None else None,
+                                                    torch.cuda.current_stream(dev).cuda_stream), "lbbnn_layers_operands")
+        for l, c in zip(layers, cfgs):
+            l._preprep = {"cfg": c, "split": l._split_now}
         del keep
 
     def _forward_streams(self, x, sample):
