@@ -431,31 +431,38 @@ class _BayesLinearBase(nn.Module):
         if self._uses_rng(cfg):
             st = ops.RngState.get(x.device)
             rng = st.t
-            saved["rng"] = rng.clone() if save_rng else None
+            pre_ = self._preprep
+            # (a network that drives its layers takes ONE snapshot of the shared state for all of them)
+            saved["rng"] = (pre_["snap"] if (pre_ is not None and pre_.get("snap") is not None) else rng.clone()) if save_rng else None
         kl = torch.empty((), dtype=torch.float32, device=x.device) if cfg[1] else None
         self._split_now = self._split(x)
         self._last_masks = None
         # the layer's KL tail (K5) depends on parameters only: it rides in the GEMM's launch (lbbnn_lrt_gemm_finalize)
         # instead of a launch of its own between the weight pass and the GEMM
-        fin = None
+        fin, hosted_all = None, False
         pre = self._preprep
         if pre is not None and pre["cfg"][:2] == tuple(cfg[:2]) and pre["split"] == self._split_now:
             # K3 / K1 of this call were run by the network for all layers at once (_NetworkBase._preprep_all)
             if self._preflow is not None:
                 fl = self._preflow
                 self._last_masks, self._last_dense_save, self._last_flow_rng = fl["masks"], fl["save"], fl["rng"]
+            sh = pre["shared"]
+            if cfg[1] and sh["fin_all"] is not None and (sh["hosted"] or pre["first"]):
+                # every layer's KL tail rides in the FIRST layer's GEMM launch (one extra workgroup for the network)
+                kl = pre["kl"]
+                if pre["first"]:
+                    fin, sh["hosted"] = sh["fin_all"], True
+                hosted_all = True
         else:
             self._prep(cfg, rng, kl_layer=kl, finalize=not cfg[1])
-        if cfg[1]:
+        if cfg[1] and not hosted_all:
             from . import _lib
             desc = (_lib.LayerDesc * 1)()
-            keep = self._fill_desc(desc[0], cfg, kl)
+            saved["_keep"] = self._fill_desc(desc[0], cfg, kl)         # reshaped noise views: alive past the launch
             fin = (desc, 1, rng.data_ptr() if rng is not None else None, None)
         saved["masks"] = self._last_masks
         std = torch.empty((x.shape[0], self.out_features), dtype=torch.float32, device=x.device) if want_std else None
         out = self._gemm(x, cfg, rng, std_out=std, finalize=fin)
-        if cfg[1]:
-            del keep
         if std is not None:
             saved["std"] = std
         if st is not None and advance:
@@ -967,9 +974,12 @@ class _NetworkBase(nn.Module):
             keep.append(l._fill_desc(descs[i], c, kl))
         _lib.check(_lib.lib().lbbnn_layers_operands(descs, len(layers), rng.data_ptr() if rng is not None else None,
                                                     torch.cuda.current_stream(dev).cuda_stream), "lbbnn_layers_operands")
-        for l, c in zip(layers, cfgs):
-            l._preprep = {"cfg": c, "split": l._split_now}
-        del keep
+        all_kl = all(c[1] for c in cfgs)
+        shared = {"hosted": False, "keep": keep,
+                  "fin_all": (descs, len(layers), rng.data_ptr() if rng is not None else None, None) if all_kl else None}
+        snap = rng.clone() if rng is not None else None
+        for i, (l, c) in enumerate(zip(layers, cfgs)):
+            l._preprep = {"cfg": c, "split": l._split_now, "kl": kls[i], "first": i == 0, "shared": shared, "snap": snap}
 
     def _forward_streams(self, x, sample):
         """Fused no-grad forward: ONE stream, 2 + 3 launches.
