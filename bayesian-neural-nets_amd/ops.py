@@ -85,6 +85,7 @@ class RngState:
     reseeds the in-kernel noise too); the offset is advanced on the device after every layer call.
     """
     _states = {}
+    _requested = None          # (seed, offset) of the last manual_seed(): applies to states created afterwards too
 
     def __init__(self, device: torch.device):
         self.device = device
@@ -92,7 +93,8 @@ class RngState:
         # words 0-1: the live {seed, offset}; words 2-3: the copy a fused forward's later kernels read
         # (lbbnn_layers_operands_snap)
         self.t = torch.zeros(4, dtype=torch.int64, device=device)
-        self.reseed(torch.initial_seed())
+        req = RngState._requested
+        self.reseed(torch.initial_seed(), req[1] if (req is not None and req[0] == torch.initial_seed()) else 0)
 
     def reseed(self, seed: int, offset: int = 0):
         self.seed = int(seed)
@@ -120,6 +122,7 @@ def manual_seed(seed: int, offset: int = 0):
     """Reseed the in-kernel noise of every device that has a state (also done implicitly when
     ``torch.manual_seed`` changes ``torch.initial_seed()``)."""
     torch.manual_seed(seed)
+    RngState._requested = (int(seed), int(offset))
     for st in RngState._states.values():
         st.reseed(seed, offset)
 

@@ -1323,6 +1323,64 @@ def test_vector_backward_overlap_same_gradients(bnn, dev, kind):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("O,I,split,mnf", [(96, 160, True, True), (96, 160, False, True), (50, 77, False, False), (1200, 784, True, True)])
+def test_weight_operands_t_matches_weight_pass_plus_transpose(bnn, dev, O, I, split, mnf):
+    """lbbnn_weight_operands_t ((e_w z)^T | var_w^T from the parameters in one pass) is bit-identical to the path it
+    replaces, lbbnn_weight_pass (fp32 operands) + 2 x lbbnn_transpose_operand, in both operand formats -- compared through
+    the GEMM that consumes them (same operand bits => same product bits)."""
+    from bnn_amd import ops, _lib
+    g = torch.Generator().manual_seed(8)
+    mu = (0.2 * torch.randn(O, I, generator=g)).to(dev)
+    rho = (-4.5 + 0.3 * torch.randn(O, I, generator=g)).to(dev)
+    lam = torch.randn(O, I, generator=g).to(dev)
+    z = (1 + 0.1 * torch.randn(I, generator=g)).to(dev) if mnf else None
+    ld_i = ops.operand_ld(I)
+    e_w, v_w = torch.empty(O, ld_i, device=dev), torch.empty(O, ld_i, device=dev)
+    ops.weight_pass(mu, rho, lam, z_fwd=z, priors=bnn.Priors(), e_w=e_w, var_w=v_w)
+    ref_e = ops.transpose_operand(e_w[:, :I], split=split)
+    ref_v = ops.transpose_operand(v_w[:, :I], split=split)
+    ld = ops.operand_ld(O)
+    e_t, v_t = torch.empty(I, ld, device=dev), torch.empty(I, ld, device=dev)
+    _lib.check(_lib.lib().lbbnn_weight_operands_t(mu.data_ptr(), rho.data_ptr(), lam.data_ptr(), z.data_ptr() if mnf else None,
+                                                  e_t.data_ptr(), v_t.data_ptr(), ld, O, I, ops.F_SPLIT16 if split else 0,
+                                                  torch.cuda.current_stream(dev).cuda_stream), "lbbnn_weight_operands_t")
+    torch.cuda.synchronize()
+    assert torch.equal(e_t.view(torch.int32), ref_e.view(torch.int32))
+    assert torch.equal(v_t.view(torch.int32), ref_v.view(torch.int32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims,B", [((784, 1200, 1200, 10), 4096), ((40, 48, 24, 10), 64), ((64, 16, 16, 10), 32)])
+def test_gemm_hosted_finalize_equals_standalone_finalize(bnn, dev, dims, B):
+    """lbbnn_lrt_gemm_finalize: the KL tail computed by the extra workgroup of a GEMM launch (big-tile kernel, 2-wave
+    small-tile kernel) or, where the kernel cannot host it (O <= 16: skinny kernel), by the fall-back launch, against the
+    stand-alone lbbnn_layers_finalize on the same inputs: per-layer KLs and total (same arithmetic, 1e-6 relative), and
+    the RNG offset advanced exactly once per forward."""
+    from bnn_amd import _lib, ops
+    bnn.manual_seed(31, 4)
+    net = bnn.mnf.BayesianNetwork(dims, 2, z_flow_type="Planar", r_flow_type="Planar").to(dev).train()
+    x = torch.rand(B, dims[0], device=dev)
+    with torch.no_grad():
+        out = net(x, sample=True)
+        kls = [float(l.kl) for l in (net.l1, net.l2, net.l3)]
+        total = float(net.kl())
+        st = ops.RngState.get(dev)
+        assert int(st.t[1]) == 5 and int(st.t[3]) == 4          # live offset advanced once; the snapshot holds the offset used
+        # stand-alone finalize on the buffers the forward left behind (K1 outputs, scal), reading the snapshot
+        layers = [net.l1, net.l2, net.l3]
+        descs = (_lib.LayerDesc * 3)()
+        ref = torch.empty(4, device=dev)
+        keep = [l._fill_desc(descs[i], (True, True, i < 2), ref[i]) for i, l in enumerate(layers)]
+        _lib.check(_lib.lib().lbbnn_layers_finalize(descs, 3, st.t[2:4].data_ptr(), 0, ref[3:].data_ptr(),
+                                                    torch.cuda.current_stream(dev).cuda_stream), "lbbnn_layers_finalize")
+        torch.cuda.synchronize()
+        del keep
+    for a, b in zip(kls + [total], ref.tolist()):
+        assert abs(a - b) <= 1e-6 * abs(b), (kls, total, ref.tolist())
+    assert torch.isfinite(out).all()
+
+
+@pytest.mark.gpu
 def test_gemm_random_shape_sweep():
     """tools/gemm_fuzz.py: 40 random (B, I, O) shapes through K1 + the dual-moment GEMM in both precisions against fp64
     (tails in every dimension, clamped rows, split eligibility boundaries)."""
