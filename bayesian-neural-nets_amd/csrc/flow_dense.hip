@@ -168,19 +168,22 @@ __global__ __launch_bounds__(NTC) void dense_stage_c_kernel(const StageBatch bt,
     partial_a_load(a.nx, path, row0, a.I, pr);
     if (rnvp && use_lds) {
         const int HH = H * H;
-        // explicit batches of 24 loads per thread before the first LDS write: left as a plain copy loop the compiler
-        // waited for each load (or small group) before issuing the next, 22 x 3 memory round trips per workgroup
+        // ALL loads of the three matrices (up to 3 x 24 per thread) are requested before the first LDS write: as a plain
+        // copy loop the compiler waited for each load (or small group) before issuing the next, and even one batch per
+        // matrix cost three memory round trips instead of one.  (H > 78: further rounds of the same shape.)
         constexpr int NB = 24;
+        for (int base = tid; base < HH; base += NTC * NB) {
+            float v[3][NB];
 #pragma unroll
-        for (int l = 0; l < 3; ++l) {
-            const float* __restrict__ wg = a.tr.w_mid[l];
-            for (int base = tid; base < HH; base += NTC * NB) {
-                float v[NB];
+            for (int l = 0; l < 3; ++l) {
+                const float* __restrict__ wg = a.tr.w_mid[l];
 #pragma unroll
-                for (int j = 0; j < NB; ++j) { const int e = base + j * NTC; v[j] = e < HH ? wg[e] : 0.f; }
-#pragma unroll
-                for (int j = 0; j < NB; ++j) { const int e = base + j * NTC; if (e < HH) wl[l * HH + e] = v[j]; }
+                for (int j = 0; j < NB; ++j) { const int e = base + j * NTC; v[l][j] = e < HH ? wg[e] : 0.f; }
             }
+#pragma unroll
+            for (int l = 0; l < 3; ++l)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) { const int e = base + j * NTC; if (e < HH) wl[l * HH + e] = v[l][j]; }
         }
     }
     float bm[3] = {0.f, 0.f, 0.f};                                               // middle-layer biases: requested with the rest
@@ -194,11 +197,20 @@ __global__ __launch_bounds__(NTC) void dense_stage_c_kernel(const StageBatch bt,
         const float* src = a.Pin + (size_t)path * nwg * HMAX + tid;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         int w = 0;
-        for (; w + 4 <= nwg; w += 4) {
-            const float v0 = src[(size_t)w * HMAX], v1 = src[(size_t)(w + 1) * HMAX], v2 = src[(size_t)(w + 2) * HMAX], v3 = src[(size_t)(w + 3) * HMAX];
-            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        for (; w + 16 <= nwg; w += 16) {                                          // 16 loads in flight per trip
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = src[(size_t)(w + q) * HMAX];
+#pragma unroll
+            for (int q = 0; q < 16; q += 4) { a0 += v[q]; a1 += v[q + 1]; a2 += v[q + 2]; a3 += v[q + 3]; }
         }
-        for (; w < nwg; ++w) a0 += src[(size_t)w * HMAX];
+        {
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = (w + q < nwg) ? src[(size_t)(w + q) * HMAX] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; q += 4) { a0 += v[q]; a1 += v[q + 1]; a2 += v[q + 2]; a3 += v[q + 3]; }
+        }
         const float v = ((a0 + a1) + (a2 + a3)) + a.tr.b_in[tid];
         const float h1 = rnvp ? (v >= 0.f ? v : 0.1f * v) : tanhf(v);
         hs[0][tid] = h1;
