@@ -15,13 +15,13 @@ inline size_t piggy_lds_bytes(const FinalizePiggy& p) {
     int mx = 0;
     for (int i = 0; i < p.n; ++i)
         if (p.active[i]) { const int v = piggy_layer_floats(p.l[i].O, p.l[i].I, p.l[i].scal != nullptr); mx = v > mx ? v : mx; }
-    return (size_t)mx * sizeof(float) + 3 * 4 * sizeof(double) + LBBNN_MAX_LAYERS * sizeof(float) + 16;
+    return (size_t)mx * sizeof(float) + 3 * 8 * sizeof(double) + LBBNN_MAX_LAYERS * sizeof(float) + 16;
 }
 
 // blockDim.x == NW * 64 (NW = 2 or 4 waves); every thread of the workgroup must call it
 template <int NW>
 __device__ __forceinline__ void kl_finalize_piggy(const LBBNN_CONST_AS FinalizePiggy& A, float* sm) {
-    static_assert(NW >= 1 && NW <= 4, "scratch holds 4 partials per sum");
+    static_assert(NW >= 1 && NW <= 8, "scratch holds 8 partials per sum");
     constexpr int NT = NW * 64;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     float total = 0.f;
@@ -69,13 +69,13 @@ __device__ __forceinline__ void kl_finalize_piggy(const LBBNN_CONST_AS FinalizeP
             }
         }
         s_rows = wave_sum(s_rows); s_bias = wave_sum(s_bias); s_act = wave_sum(s_act);
-        if (t < 12) scr[t] = 0.0;                                 // (waves beyond NW contribute nothing)
+        if (t < 24) scr[t] = 0.0;                                 // (slots of waves beyond NW stay zero)
         __syncthreads();
-        if (lane == 0) { scr[w] = s_rows; scr[4 + w] = s_bias; scr[8 + w] = s_act; }
+        if (lane == 0) { scr[w] = s_rows; scr[8 + w] = s_bias; scr[16 + w] = s_act; }
         __syncthreads();
-        s_rows = (scr[0] + scr[1]) + (scr[2] + scr[3]);
-        s_bias = (scr[4] + scr[5]) + (scr[6] + scr[7]);
-        s_act = (scr[8] + scr[9]) + (scr[10] + scr[11]);
+        s_rows = ((scr[0] + scr[1]) + (scr[2] + scr[3])) + ((scr[4] + scr[5]) + (scr[6] + scr[7]));
+        s_bias = ((scr[8] + scr[9]) + (scr[10] + scr[11])) + ((scr[12] + scr[13]) + (scr[14] + scr[15]));
+        s_act = ((scr[16] + scr[17]) + (scr[18] + scr[19])) + ((scr[20] + scr[21]) + (scr[22] + scr[23]));
         double kl = s_bias + s_rows;
         if (mnf) {
             const float m = (float)(s_act / (double)O);          // outer(b, act).mean(-1) = b * mean(act)   :220-221
@@ -87,11 +87,11 @@ __device__ __forceinline__ void kl_finalize_piggy(const LBBNN_CONST_AS FinalizeP
             }
             s_rb = wave_sum(s_rb);
             __syncthreads();                                     // scr free again
-            if (t < 4) scr[t] = 0.0;
+            if (t < 8) scr[t] = 0.0;
             __syncthreads();
             if (lane == 0) scr[w] = s_rb;
             __syncthreads();
-            s_rb = (scr[0] + scr[1]) + (scr[2] + scr[3]);
+            s_rb = ((scr[0] + scr[1]) + (scr[2] + scr[3])) + ((scr[4] + scr[5]) + (scr[6] + scr[7]));
             kl += (-(double)ldq + (double)lq0) - ((double)ldr + s_rb);                          // :215,:225,:235
         }
         if (t == 0 && a.kl_layer) *a.kl_layer = (float)kl;

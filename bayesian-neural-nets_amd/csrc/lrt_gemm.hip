@@ -498,7 +498,7 @@ constexpr int BKS = 32;
 __device__ __forceinline__ int swzx(int r) { return (((r >> 1) & 3) << 1) | ((r >> 3) & 1); }
 
 template <int TO, int TB, int WB, bool MEAN_ONLY>
-__global__ __launch_bounds__(WB * 64, (TB * TO > 10) ? 1 : 2) void lrt_gemm_bf16x3_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(WB * 64, (TB * TO > 10) ? 1 : (WB == 8 ? 4 : 2)) void lrt_gemm_bf16x3_kernel(const GemmArgs a) {
     constexpr int BN = TO * 16, BM = TB * WB * 16;
     constexpr int NWR = MEAN_ONLY ? 1 : 2;               // weight regions: e_w (, var_w); a row = [hi 64 B | lo 64 B]
     constexpr int XB = BM * 128;                         // bytes of the X region
@@ -875,6 +875,9 @@ int launch_split(GemmArgs& a, bool mean_only, hipStream_t s, bool* hosted) {
     const long blocks_big = (long)((a.O + 79) / 80) * ((a.B + 127) / 128) * nz;
 #ifdef LAB_GEMM_542         // tools/lab experiment: the same 128x80 tile computed by TWO waves of 64 rows each
     if (blocks_big >= 256 && a.B >= 96) return launch_split_cfg<5, 4, 2>(a, mean_only, s, hosted);
+#endif
+#ifdef LAB_GEMM_518         // tools/lab experiment: ... by EIGHT waves of 16 rows each (4 waves per SIMD at 2 workgroups per CU)
+    if (blocks_big >= 256 && a.B >= 96) return launch_split_cfg<5, 1, 8>(a, mean_only, s, hosted);
 #endif
     if (blocks_big >= 256 && a.B >= 96) return launch_split_cfg<5, 2, 4>(a, mean_only, s, hosted);
     return launch_split_cfg<5, 1, 2>(a, mean_only, s, hosted);
