@@ -92,7 +92,7 @@ class DenseLayer(ctypes.Structure):
     """lbbnn_dense_layer_t"""
     _fields_ = [("q0_mean", c_p), ("q0_log_var", c_p), ("zt", ctypes.POINTER(DenseTransform)), ("rt", ctypes.POINTER(DenseTransform)),
                 ("eps_fwd", c_p), ("eps_kl", c_p), ("z_fwd", c_p), ("z_kl", c_p), ("scal", c_p), ("work", c_p),
-                ("Tz", c_i), ("Tr", c_i), ("I", c_i), ("want_kl", c_i), ("layer_id", c_u32), ("save", c_p)]
+                ("Tz", c_i), ("Tr", c_i), ("I", c_i), ("want_kl", c_i), ("layer_id", c_u32), ("save", c_p), ("draw_masks", c_i)]
 
 
 class DenseGrad(ctypes.Structure):

@@ -45,6 +45,20 @@ __device__ __forceinline__ void partial_a_load(const LBBNN_CONST_AS NextA& nx, i
     for (int jj = 0; jj < RJ; ++jj) { const int j = wv + 4 * jj; if (j < H) r.w[jj] = nx.w_in[(size_t)j * I + i]; }
 }
 
+// the same without reading the mask from memory (the caller supplies r.m)
+__device__ __forceinline__ void partial_a_load_nomask(const LBBNN_CONST_AS NextA& nx, int path, int row0, int I, PartialRegs& r) {
+    r.on = nx.w_in && path >= nx.path_lo && path < nx.path_lo + nx.npaths;            // uniform
+    r.m = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < RJ; ++jj) r.w[jj] = 0.f;
+    if (!r.on) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, H = nx.hidden;
+    const int i = row0 + lane;
+    if (i >= I) return;
+#pragma unroll
+    for (int jj = 0; jj < RJ; ++jj) { const int j = wv + 4 * jj; if (j < H) r.w[jj] = nx.w_in[(size_t)j * I + i]; }
+}
+
 // znew: LDS, the new z of this workgroup's CB rows (lane = row; 0 past the end of the vector)
 __device__ __forceinline__ void partial_a_reduce(const LBBNN_CONST_AS NextA& nx, int path, const float* znew, int nwg, const PartialRegs& r) {
     if (!r.on) return;
@@ -65,6 +79,10 @@ struct InitArgs {
     float* z[2]; float* lq0_part;   // per-workgroup partials of log_q0 (KL path)
     NextA nx;
     int I; uint32_t layer; int npaths;
+    // draw_masks: mask vectors to fill -- [0] z flow / forward call, [1] z flow / KL call, [2] r flow; Tm[k] of them each
+    float* mk[3][LBBNN_MAX_FLOW_T];
+    int Tm[3];
+    int draw, nx_word;              // nx_word: which of the three words holds the mask partial_a needs on path 1 (1 or 2)
 };
 
 // z0 = q0_mean + exp(q0_log_var)^.5 * eps  (LBBNN-GP-MF-MNF.py:183-185) for both paths; log_q0 partials (:213-214);
@@ -78,7 +96,26 @@ __global__ __launch_bounds__(NTC) void dense_init_kernel(const InitBatch bt) {
     if (blockIdx.x * CB >= a.I) return;                                             // grid sized for the widest layer
     const int row0 = blockIdx.x * CB, tid = threadIdx.x;
     PartialRegs pr;
-    partial_a_load(a.nx, path, row0, a.I, pr);
+    if (a.draw) {
+        // Bernoulli(0.5) masks from Philox: one call gives this row's bit for every transform (every wave needs its own
+        // lane's bits for the partial below; wave 0 also stores them for the later launches and the backward)
+        const int i = row0 + (tid & 63);
+        const Philox4 b = philox_bits4(a.rng[0], a.rng[1], LBBNN_STREAM_MASK * 64u + a.layer, (uint64_t)i, 0u);
+        if (tid < CB && i < a.I) {
+            if (path == 0) {
+                for (int t = 0; t < a.Tm[0]; ++t) a.mk[0][t][i] = (float)((b.x >> t) & 1u);
+            } else {
+                for (int t = 0; t < a.Tm[1]; ++t) a.mk[1][t][i] = (float)((b.y >> t) & 1u);
+                for (int t = 0; t < a.Tm[2]; ++t) a.mk[2][t][i] = (float)((b.z >> t) & 1u);
+            }
+        }
+        // the first transform's mask for partial_a: bit 0 of this path's word (not yet in memory)
+        partial_a_load_nomask(a.nx, path, row0, a.I, pr);
+        const uint32_t w0 = path == 0 ? b.x : (a.nx_word == 2 ? b.z : b.y);
+        pr.m = (pr.on && i < a.I) ? (float)(w0 & 1u) : 0.f;
+    } else {
+        partial_a_load(a.nx, path, row0, a.I, pr);
+    }
     if (tid < CB) {                                                                 // wave 0: one row per lane
         const int i = row0 + tid;
         float lq = 0.f, z0 = 0.f;
@@ -341,6 +378,7 @@ static int dense_flows_impl(const lbbnn_dense_layer_t* L, int n, const uint64_t*
         if (d.Tz != Tz || d.Tr != Tr || (d.want_kl != 0) != (want_kl != 0)) return LBBNN_E_SHAPE;
         if (d.want_kl && !d.z_kl) return LBBNN_E_NULL;
         if ((!d.eps_fwd || (d.want_kl && !d.eps_kl)) && !rng) return LBBNN_E_NOISE;
+        if (d.draw_masks && !rng) return LBBNN_E_NOISE;
         if ((d.Tz && !d.zt) || (d.want_kl && d.Tr && !d.rt)) return LBBNN_E_NULL;
         for (int t = 0; t < d.Tz; ++t) { if (!transform_ok(d.zt[t], true, d.want_kl != 0)) return LBBNN_E_NULL; maxH = d.zt[t].hidden > maxH ? d.zt[t].hidden : maxH; }
         if (d.want_kl) for (int t = 0; t < d.Tr; ++t) { if (!transform_ok(d.rt[t], false, true)) return LBBNN_E_NULL; maxH = d.rt[t].hidden > maxH ? d.rt[t].hidden : maxH; }
@@ -379,6 +417,13 @@ static int dense_flows_impl(const lbbnn_dense_layer_t* L, int n, const uint64_t*
         ia.q0_mean = d.q0_mean; ia.q0_log_var = d.q0_log_var; ia.eps[0] = d.eps_fwd; ia.eps[1] = d.eps_kl; ia.rng = rng;
         ia.z[0] = d.save ? b.ZF : d.z_fwd; ia.z[1] = d.save ? b.ZK : b.zbuf1; ia.lq0_part = b.lq0; ia.I = d.I; ia.layer = d.layer_id & 63u; ia.npaths = npaths;
         ia.nx = next_of(d, b, 0);
+        ia.draw = d.draw_masks ? 1 : 0;
+        ia.Tm[0] = Tz; ia.Tm[1] = want_kl ? Tz : 0; ia.Tm[2] = want_kl ? Tr : 0;
+        ia.nx_word = Tz > 0 ? 1 : 2;
+        if (ia.draw) {
+            for (int t = 0; t < Tz; ++t) { ia.mk[0][t] = const_cast<float*>(d.zt[t].mask_fwd); ia.mk[1][t] = const_cast<float*>(d.zt[t].mask_kl); }
+            for (int t = 0; t < ia.Tm[2]; ++t) ia.mk[2][t] = const_cast<float*>(d.rt[t].mask_kl);
+        }
     }
     hipLaunchKernelGGL(dense_init_kernel, dim3(gblk, npaths, n), dim3(NTC), 0, s, ib);
 

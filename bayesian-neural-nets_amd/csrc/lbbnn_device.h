@@ -163,4 +163,11 @@ __device__ __forceinline__ void philox_normal4(uint64_t seed, uint64_t offset, u
     out[0] = ra * ca; out[1] = ra * sa; out[2] = rb * cb; out[3] = rb * sb;
 }
 
+// 128 raw bits for counter (ctr0, ctr1) of stream `stream` (same keying as philox_normal4): Bernoulli(0.5) masks.
+__device__ __forceinline__ Philox4 philox_bits4(uint64_t seed, uint64_t offset, uint32_t stream, uint64_t ctr0, uint32_t ctr1) {
+    const uint32_t k0 = (uint32_t)seed ^ ((uint32_t)offset * 0x9E3779B9u);
+    const uint32_t k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(offset >> 32) ^ ((uint32_t)offset >> 7);
+    return philox4x32_10((uint32_t)ctr0, (uint32_t)(ctr0 >> 32), ctr1, stream, k0, k1);
+}
+
 }  // namespace lbbnn

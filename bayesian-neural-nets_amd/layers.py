@@ -34,6 +34,9 @@ import os as _os
 # LBBNN_DENSE_TORCH_BWD=1: differentiate the dense (RNVP / MNF-type) flows with torch autograd on the GPU vectors, as
 # before lbbnn_mnf_flow_dense_backward existed (kept for A/B timing and as a second opinion in the tests)
 _DENSE_HIP_BWD = _os.environ.get("LBBNN_DENSE_TORCH_BWD", "0") != "1"
+# LBBNN_TORCH_MASKS=1: draw the Bernoulli masks of the dense flows with torch's generator (one bernoulli_ launch per
+# forward) instead of in the flow kernels from the layer's Philox state
+_MASKS_IN_KERNEL = _os.environ.get("LBBNN_TORCH_MASKS", "0") != "1"
 
 # Optional overlap of the vector-sized backward chains (V2 / lbbnn_mnf_flow_dense_backward: latency-bound, a handful of
 # workgroups, feeding nothing but the optimizer) with the backward GEMMs of the other layers: they are issued on a side
@@ -617,14 +620,18 @@ class MNFBayesianLinear(_BayesLinearBase):
 
         Tr = len(self.r_flow.transforms)
         pool = []
+        explicit = any(k in noise for k in ("zmask", "zmask2", "rmask"))
+        # no explicit masks and in-kernel noise: the first launch of the flow kernels draws them from Philox
+        # (lbbnn_dense_layer_t::draw_masks) -- the vectors are only allocated here; else ONE torch launch draws all of them
+        in_kernel = (not explicit) and self._uses_rng(cfg) and _MASKS_IN_KERNEL
 
         def draw(n):
-            # all Bernoulli(0.5) masks this call needs come from ONE device launch (2T + Tr rows, or the rows a network
-            # drew for all of its layers at once: _mask_pool), not one per mask
             if not pool:
                 if self._mask_pool is not None:
                     pool.extend(self._mask_pool)
                     self._mask_pool = None
+                elif in_kernel:
+                    pool.extend(torch.empty(2 * T + Tr, I, device=dev).unbind(0))
                 else:
                     pool.extend(torch.empty(2 * T + Tr, I, device=dev).bernoulli_(0.5).unbind(0))
             return [pool.pop() for _ in range(n)]
@@ -633,6 +640,7 @@ class MNFBayesianLinear(_BayesLinearBase):
         if cfg[1]:
             out["zmask2"] = [m.reshape(-1) for m in noise["zmask2"]] if "zmask2" in noise else draw(T)
             out["rmask"] = [m.reshape(-1) for m in noise["rmask"]] if "rmask" in noise else draw(Tr)
+        out["_in_kernel"] = in_kernel
         return out
 
     def sample_z(self, batch_size=1):
@@ -653,13 +661,12 @@ class MNFBayesianLinear(_BayesLinearBase):
         elif family == "chain":
             self._chain_flows(rng, None, None, False)
         else:
-            masks = self._masks((True, False, False), 0)
-            zd, Tz, keep = self.z_flow.dense_descs(masks["zmask"], None)
-            if getattr(ws, "flow_work", None) is None:
-                ws.flow_work = torch.empty(ops.flow_dense_workspace(self.in_features), dtype=torch.float32,
-                                           device=self.q0_mean.device)
-            ops.mnf_flow_dense(self.q0_mean, self.q0_log_var, zd, Tz, None, 0, rng=rng, layer_id=self._layer_id,
-                               z_fwd=ws.z_fwd, scal=ws.scal, work=ws.flow_work, want_kl=False)
+            from . import _lib
+            dl, keep = (_lib.DenseLayer * 1)(), []
+            self._dense_layer_desc(dl[0], (True, False, False), keep)
+            _lib.check(_lib.lib().lbbnn_layers_dense_flows(dl, 1, rng.data_ptr() if rng is not None else None,
+                                                           torch.cuda.current_stream(self.q0_mean.device).cuda_stream),
+                       "lbbnn_layers_dense_flows")
             del keep
 
     def _needed_noise(self, cfg):
@@ -722,6 +729,7 @@ class MNFBayesianLinear(_BayesLinearBase):
         dl.eps_kl = eps_z2.data_ptr() if eps_z2 is not None else None
         dl.z_fwd, dl.z_kl, dl.scal, dl.work = ws.z_fwd.data_ptr(), ws.z_kl.data_ptr(), ws.scal.data_ptr(), ws.flow_work.data_ptr()
         dl.Tz, dl.Tr, dl.I, dl.want_kl, dl.layer_id = Tz, Tr, self.in_features, int(want_kl), self._layer_id
+        dl.draw_masks = int(bool(masks.get("_in_kernel")))
 
     def _uses_rng(self, cfg):
         noise = self.noise or {}
@@ -912,7 +920,9 @@ class _NetworkBase(nn.Module):
         dev = need[0].q0_mean.device
         rows = [2 * len(l.z_flow.transforms) + len(l.r_flow.transforms) for l in need]
         width = max(l.in_features for l in need)
-        allm = torch.empty(sum(rows), width, device=dev).bernoulli_(0.5)
+        allm = torch.empty(sum(rows), width, device=dev)
+        if not (_MASKS_IN_KERNEL and all(l._uses_rng((True, l.training, False)) for l in need)):
+            allm.bernoulli_(0.5)                 # (else the flow kernels fill them: lbbnn_dense_layer_t::draw_masks)
         r0 = 0
         for l, r in zip(need, rows):
             l._mask_pool = [allm[r0 + k, :l.in_features] for k in range(r)]

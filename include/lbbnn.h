@@ -52,6 +52,7 @@ extern "C" {
 #define LBBNN_STREAM_EPS_Z 1
 #define LBBNN_STREAM_EPS_Z2 2
 #define LBBNN_STREAM_EPS_ACT 3
+#define LBBNN_STREAM_MASK 6    /* Bernoulli(0.5) masks of the dense flows (lbbnn_dense_layer_t::draw_masks) */
 
 /* Prior constants of one layer.  The reference keeps them as constant tensors:
  * LBBNN-GP-MF-LRT.py:142-143,151,159-160; LBBNN-GP-MF-MNF.py:145-146,154,162-163. */
@@ -194,6 +195,11 @@ typedef struct lbbnn_dense_layer {
     float *save;                                 /* NULL, or lbbnn_flow_dense_save_size(I, Tz, Tr) floats: the forward keeps the
                                                     input of every transform and the hidden activations of the coupling MLPs
                                                     there for lbbnn_mnf_flow_dense_backward */
+    int draw_masks;                              /* 1: the mask vectors of zt / rt are OUTPUTS of this call -- Bernoulli(0.5)
+                                                    (flows2.py:209,234) from Philox stream LBBNN_STREAM_MASK of `rng`
+                                                    (required), counter = row i: bit t of word 0 / 1 / 2 = transform t of the
+                                                    z flow's forward call / its KL call / the r flow -- written by the first
+                                                    launch; 0: they are inputs */
 } lbbnn_dense_layer_t;
 
 int64_t lbbnn_flow_dense_save_size(int I, int Tz, int Tr);

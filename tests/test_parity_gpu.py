@@ -1381,6 +1381,51 @@ def test_gemm_hosted_finalize_equals_standalone_finalize(bnn, dev, dims, B):
 
 
 @pytest.mark.gpu
+def test_dense_masks_drawn_in_kernel(bnn, dev):
+    """Without explicit masks the first launch of the dense-flow kernels draws the Bernoulli(0.5) masks from the layer's
+    Philox state (lbbnn_dense_layer_t::draw_masks): values in {0,1}, about half ones, different per transform / call,
+    reproducible from (seed, offset), and the forward that used them agrees with the oracle fed the same masks."""
+    from bnn_amd import ops
+    I, O, T, B = 1200, 64, 2, 16
+    torch.manual_seed(2)
+    layer = bnn.mnf.BayesianLinear(I, O, T).to(dev).train()          # RNVP by default
+    x = torch.rand(B, I, device=dev)
+    got = []
+    for rep in range(2):
+        bnn.manual_seed(99, 7)
+        with torch.no_grad():
+            out = layer(x, sample=True)
+        m = layer._last_masks
+        assert m["_in_kernel"]
+        rows = torch.stack([*m["zmask"], *m["zmask2"], *m["rmask"]]).clone()
+        got.append((rows, out.clone(), float(layer.kl)))
+    rows = got[0][0]
+    assert torch.equal(rows, got[1][0]) and torch.equal(got[0][1], got[1][1]) and got[0][2] == got[1][2]
+    assert bool(((rows == 0) | (rows == 1)).all())
+    means = rows.mean(1)
+    assert float((means - 0.5).abs().max()) < 0.06, means            # 1200 draws each: sigma = 0.014
+    for a in range(rows.shape[0]):
+        for b in range(a + 1, rows.shape[0]):
+            assert float((rows[a] != rows[b]).float().mean()) > 0.4   # independent masks
+    # oracle on the same draws: eps from the Philox state the forward used, masks as drawn
+    st = ops.RngState.get(dev)
+    r = st.t.clone(); r[1] = 7
+    L = layer._layer_id
+    noise = {"eps_z": ops.philox_normal(r, ops.STREAM_EPS_Z * 64 + L, 0, I).cpu().reshape(1, I),
+             "eps_z2": ops.philox_normal(r, ops.STREAM_EPS_Z2 * 64 + L, 0, I).cpu().reshape(1, I),
+             "eps_act": ops.philox_normal(r, ops.STREAM_EPS_ACT * 64 + L, 0, O).cpu(),
+             "eps_out": ops.philox_normal(r, ops.STREAM_EPS_OUT * 64 + L, B, O, 0).cpu(),
+             "zmask": [rows[t].cpu() for t in range(T)], "zmask2": [rows[T + t].cpu() for t in range(T)],
+             "rmask": [rows[2 * T + t].cpu() for t in range(T)]}
+    p = {k: v.detach().cpu() for k, v in layer.state_dict().items()}
+    zf = orc.flow_from_state("z_flow", "RNVP", p, T)
+    rf = orc.flow_from_state("r_flow", "RNVP", p, T)
+    o, kl, _ = orc.mnf_forward(x.cpu(), p, zf, rf, noise)
+    assert rel_err(got[0][1].cpu(), o) < TOL
+    assert abs(got[0][2] - float(kl)) / abs(float(kl)) < TOL
+
+
+@pytest.mark.gpu
 def test_gemm_random_shape_sweep():
     """tools/gemm_fuzz.py: 40 random (B, I, O) shapes through K1 + the dual-moment GEMM in both precisions against fp64
     (tails in every dimension, clamped rows, split eligibility boundaries)."""
