@@ -60,8 +60,28 @@ __global__ __launch_bounds__(NT) void mnf_aux_backward_kernel(const float* __res
     if (tid == 0) aux[0] = m;
 }
 
-__global__ __launch_bounds__(NT) void mnf_flow_planar_backward_kernel(const lbbnn_flow_bwd_args_t a, int in_lds) {
-    extern __shared__ __attribute__((aligned(16))) float dyn[];
+// Compact form of lbbnn_flow_bwd_args_t (flows of at most kBatchT transforms) so that the arguments of several layers fit
+// one kernel-argument block: lbbnn_mnf_flow_planar_backward_batch runs one workgroup per layer in a single launch.
+constexpr int kBatchT = 4;
+struct PlanarSet4 { const float* u[kBatchT]; const float* w[kBatchT]; const float* b[kBatchT]; int T; };
+struct PlanarGrad4 { float* u[kBatchT]; float* w[kBatchT]; float* b[kBatchT]; };
+struct FlowBwdCompact {
+    const float *q0_mean, *q0_log_var, *eps_fwd, *eps_kl, *r0_b1, *r0_b2, *aux, *dz_fwd, *dz_kl, *g_kl;
+    const float *bias_mu, *bias_rho, *g_sum, *gv_sum;
+    PlanarSet4 z_flow, r_flow;
+    lbbnn_priors_t priors;
+    float *d_q0_mean, *d_q0_log_var, *d_r0_b1, *d_r0_b2, *d_bias_mu, *d_bias_rho;
+    PlanarGrad4 d_z_flow, d_r_flow;
+    float* work;
+    int O, I;
+    const uint64_t* rng;
+    uint32_t layer_id;
+    int in_lds;
+};
+struct FlowBwdBatch { FlowBwdCompact l[LBBNN_MAX_LAYERS]; };
+
+template <typename A>
+__device__ __forceinline__ void flow_planar_backward_body(const A& a, int in_lds, float* dyn) {
     __shared__ double scratch[3 * NWV];
     __shared__ float thF[LBBNN_MAX_FLOW_T], thK[LBBNN_MAX_FLOW_T], uwZ[LBBNN_MAX_FLOW_T], thR[LBBNN_MAX_FLOW_T], uwR[LBBNN_MAX_FLOW_T];
     __shared__ float s_zb;
@@ -218,6 +238,17 @@ __global__ __launch_bounds__(NT) void mnf_flow_planar_backward_kernel(const lbbn
     }
 }
 
+__global__ __launch_bounds__(NT) void mnf_flow_planar_backward_kernel(const lbbnn_flow_bwd_args_t a, int in_lds) {
+    extern __shared__ __attribute__((aligned(16))) float dyn[];
+    flow_planar_backward_body(a, in_lds, dyn);
+}
+
+__global__ __launch_bounds__(NT) void mnf_flow_planar_backward_batch_kernel(const FlowBwdBatch bt) {
+    extern __shared__ __attribute__((aligned(16))) float dyn[];
+    const LBBNN_CONST_AS FlowBwdCompact& a = kernarg_as<FlowBwdBatch>()->l[blockIdx.x];
+    flow_planar_backward_body(a, a.in_lds, dyn);
+}
+
 }  // namespace
 
 extern "C" int lbbnn_mnf_aux_backward(const float* act_mu, const float* act_var, const float* eps_act, const float* r0_b1,
@@ -260,5 +291,55 @@ extern "C" int lbbnn_mnf_flow_planar_backward(const lbbnn_flow_bwd_args_t* p, vo
     }
     hipLaunchKernelGGL(mnf_flow_planar_backward_kernel, dim3(1), dim3(NT), in_lds ? bytes : 0, static_cast<hipStream_t>(stream),
                        a, in_lds);
+    return (int)hipGetLastError();
+}
+
+// V2 of up to LBBNN_MAX_LAYERS layers as ONE launch (one workgroup per layer): the chains are latency-bound and independent,
+// so n of them take the time of one.  Every flow must have at most 4 transforms (LBBNN_E_SHAPE otherwise: call the
+// single-layer entry point per layer).
+extern "C" int lbbnn_mnf_flow_planar_backward_batch(const lbbnn_flow_bwd_args_t* args, int n, void* stream) {
+    if (!args) return LBBNN_E_NULL;
+    if (n <= 0 || n > LBBNN_MAX_LAYERS) return LBBNN_E_SHAPE;
+    FlowBwdBatch bt{};
+    size_t dyn_bytes = 0;
+    for (int k = 0; k < n; ++k) {
+        const lbbnn_flow_bwd_args_t& a = args[k];
+        if (!a.eps_fwd && !a.rng) return LBBNN_E_NOISE;
+        if (!a.q0_mean || !a.q0_log_var || !a.bias_mu || !a.bias_rho || !a.g_sum || !a.work ||
+            !a.d_q0_mean || !a.d_q0_log_var || !a.d_r0_b1 || !a.d_r0_b2 || !a.d_bias_mu || !a.d_bias_rho) return LBBNN_E_NULL;
+        if (a.g_kl && ((a.eps_fwd && !a.eps_kl) || !a.r0_b1 || !a.r0_b2 || !a.aux)) return LBBNN_E_NULL;
+        if (a.O <= 0 || a.I <= 0) return LBBNN_E_SHAPE;
+        if (a.z_flow.T < 0 || a.z_flow.T > kBatchT || a.r_flow.T < 0 || a.r_flow.T > kBatchT) return LBBNN_E_SHAPE;
+        FlowBwdCompact& c = bt.l[k];
+        c.q0_mean = a.q0_mean; c.q0_log_var = a.q0_log_var; c.eps_fwd = a.eps_fwd; c.eps_kl = a.eps_kl;
+        c.r0_b1 = a.r0_b1; c.r0_b2 = a.r0_b2; c.aux = a.aux; c.dz_fwd = a.dz_fwd; c.dz_kl = a.dz_kl; c.g_kl = a.g_kl;
+        c.bias_mu = a.bias_mu; c.bias_rho = a.bias_rho; c.g_sum = a.g_sum; c.gv_sum = a.gv_sum;
+        c.z_flow.T = a.z_flow.T; c.r_flow.T = a.r_flow.T;
+        for (int t = 0; t < a.z_flow.T; ++t) {
+            if (!a.z_flow.u[t] || !a.z_flow.w[t] || !a.z_flow.b[t] || !a.d_z_flow.u[t] || !a.d_z_flow.w[t] || !a.d_z_flow.b[t]) return LBBNN_E_NULL;
+            c.z_flow.u[t] = a.z_flow.u[t]; c.z_flow.w[t] = a.z_flow.w[t]; c.z_flow.b[t] = a.z_flow.b[t];
+            c.d_z_flow.u[t] = a.d_z_flow.u[t]; c.d_z_flow.w[t] = a.d_z_flow.w[t]; c.d_z_flow.b[t] = a.d_z_flow.b[t];
+        }
+        for (int t = 0; t < a.r_flow.T; ++t) {
+            if (!a.r_flow.u[t] || !a.r_flow.w[t] || !a.r_flow.b[t] || !a.d_r_flow.u[t] || !a.d_r_flow.w[t] || !a.d_r_flow.b[t]) return LBBNN_E_NULL;
+            c.r_flow.u[t] = a.r_flow.u[t]; c.r_flow.w[t] = a.r_flow.w[t]; c.r_flow.b[t] = a.r_flow.b[t];
+            c.d_r_flow.u[t] = a.d_r_flow.u[t]; c.d_r_flow.w[t] = a.d_r_flow.w[t]; c.d_r_flow.b[t] = a.d_r_flow.b[t];
+        }
+        c.priors = a.priors;
+        c.d_q0_mean = a.d_q0_mean; c.d_q0_log_var = a.d_q0_log_var; c.d_r0_b1 = a.d_r0_b1; c.d_r0_b2 = a.d_r0_b2;
+        c.d_bias_mu = a.d_bias_mu; c.d_bias_rho = a.d_bias_rho; c.work = a.work; c.O = a.O; c.I = a.I;
+        c.rng = a.rng; c.layer_id = a.layer_id;
+        const size_t bytes = (size_t)lbbnn_mnf_flow_backward_workspace(a.I, a.z_flow.T, a.r_flow.T) * sizeof(float);
+        c.in_lds = bytes <= 144 * 1024 ? 1 : 0;
+        if (c.in_lds && bytes > dyn_bytes) dyn_bytes = bytes;
+    }
+    static size_t raised = 0;
+    if (dyn_bytes > 64 * 1024 && dyn_bytes > raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mnf_flow_planar_backward_batch_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes);
+        if (e != hipSuccess) return (int)e;
+        raised = dyn_bytes;
+    }
+    hipLaunchKernelGGL(mnf_flow_planar_backward_batch_kernel, dim3(n), dim3(NT), dyn_bytes, static_cast<hipStream_t>(stream), bt);
     return (int)hipGetLastError();
 }

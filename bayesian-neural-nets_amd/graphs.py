@@ -13,20 +13,19 @@ def make_graphed_train_step(net, optimizer, loss_fn, example_x, example_y, warmu
     """loss_fn(net, x, y) -> scalar loss.  The optimizer must be capture-safe: ``bnn_amd.optim.Adam`` (device-side
     step counter) or ``torch.optim.Adam(capturable=True)``.  The warm-up steps run eagerly first, so optimizer state is
     allocated outside the capture.
-    ``overlap_vector_backward``: the vector-sized backward chains of the MNF layers are captured on a side stream (a
-    parallel branch of the graph) and joined before the optimizer step.  Default (None): env LBBNN_BWD_OVERLAP if set,
-    else on exactly when the net has dense (RNVP / MNF-type) flows -- measured on the headline net: RNVP 1.35 -> 1.28 ms,
-    planar 1.00 -> 1.04 ms (a cross-branch edge of a HIP graph costs more than the 37 us planar chain it hides).
+    ``overlap_vector_backward``: the vector-sized backward chains of the MNF layers are deferred
+    (``layers.vector_backward_overlap``): dense-flow chains are captured on a side stream (a parallel branch of the graph,
+    joined before the optimizer step), planar chains are issued as ONE launch for all layers after the backward pass.
+    Default (None): on, unless env LBBNN_BWD_OVERLAP=0.  Measured on the headline net: RNVP 1.35 -> 1.28 ms (side stream),
+    planar 0.95 -> see DESIGN.md section 9 (batched V2).  The gradients are complete only after the join, which this helper
+    does before ``optimizer.step()``.
     Returns step(x, y) -> loss tensor (a static buffer, overwritten by the next replay)."""
     import contextlib
     import os
     from . import layers
     if overlap_vector_backward is None:
         env = os.environ.get("LBBNN_BWD_OVERLAP")
-        if env is not None:
-            overlap_vector_backward = env == "1"
-        else:
-            overlap_vector_backward = any(getattr(m, "_mnf", False) and m._check_flows() == "dense" for m in net.modules())
+        overlap_vector_backward = env != "0"
     ov = layers.vector_backward_overlap if overlap_vector_backward else contextlib.nullcontext
     dev = example_x.device
     static_x, static_y = example_x.clone(), example_y.clone()

@@ -38,12 +38,13 @@ _DENSE_HIP_BWD = _os.environ.get("LBBNN_DENSE_TORCH_BWD", "0") != "1"
 # forward) instead of in the flow kernels from the layer's Philox state
 _MASKS_IN_KERNEL = _os.environ.get("LBBNN_TORCH_MASKS", "0") != "1"
 
-# Optional overlap of the vector-sized backward chains (V2 / lbbnn_mnf_flow_dense_backward: latency-bound, a handful of
-# workgroups, feeding nothing but the optimizer) with the backward GEMMs of the other layers: they are issued on a side
-# stream forked after K1b.  OFF unless a caller that also JOINS before the optimizer step turns it on
+# Optional deferral of the vector-sized backward chains (V2 / lbbnn_mnf_flow_dense_backward: latency-bound, a handful of
+# workgroups, feeding nothing but the optimizer).  Dense-flow chains are issued on a side stream forked after K1b and
+# overlap the backward GEMMs of the other layers; planar chains (one workgroup each) are collected and issued as ONE
+# launch for all layers when the backward pass is over.  OFF unless a caller that also JOINS before the optimizer step turns it on
 # (graphs.make_graphed_train_step, or `with layers.vector_backward_overlap(): loss.backward()`): the gradients such a
 # backward returns are only complete after join_vector_backward().
-_OVERLAP = {"on": False, "streams": {}, "pending": []}
+_OVERLAP = {"on": False, "streams": {}, "pending": [], "planar": []}
 
 
 def _side_stream(dev):
@@ -56,7 +57,10 @@ def _side_stream(dev):
 
 
 def join_vector_backward():
-    """Make the current stream wait for the side-stream backward chains issued so far (no-op if there are none)."""
+    """Issue the deferred planar chains (ONE launch for all layers: lbbnn_mnf_flow_planar_backward_batch) and make the
+    current stream wait for the side-stream dense chains issued so far (no-op if there are none)."""
+    if _OVERLAP["planar"]:
+        ops.mnf_flow_planar_backward_flush(_OVERLAP["planar"])
     if not _OVERLAP["pending"]:
         return
     for dev in {t.device for grp in _OVERLAP["pending"] for t in grp if t is not None}:
@@ -78,12 +82,21 @@ class vector_backward_overlap:
         return False
 
 
+def _deferral_ok(layer):
+    """Deferred / side-stream chains write their outputs AFTER the backward function has returned them, so autograd must
+    adopt those tensors rather than read them: the parameters' .grad must be None (zero_grad(set_to_none=True)) and the
+    backward must not be building a graph.  Otherwise the chains run in place, as without the context manager."""
+    if not _OVERLAP["on"] or torch.is_grad_enabled():
+        return False
+    return all(p.grad is None for p in layer._param_list()[3:])
+
+
 class _SideSection:
     """Issue the enclosed launches on the side stream (after everything issued so far on the current one) and keep the
     listed input tensors alive until the join -- or do nothing when the overlap is off."""
 
-    def __init__(self, dev, keep):
-        self.on = _OVERLAP["on"]
+    def __init__(self, dev, keep, on=True):
+        self.on = _OVERLAP["on"] and on
         self.dev, self.keep, self.cm = dev, keep, None
 
     def __enter__(self):
@@ -237,12 +250,11 @@ class _BayesLinearFn(torch.autograd.Function):
             zp, rp = layer._planar_params_from(params)
             e1 = None if in_kernel else noise["eps_z"].contiguous()
             e2 = noise["eps_z2"].contiguous() if (want_kl and not in_kernel) else None
-            with _SideSection(x.device, (aux, dz_k, dz2, g_kl, g_sum, gv_sum, rng_snap, e1, e2)):
-                G = ops.mnf_flow_planar_backward(
-                    P["q0_mean"], P["q0_log_var"], zp, rp, eps_fwd=e1, eps_kl=e2,
-                    rng=rng_snap, layer_id=layer._layer_id, r0_b1=P["r0_b1"], r0_b2=P["r0_b2"], aux=aux,
-                    dz_fwd=dz_k, dz_kl=dz2, g_kl=g_kl, bias_mu=P["bias_mu"], bias_rho=P["bias_rho"], g_sum=g_sum,
-                    gv_sum=gv_sum, priors=layer.priors)
+            G = ops.mnf_flow_planar_backward(
+                P["q0_mean"], P["q0_log_var"], zp, rp, eps_fwd=e1, eps_kl=e2,
+                rng=rng_snap, layer_id=layer._layer_id, r0_b1=P["r0_b1"], r0_b2=P["r0_b2"], aux=aux,
+                dz_fwd=dz_k, dz_kl=dz2, g_kl=g_kl, bias_mu=P["bias_mu"], bias_rho=P["bias_rho"], g_sum=g_sum,
+                gv_sum=gv_sum, priors=layer.priors, defer=_OVERLAP["planar"] if _deferral_ok(layer) else None)
             G["r0_c"] = dr0c if dr0c is not None else torch.zeros_like(P["q0_mean"])
             vgrads = [G[n] for n in layer._vec_names]
             for key in ("z_flow", "r_flow"):
@@ -260,7 +272,7 @@ class _BayesLinearFn(torch.autograd.Function):
             e2 = noise["eps_z2"].contiguous() if (want_kl and not in_kernel) else None
             rng_f = ctx.saved.get("rng_flow") if ctx.saved.get("rng_flow") is not None else rng_snap
             with _SideSection(x.device, (aux, dz_k, dz2, g_kl, g_sum, gv_sum, rng_f, e1, e2, ctx.saved["dense_save"],
-                                         *k1, *(k2 or ()))):
+                                         *k1, *(k2 or ())), on=_deferral_ok(layer)):
                 G = ops.mnf_flow_dense_backward(
                     P["q0_mean"], P["q0_log_var"], zd, Tz, 0 if layer.z_flow.kind == "RNVP" else 1, rest[:nz],
                     rd, Tr, 0 if layer.r_flow.kind == "RNVP" else 1, rest[nz:], save=ctx.saved["dense_save"],

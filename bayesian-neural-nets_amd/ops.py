@@ -379,9 +379,10 @@ def mnf_aux_backward(act_mu, act_var, eps_act, r0_b1, r0_b2, zb_last, g_kl, rng=
 
 def mnf_flow_planar_backward(q0_mean, q0_log_var, z_params, r_params, *, eps_fwd=None, eps_kl=None, r0_b1=None, r0_b2=None,
                              aux=None, dz_fwd=None, dz_kl=None, g_kl=None, bias_mu, bias_rho, g_sum, gv_sum=None,
-                             priors: Priors, rng=None, layer_id: int = 0):
+                             priors: Priors, rng=None, layer_id: int = 0, defer=None):
     """lbbnn_mnf_flow_planar_backward.  Returns a dict: q0_mean, q0_log_var, r0_b1, r0_b2, bias_mu, bias_rho and
-    z_flow / r_flow = lists of (du, dw, dbias) per transform."""
+    z_flow / r_flow = lists of (du, dw, dbias) per transform.  ``defer``: a list -- the launch is NOT issued; the filled
+    argument struct (with everything it points to kept alive) is appended for mnf_flow_planar_backward_flush."""
     I, O = q0_mean.shape[0], bias_mu.shape[0]
     a = _lib.FlowBwdArgs()
     for name, t in (("q0_mean", q0_mean), ("q0_log_var", q0_log_var), ("eps_fwd", eps_fwd), ("eps_kl", eps_kl),
@@ -406,8 +407,34 @@ def mnf_flow_planar_backward(q0_mean, q0_log_var, z_params, r_params, *, eps_fwd
     work = torch.empty(_lib.lib().lbbnn_mnf_flow_backward_workspace(I, len(z_params), len(r_params)), **f)
     a.work, a.O, a.I = work.data_ptr(), O, I
     a.rng, a.layer_id = (rng.data_ptr() if rng is not None else None), layer_id
+    if defer is not None:
+        keep = (q0_mean, q0_log_var, eps_fwd, eps_kl, r0_b1, r0_b2, aux, dz_fwd, dz_kl, g_kl, bias_mu, bias_rho, g_sum, gv_sum,
+                z_params, r_params, work, rng)
+        # (NOT the output tensors: autograd must hold the only reference so that AccumulateGrad adopts them instead of
+        # copying them -- a copy made before the deferred launch would copy unwritten memory)
+        defer.append((a, keep))
+        return out
     _lib.check(_lib.lib().lbbnn_mnf_flow_planar_backward(ctypes.byref(a), _stream()), "lbbnn_mnf_flow_planar_backward")
     return out
+
+
+def mnf_flow_planar_backward_flush(pending):
+    """Issue the deferred V2 chains: ONE launch per group of up to 4 layers (lbbnn_mnf_flow_planar_backward_batch), or one
+    launch each where a flow has more than 4 transforms."""
+    i = 0
+    while i < len(pending):
+        grp = pending[i:i + 4]
+        arr = (_lib.FlowBwdArgs * len(grp))()
+        for k, (a, _) in enumerate(grp):
+            ctypes.memmove(ctypes.byref(arr[k]), ctypes.byref(a), ctypes.sizeof(_lib.FlowBwdArgs))
+        rc = _lib.lib().lbbnn_mnf_flow_planar_backward_batch(arr, len(grp), _stream())
+        if rc == -2:                                  # LBBNN_E_SHAPE: a flow with more than 4 transforms
+            for a, _ in grp:
+                _lib.check(_lib.lib().lbbnn_mnf_flow_planar_backward(ctypes.byref(a), _stream()), "lbbnn_mnf_flow_planar_backward")
+        else:
+            _lib.check(rc, "lbbnn_mnf_flow_planar_backward_batch")
+        i += 4
+    pending.clear()
 
 
 _DENSE_GRAD_FIELDS = {0: ("w_in", "b_in", ("w_mid", 0), ("b_mid", 0), ("w_mid", 1), ("b_mid", 1), ("w_mid", 2), ("b_mid", 2),

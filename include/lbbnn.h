@@ -456,6 +456,11 @@ int lbbnn_mnf_aux_backward(const float* act_mu, const float* act_var, const floa
                            float* da_mu, float* da_var, float* aux, const uint64_t* rng, uint32_t layer_id, void* stream);
 int64_t lbbnn_mnf_flow_backward_workspace(int I, int Tz, int Tr);
 int lbbnn_mnf_flow_planar_backward(const lbbnn_flow_bwd_args_t* args, void* stream);
+/* The same for n <= LBBNN_MAX_LAYERS layers in ONE launch (one workgroup per layer): the chains are latency-bound and
+ * independent of each other, so a network's worth takes the time of one.  Every flow must have at most 4 transforms
+ * (LBBNN_E_SHAPE otherwise: use the single-layer entry point).  The caller must have all n layers' inputs ready -- i.e. defer
+ * the vector-sized chains to the end of the backward pass (bnn_amd.layers.vector_backward_overlap). */
+int lbbnn_mnf_flow_planar_backward_batch(const lbbnn_flow_bwd_args_t* args, int n, void* stream);
 
 /* lbbnn_flow_chain -- a chain of 1-D (vector) flow transforms on one z (I): planar, radial, Householder,
  * Sylvester (flows2.py:72-95, 48-69, 122-135, 98-120) in any order ('mixed' = 5 x (Householder, Planar),
