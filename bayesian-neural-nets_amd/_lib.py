@@ -163,6 +163,7 @@ SIGNATURES = {
     "lbbnn_flow_dense_save_size": (c_i64, [c_i, c_i, c_i]),
     "lbbnn_mnf_flow_dense_backward_workspace": (c_i64, [c_i]),
     "lbbnn_mnf_flow_dense_backward": (c_i, [ctypes.POINTER(DenseBwdArgs), c_p]),
+    "lbbnn_mnf_flow_dense_backward_batch": (c_i, [ctypes.POINTER(DenseBwdArgs), c_i, c_p]),
     "lbbnn_flow_dense_apply_workspace": (c_i64, [c_i, c_i]),
     "lbbnn_flow_dense_apply": (c_i, [ctypes.POINTER(DenseTransform), c_i, c_i, c_p, c_i, c_p, c_p, c_p]),
     "lbbnn_flow_dense_apply_backward": (c_i, [ctypes.POINTER(DenseTransform), ctypes.POINTER(DenseGrad), c_i, c_i, c_p, c_p,

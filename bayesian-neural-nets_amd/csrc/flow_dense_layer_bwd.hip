@@ -39,9 +39,13 @@ struct StepArgs {
     int npaths, I, nwg;
 };
 
-__global__ __launch_bounds__(256) void dense_bwd_heads_kernel(const StepArgs ka) {
+// every launch handles up to LBBNN_MAX_LAYERS layers (blockIdx.z = layer; grids are sized for the widest one)
+struct StepBatch { StepArgs l[LBBNN_MAX_LAYERS]; };
+
+__global__ __launch_bounds__(256) void dense_bwd_heads_kernel(const StepBatch ka) {
     __shared__ float dpart[2][4][HMAX];
-    const LBBNN_CONST_AS StepArgs& A = *kernarg_as<StepArgs>();
+    const LBBNN_CONST_AS StepArgs& A = kernarg_as<StepBatch>()->l[blockIdx.z];
+    if ((int)blockIdx.x >= A.nwg) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, H = A.tr.hidden, I = A.I;
     const bool c0 = lane < H, c1 = lane + 64 < H;
     const float G = A.g_kl ? A.g_kl[0] : 0.f;
@@ -119,11 +123,11 @@ __global__ __launch_bounds__(256) void dense_bwd_heads_kernel(const StepArgs ka)
 
 constexpr int NTC = 1024;          // chain kernel: 8 slices x HMAX units
 
-__global__ __launch_bounds__(NTC) void dense_bwd_chain_kernel(const StepArgs ka) {
+__global__ __launch_bounds__(NTC) void dense_bwd_chain_kernel(const StepBatch ka) {
     __shared__ float d[2][2][HMAX];        // [buffer][path][unit]
     __shared__ float hh[2][HMAX];          // input activations of the layer being differentiated
     __shared__ float part[8][2][HMAX];     // [slice][path][unit]
-    const LBBNN_CONST_AS StepArgs& A = *kernarg_as<StepArgs>();
+    const LBBNN_CONST_AS StepArgs& A = kernarg_as<StepBatch>()->l[blockIdx.z];
     const int tid = threadIdx.x, H = A.tr.hidden, np = A.npaths;
     const int k = tid & 127, q = tid >> 7;                                     // unit, slice 0..7
     const bool rnvp = A.tr.kind == LBBNN_FLOW_RNVP;
@@ -204,10 +208,11 @@ __global__ __launch_bounds__(NTC) void dense_bwd_chain_kernel(const StepArgs ka)
     if (tid < H) A.gr.b_in[tid] = d[cur][0][tid] + d[cur][1][tid];
 }
 
-__global__ __launch_bounds__(256) void dense_bwd_input_kernel(const StepArgs ka) {
+__global__ __launch_bounds__(256) void dense_bwd_input_kernel(const StepBatch ka) {
     __shared__ float dl[2][HMAX];
     __shared__ float accs[2][4][CW];
-    const LBBNN_CONST_AS StepArgs& A = *kernarg_as<StepArgs>();
+    const LBBNN_CONST_AS StepArgs& A = kernarg_as<StepBatch>()->l[blockIdx.z];
+    if ((int)blockIdx.x * CW >= A.I) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, H = A.tr.hidden, I = A.I;
     dl[tid >> 7][tid & 127] = A.delta0[tid];
     __syncthreads();
@@ -254,8 +259,11 @@ __device__ __forceinline__ double bsum1(double a, double* scratch) {
 
 // bias terms (LBBNN-GP-MF-MNF.py:197-198, 234-236), log_rb gradients (:224-233), and the two running gradients' start:
 // DK = -g_kl * dlog_rb/dz_b (only the last element is non-zero), DF = dz_fwd
-__global__ __launch_bounds__(NT1) void dense_bwd_head_kernel(const HeadArgs a) {
+struct HeadBatch { HeadArgs l[LBBNN_MAX_LAYERS]; };
+
+__global__ __launch_bounds__(NT1) void dense_bwd_head_kernel(const HeadBatch hb) {
     __shared__ double scratch[NWV1];
+    const LBBNN_CONST_AS HeadArgs& a = kernarg_as<HeadBatch>()->l[blockIdx.x];
     const int tid = threadIdx.x, I = a.I, O = a.O;
     const bool has_kl = a.g_kl != nullptr;
     const float G = has_kl ? a.g_kl[0] : 0.f;
@@ -298,7 +306,10 @@ struct TailArgs {
 };
 
 // q0 (LBBNN-GP-MF-MNF.py:183-185, 201-205): dlog_q0/dlog_var = -1/2 exactly, dlog_q0/dmean = 0
-__global__ __launch_bounds__(256) void dense_bwd_tail_kernel(const TailArgs a) {
+struct TailBatch { TailArgs l[LBBNN_MAX_LAYERS]; };
+
+__global__ __launch_bounds__(256) void dense_bwd_tail_kernel(const TailBatch tb) {
+    const LBBNN_CONST_AS TailArgs& a = kernarg_as<TailBatch>()->l[blockIdx.z];
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= a.I) return;
     const bool has_kl = a.g_kl != nullptr;
@@ -345,70 +356,101 @@ extern "C" int64_t lbbnn_mnf_flow_dense_backward_workspace(int I) {
     return 2 * (int64_t)I + 2 * nwg * HMAX + 2 * HMAX;
 }
 
-extern "C" int lbbnn_mnf_flow_dense_backward(const lbbnn_dense_bwd_args_t* pa, void* stream) {
-    if (!pa) return LBBNN_E_NULL;
-    const lbbnn_dense_bwd_args_t& a = *pa;
-    if (!a.eps_fwd && !a.rng) return LBBNN_E_NOISE;
-    if (!a.q0_mean || !a.q0_log_var || !a.bias_mu || !a.bias_rho || !a.g_sum || !a.work || !a.save ||
-        !a.d_q0_mean || !a.d_q0_log_var || !a.d_r0_b1 || !a.d_r0_b2 || !a.d_bias_mu || !a.d_bias_rho) return LBBNN_E_NULL;
-    const bool has_kl = a.g_kl != nullptr;
-    if (has_kl && ((a.eps_fwd && !a.eps_kl) || !a.r0_b1 || !a.r0_b2 || !a.aux)) return LBBNN_E_NULL;
-    if (a.O <= 0 || a.I <= 0) return LBBNN_E_SHAPE;
-    const int Tz = a.Tz, Tr = a.Tr, I = a.I;
-    if (Tz < 0 || Tz > LBBNN_MAX_FLOW_T || Tr < 0 || Tr > LBBNN_MAX_FLOW_T) return LBBNN_E_SHAPE;
-    if ((Tz && (!a.zt || !a.d_zt)) || (Tr && (!a.rt || !a.d_rt))) return LBBNN_E_NULL;
-    for (int t = 0; t < Tz; ++t) if (const int rc = check_pair(a.zt[t], a.d_zt[t], true, has_kl)) return rc;
-    for (int t = 0; t < Tr; ++t) if (const int rc = check_pair(a.rt[t], a.d_rt[t], false, has_kl)) return rc;
+// n layers in the same launches (blockIdx.z = layer); they must agree on Tz, Tr and on having a KL branch
+static int dense_backward_impl(const lbbnn_dense_bwd_args_t* L, int n, void* stream) {
+    if (!L) return LBBNN_E_NULL;
+    if (n <= 0 || n > LBBNN_MAX_LAYERS) return LBBNN_E_SHAPE;
+    const int Tz = L[0].Tz, Tr = L[0].Tr;
+    const bool has_kl = L[0].g_kl != nullptr;
+    int maxI = 0;
+    for (int k = 0; k < n; ++k) {
+        const lbbnn_dense_bwd_args_t& a = L[k];
+        if (!a.eps_fwd && !a.rng) return LBBNN_E_NOISE;
+        if (!a.q0_mean || !a.q0_log_var || !a.bias_mu || !a.bias_rho || !a.g_sum || !a.work || !a.save ||
+            !a.d_q0_mean || !a.d_q0_log_var || !a.d_r0_b1 || !a.d_r0_b2 || !a.d_bias_mu || !a.d_bias_rho) return LBBNN_E_NULL;
+        if ((a.g_kl != nullptr) != has_kl || a.Tz != Tz || a.Tr != Tr) return LBBNN_E_SHAPE;
+        if (has_kl && ((a.eps_fwd && !a.eps_kl) || !a.r0_b1 || !a.r0_b2 || !a.aux)) return LBBNN_E_NULL;
+        if (a.O <= 0 || a.I <= 0) return LBBNN_E_SHAPE;
+        if (Tz < 0 || Tz > LBBNN_MAX_FLOW_T || Tr < 0 || Tr > LBBNN_MAX_FLOW_T) return LBBNN_E_SHAPE;
+        if ((Tz && (!a.zt || !a.d_zt)) || (Tr && (!a.rt || !a.d_rt))) return LBBNN_E_NULL;
+        for (int t = 0; t < Tz; ++t) if (const int rc = check_pair(a.zt[t], a.d_zt[t], true, has_kl)) return rc;
+        for (int t = 0; t < Tr; ++t) if (const int rc = check_pair(a.rt[t], a.d_rt[t], false, has_kl)) return rc;
+        maxI = a.I > maxI ? a.I : maxI;
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int nwg = (I + RW - 1) / RW;
-    float* const DK = a.work;
-    float* const DF = DK + I;
-    float* const dypart = DF + I;
-    float* const delta0 = dypart + (size_t)2 * nwg * HMAX;
-    // the forward's kept intermediates (lbbnn_flow_dense_save_size)
-    const float* const ZF = a.save;
-    const float* const ZK = ZF + (size_t)(Tz + 1) * I;
-    const float* const ZR = ZK + (size_t)(Tz + 1) * I;
-    const float* const HS = ZR + (size_t)Tr * I;
-    auto hs_at = [&](int t, int path) { return HS + ((size_t)t * 2 + path) * 4 * HMAX; };
-    auto r_in = [&](int t) { return t == 0 ? ZK + (size_t)Tz * I : ZR + (size_t)(t - 1) * I; };
+    struct Bufs { float *DK, *DF, *dypart, *delta0; const float *ZF, *ZK, *ZR, *HS; int nwg; } B[LBBNN_MAX_LAYERS];
+    for (int k = 0; k < n; ++k) {
+        const lbbnn_dense_bwd_args_t& a = L[k];
+        Bufs& b = B[k];
+        b.nwg = (a.I + RW - 1) / RW;
+        b.DK = a.work; b.DF = b.DK + a.I; b.dypart = b.DF + a.I; b.delta0 = b.dypart + (size_t)2 * b.nwg * HMAX;
+        // the forward's kept intermediates (lbbnn_flow_dense_save_size)
+        b.ZF = a.save; b.ZK = b.ZF + (size_t)(Tz + 1) * a.I; b.ZR = b.ZK + (size_t)(Tz + 1) * a.I; b.HS = b.ZR + (size_t)Tr * a.I;
+    }
+    auto hs_at = [&](const Bufs& b, int t, int path) { return b.HS + ((size_t)t * 2 + path) * 4 * HMAX; };
+    auto r_in = [&](const Bufs& b, int I, int t) { return t == 0 ? b.ZK + (size_t)Tz * I : b.ZR + (size_t)(t - 1) * I; };
+    const int gwg = (maxI + RW - 1) / RW;
 
-    HeadArgs h{};
-    h.bias_mu = a.bias_mu; h.bias_rho = a.bias_rho; h.g_sum = a.g_sum; h.gv_sum = a.gv_sum; h.g_kl = a.g_kl;
-    h.r0_b1 = a.r0_b1; h.r0_b2 = a.r0_b2; h.aux = a.aux; h.dz_fwd = a.dz_fwd;
-    h.zr_last = r_in(Tr) + (I - 1);
-    h.d_bias_mu = a.d_bias_mu; h.d_bias_rho = a.d_bias_rho; h.d_r0_b1 = a.d_r0_b1; h.d_r0_b2 = a.d_r0_b2; h.DK = DK; h.DF = DF;
-    h.priors = a.priors; h.O = a.O; h.I = I;
-    hipLaunchKernelGGL(dense_bwd_head_kernel, dim3(1), dim3(NT1), 0, s, h);
+    HeadBatch hb{};
+    for (int k = 0; k < n; ++k) {
+        const lbbnn_dense_bwd_args_t& a = L[k];
+        HeadArgs& h = hb.l[k];
+        h.bias_mu = a.bias_mu; h.bias_rho = a.bias_rho; h.g_sum = a.g_sum; h.gv_sum = a.gv_sum; h.g_kl = a.g_kl;
+        h.r0_b1 = a.r0_b1; h.r0_b2 = a.r0_b2; h.aux = a.aux; h.dz_fwd = a.dz_fwd;
+        h.zr_last = r_in(B[k], a.I, Tr) + (a.I - 1);
+        h.d_bias_mu = a.d_bias_mu; h.d_bias_rho = a.d_bias_rho; h.d_r0_b1 = a.d_r0_b1; h.d_r0_b2 = a.d_r0_b2;
+        h.DK = B[k].DK; h.DF = B[k].DF; h.priors = a.priors; h.O = a.O; h.I = a.I;
+    }
+    hipLaunchKernelGGL(dense_bwd_head_kernel, dim3(n), dim3(NT1), 0, s, hb);
 
-    auto step = [&](const StepArgs& sa) {
-        hipLaunchKernelGGL(dense_bwd_heads_kernel, dim3(nwg), dim3(256), 0, s, sa);
-        hipLaunchKernelGGL(dense_bwd_chain_kernel, dim3(1), dim3(NTC), 0, s, sa);
-        hipLaunchKernelGGL(dense_bwd_input_kernel, dim3((I + CW - 1) / CW), dim3(256), 0, s, sa);
+    auto step = [&](const StepBatch& sb) {
+        hipLaunchKernelGGL(dense_bwd_heads_kernel, dim3(gwg, 1, n), dim3(256), 0, s, sb);
+        hipLaunchKernelGGL(dense_bwd_chain_kernel, dim3(1, 1, n), dim3(NTC), 0, s, sb);
+        hipLaunchKernelGGL(dense_bwd_input_kernel, dim3((maxI + CW - 1) / CW, 1, n), dim3(256), 0, s, sb);
     };
     if (has_kl) {
         for (int t = Tr - 1; t >= 0; --t) {                                    // r flow on z2; log_det_r enters the KL as -log_det_r
-            StepArgs sa{};
-            sa.tr = a.rt[t]; sa.gr = a.d_rt[t];
-            sa.p[0] = PathB{r_in(t), a.rt[t].mask_kl, hs_at(Tz + t, 1), DK, nullptr, 1};
-            sa.g_kl = a.g_kl; sa.dypart = dypart; sa.delta0 = delta0; sa.npaths = 1; sa.I = I; sa.nwg = nwg;
-            step(sa);
+            StepBatch sb{};
+            for (int k = 0; k < n; ++k) {
+                const lbbnn_dense_bwd_args_t& a = L[k];
+                StepArgs& sa = sb.l[k];
+                sa.tr = a.rt[t]; sa.gr = a.d_rt[t];
+                sa.p[0] = PathB{r_in(B[k], a.I, t), a.rt[t].mask_kl, hs_at(B[k], Tz + t, 1), B[k].DK, nullptr, 1};
+                sa.g_kl = a.g_kl; sa.dypart = B[k].dypart; sa.delta0 = B[k].delta0; sa.npaths = 1; sa.I = a.I; sa.nwg = B[k].nwg;
+            }
+            step(sb);
         }
     } else {
-        for (int t = 0; t < Tr; ++t) zero_grads(a.rt[t], a.d_rt[t], I, s);
+        for (int k = 0; k < n; ++k) for (int t = 0; t < Tr; ++t) zero_grads(L[k].rt[t], L[k].d_rt[t], L[k].I, s);
     }
     for (int t = Tz - 1; t >= 0; --t) {                                        // z flow, both draws; log_q = -log_det_q + log_q0
-        StepArgs sa{};
-        sa.tr = a.zt[t]; sa.gr = a.d_zt[t];
-        sa.p[0] = PathB{ZF + (size_t)t * I, a.zt[t].mask_fwd, hs_at(t, 0), DF, nullptr, 0};
-        sa.p[1] = PathB{ZK + (size_t)t * I, a.zt[t].mask_kl, hs_at(t, 1), DK, (t == Tz - 1) ? a.dz_kl : nullptr, 1};
-        sa.g_kl = a.g_kl; sa.dypart = dypart; sa.delta0 = delta0; sa.npaths = has_kl ? 2 : 1; sa.I = I; sa.nwg = nwg;
-        step(sa);
+        StepBatch sb{};
+        for (int k = 0; k < n; ++k) {
+            const lbbnn_dense_bwd_args_t& a = L[k];
+            StepArgs& sa = sb.l[k];
+            sa.tr = a.zt[t]; sa.gr = a.d_zt[t];
+            sa.p[0] = PathB{B[k].ZF + (size_t)t * a.I, a.zt[t].mask_fwd, hs_at(B[k], t, 0), B[k].DF, nullptr, 0};
+            sa.p[1] = PathB{B[k].ZK + (size_t)t * a.I, a.zt[t].mask_kl, hs_at(B[k], t, 1), B[k].DK, (t == Tz - 1) ? a.dz_kl : nullptr, 1};
+            sa.g_kl = a.g_kl; sa.dypart = B[k].dypart; sa.delta0 = B[k].delta0; sa.npaths = has_kl ? 2 : 1; sa.I = a.I; sa.nwg = B[k].nwg;
+        }
+        step(sb);
     }
-    TailArgs ta{};
-    ta.q0_log_var = a.q0_log_var; ta.eps_fwd = a.eps_fwd; ta.eps_kl = a.eps_kl; ta.DK = DK; ta.DF = DF;
-    ta.dk_add = (Tz == 0 && has_kl) ? a.dz_kl : nullptr; ta.g_kl = a.g_kl;
-    ta.d_q0_mean = a.d_q0_mean; ta.d_q0_log_var = a.d_q0_log_var; ta.rng = a.rng; ta.layer = a.layer_id & 63u; ta.I = I;
-    hipLaunchKernelGGL(dense_bwd_tail_kernel, dim3((I + 255) / 256), dim3(256), 0, s, ta);
+    TailBatch tb{};
+    for (int k = 0; k < n; ++k) {
+        const lbbnn_dense_bwd_args_t& a = L[k];
+        TailArgs& ta = tb.l[k];
+        ta.q0_log_var = a.q0_log_var; ta.eps_fwd = a.eps_fwd; ta.eps_kl = a.eps_kl; ta.DK = B[k].DK; ta.DF = B[k].DF;
+        ta.dk_add = (Tz == 0 && has_kl) ? a.dz_kl : nullptr; ta.g_kl = a.g_kl;
+        ta.d_q0_mean = a.d_q0_mean; ta.d_q0_log_var = a.d_q0_log_var; ta.rng = a.rng; ta.layer = a.layer_id & 63u; ta.I = a.I;
+    }
+    hipLaunchKernelGGL(dense_bwd_tail_kernel, dim3((maxI + 255) / 256, 1, n), dim3(256), 0, s, tb);
     return (int)hipGetLastError();
+}
+
+extern "C" int lbbnn_mnf_flow_dense_backward(const lbbnn_dense_bwd_args_t* args, void* stream) {
+    return dense_backward_impl(args, 1, stream);
+}
+
+extern "C" int lbbnn_mnf_flow_dense_backward_batch(const lbbnn_dense_bwd_args_t* args, int n, void* stream) {
+    return dense_backward_impl(args, n, stream);
 }

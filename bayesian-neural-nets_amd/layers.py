@@ -39,37 +39,25 @@ _DENSE_HIP_BWD = _os.environ.get("LBBNN_DENSE_TORCH_BWD", "0") != "1"
 _MASKS_IN_KERNEL = _os.environ.get("LBBNN_TORCH_MASKS", "0") != "1"
 
 # Optional deferral of the vector-sized backward chains (V2 / lbbnn_mnf_flow_dense_backward: latency-bound, a handful of
-# workgroups, feeding nothing but the optimizer).  Dense-flow chains are issued on a side stream forked after K1b and
-# overlap the backward GEMMs of the other layers; planar chains (one workgroup each) are collected and issued as ONE
-# launch for all layers when the backward pass is over.  OFF unless a caller that also JOINS before the optimizer step turns it on
-# (graphs.make_graphed_train_step, or `with layers.vector_backward_overlap(): loss.backward()`): the gradients such a
-# backward returns are only complete after join_vector_backward().
-_OVERLAP = {"on": False, "streams": {}, "pending": [], "planar": []}
-
-
-def _side_stream(dev):
-    key = (dev.type, dev.index)
-    st = _OVERLAP["streams"].get(key)
-    if st is None:
-        st = torch.cuda.Stream(device=dev)
-        _OVERLAP["streams"][key] = st
-    return st
+# workgroups, feeding nothing but the optimizer): each layer's backward only FILES its chain, and when the backward pass
+# is over all layers' chains are issued together -- one launch for the planar ones
+# (lbbnn_mnf_flow_planar_backward_batch), one set of 2 + 3(Tz+Tr) launches for the dense ones
+# (lbbnn_mnf_flow_dense_backward_batch) instead of one per layer.  OFF unless a caller that also FLUSHES before the
+# optimizer step turns it on (graphs.make_graphed_train_step, or `with layers.vector_backward_overlap(): loss.backward()`):
+# the gradients such a backward returns are only complete after join_vector_backward().
+_OVERLAP = {"on": False, "planar": [], "dense": []}
 
 
 def join_vector_backward():
-    """Issue the deferred planar chains (ONE launch for all layers: lbbnn_mnf_flow_planar_backward_batch) and make the
-    current stream wait for the side-stream dense chains issued so far (no-op if there are none)."""
+    """Issue the deferred vector-sized backward chains of all layers (no-op if there are none)."""
     if _OVERLAP["planar"]:
         ops.mnf_flow_planar_backward_flush(_OVERLAP["planar"])
-    if not _OVERLAP["pending"]:
-        return
-    for dev in {t.device for grp in _OVERLAP["pending"] for t in grp if t is not None}:
-        torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
-    _OVERLAP["pending"].clear()
+    if _OVERLAP["dense"]:
+        ops.mnf_flow_dense_backward_flush(_OVERLAP["dense"])
 
 
 class vector_backward_overlap:
-    """Context manager: backward passes inside run their vector-sized chains on a side stream; joined on exit."""
+    """Context manager: backward passes inside defer their vector-sized chains; issued (batched over layers) on exit."""
 
     def __enter__(self):
         self._was = _OVERLAP["on"]
@@ -83,35 +71,13 @@ class vector_backward_overlap:
 
 
 def _deferral_ok(layer):
-    """Deferred / side-stream chains write their outputs AFTER the backward function has returned them, so autograd must
-    adopt those tensors rather than read them: the parameters' .grad must be None (zero_grad(set_to_none=True)) and the
-    backward must not be building a graph.  Otherwise the chains run in place, as without the context manager."""
+    """Deferred chains write their outputs AFTER the backward function has returned them, so autograd must adopt those
+    tensors rather than read them: the parameters' .grad must be None (zero_grad(set_to_none=True)) and the backward must
+    not be building a graph.  Otherwise the chains run in place, as without the context manager."""
     if not _OVERLAP["on"] or torch.is_grad_enabled():
         return False
     return all(p.grad is None for p in layer._param_list()[3:])
 
-
-class _SideSection:
-    """Issue the enclosed launches on the side stream (after everything issued so far on the current one) and keep the
-    listed input tensors alive until the join -- or do nothing when the overlap is off."""
-
-    def __init__(self, dev, keep, on=True):
-        self.on = _OVERLAP["on"] and on
-        self.dev, self.keep, self.cm = dev, keep, None
-
-    def __enter__(self):
-        if self.on:
-            side = _side_stream(self.dev)
-            side.wait_stream(torch.cuda.current_stream(self.dev))
-            self.cm = torch.cuda.stream(side)
-            self.cm.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        if self.on:
-            self.cm.__exit__(*exc)
-            _OVERLAP["pending"].append(tuple(self.keep))
-        return False
 
 _layer_ids = itertools.count()
 
@@ -271,14 +237,13 @@ class _BayesLinearFn(torch.autograd.Function):
             e1 = None if in_kernel else noise["eps_z"].contiguous()
             e2 = noise["eps_z2"].contiguous() if (want_kl and not in_kernel) else None
             rng_f = ctx.saved.get("rng_flow") if ctx.saved.get("rng_flow") is not None else rng_snap
-            with _SideSection(x.device, (aux, dz_k, dz2, g_kl, g_sum, gv_sum, rng_f, e1, e2, ctx.saved["dense_save"],
-                                         *k1, *(k2 or ())), on=_deferral_ok(layer)):
-                G = ops.mnf_flow_dense_backward(
-                    P["q0_mean"], P["q0_log_var"], zd, Tz, 0 if layer.z_flow.kind == "RNVP" else 1, rest[:nz],
-                    rd, Tr, 0 if layer.r_flow.kind == "RNVP" else 1, rest[nz:], save=ctx.saved["dense_save"],
-                    eps_fwd=e1, eps_kl=e2, rng=rng_f, layer_id=layer._layer_id, r0_b1=P["r0_b1"], r0_b2=P["r0_b2"], aux=aux,
-                    dz_fwd=dz_k, dz_kl=dz2, g_kl=g_kl, bias_mu=P["bias_mu"], bias_rho=P["bias_rho"], g_sum=g_sum,
-                    gv_sum=gv_sum, priors=layer.priors)
+            G = ops.mnf_flow_dense_backward(
+                P["q0_mean"], P["q0_log_var"], zd, Tz, 0 if layer.z_flow.kind == "RNVP" else 1, rest[:nz],
+                rd, Tr, 0 if layer.r_flow.kind == "RNVP" else 1, rest[nz:], save=ctx.saved["dense_save"],
+                eps_fwd=e1, eps_kl=e2, rng=rng_f, layer_id=layer._layer_id, r0_b1=P["r0_b1"], r0_b2=P["r0_b2"], aux=aux,
+                dz_fwd=dz_k, dz_kl=dz2, g_kl=g_kl, bias_mu=P["bias_mu"], bias_rho=P["bias_rho"], g_sum=g_sum,
+                gv_sum=gv_sum, priors=layer.priors, defer=_OVERLAP["dense"] if _deferral_ok(layer) else None,
+                keep=(k1, k2))
             del k1, k2
             G["r0_c"] = dr0c if dr0c is not None else torch.zeros_like(P["q0_mean"])
             if not want_kl:

@@ -460,8 +460,10 @@ def _dense_grad_array(kind_id, params, T):
 
 def mnf_flow_dense_backward(q0_mean, q0_log_var, z_descs, Tz, z_kind, z_params, r_descs, Tr, r_kind, r_params, *, save,
                             eps_fwd=None, eps_kl=None, r0_b1=None, r0_b2=None, aux=None, dz_fwd=None, dz_kl=None, g_kl=None,
-                            bias_mu, bias_rho, g_sum, gv_sum=None, priors: Priors, rng=None, layer_id: int = 0):
-    """lbbnn_mnf_flow_dense_backward.  z_descs / r_descs: the forward's lbbnn_dense_transform_t arrays (same masks);
+                            bias_mu, bias_rho, g_sum, gv_sum=None, priors: Priors, rng=None, layer_id: int = 0, defer=None,
+                            keep=()):
+    """lbbnn_mnf_flow_dense_backward (``defer``: a list -- nothing is launched, the filled argument struct and what it
+    points to are appended for mnf_flow_dense_backward_flush).  z_descs / r_descs: the forward's lbbnn_dense_transform_t arrays (same masks);
     z_params / r_params: the flows' parameter tensors in module order (shapes of the gradients).  Returns a dict:
     q0_mean, q0_log_var, r0_b1, r0_b2, bias_mu, bias_rho and z_flow / r_flow = flat gradient lists in parameter order."""
     I, O = q0_mean.shape[0], bias_mu.shape[0]
@@ -486,8 +488,30 @@ def mnf_flow_dense_backward(q0_mean, q0_log_var, z_descs, Tz, z_kind, z_params, 
     work = torch.empty(_lib.lib().lbbnn_mnf_flow_dense_backward_workspace(I), **f)
     a.work, a.Tz, a.Tr, a.O, a.I = work.data_ptr(), Tz, Tr, O, I
     a.rng, a.layer_id = (rng.data_ptr() if rng is not None else None), layer_id
+    if defer is not None:
+        # (the output tensors are NOT kept here: autograd must hold their only reference, see mnf_flow_planar_backward)
+        alive = (q0_mean, q0_log_var, eps_fwd, eps_kl, r0_b1, r0_b2, aux, dz_fwd, dz_kl, g_kl, bias_mu, bias_rho, g_sum, gv_sum,
+                 save, z_descs, r_descs, z_params, r_params, gz, gr, work, rng, keep)
+        defer.append((a, alive, (Tz, Tr, g_kl is not None)))
+        return out
     _lib.check(_lib.lib().lbbnn_mnf_flow_dense_backward(ctypes.byref(a), _stream()), "lbbnn_mnf_flow_dense_backward")
     return out
+
+
+def mnf_flow_dense_backward_flush(pending):
+    """Issue the deferred dense-flow chains: layers that agree on (Tz, Tr, KL branch) share their launches
+    (lbbnn_mnf_flow_dense_backward_batch, up to 4 layers per call)."""
+    groups = {}
+    for item in pending:
+        groups.setdefault(item[2], []).append(item)
+    for items in groups.values():
+        for i in range(0, len(items), 4):
+            grp = items[i:i + 4]
+            arr = (_lib.DenseBwdArgs * len(grp))()
+            for k, (a, _, _) in enumerate(grp):
+                ctypes.memmove(ctypes.byref(arr[k]), ctypes.byref(a), ctypes.sizeof(_lib.DenseBwdArgs))
+            _lib.check(_lib.lib().lbbnn_mnf_flow_dense_backward_batch(arr, len(grp), _stream()), "lbbnn_mnf_flow_dense_backward_batch")
+    pending.clear()
 
 
 def flow_dense_save_size(I: int, Tz: int, Tr: int) -> int:

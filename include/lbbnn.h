@@ -610,6 +610,10 @@ typedef struct lbbnn_dense_bwd_args {
 
 int64_t lbbnn_mnf_flow_dense_backward_workspace(int I);
 int lbbnn_mnf_flow_dense_backward(const lbbnn_dense_bwd_args_t* args, void* stream);
+/* n <= LBBNN_MAX_LAYERS layers in the SAME 2 + 3*(Tz+Tr) launches (blockIdx.z = layer): the launches are latency-bound, so a
+ * network's worth takes about the time of one layer.  The layers must agree on Tz, Tr and on having a KL branch
+ * (LBBNN_E_SHAPE otherwise), and all of their inputs must be ready: defer the chains to the end of the backward pass. */
+int lbbnn_mnf_flow_dense_backward_batch(const lbbnn_dense_bwd_args_t* args, int n, void* stream);
 
 #ifdef __cplusplus
 }
