@@ -46,6 +46,10 @@ struct GemmArgs {
     int relu, log_softmax;
     int kchunk;              // split-K (bf16x3 kernel only): workgroup z contracts k in [z*kchunk, (z+1)*kchunk), 0 = off
     long long split_stride;  // ... and writes its partial product to out + z*split_stride
+    // lbbnn_lrt_gemm_combine (mean-only): out = comb_add + 2 * comb_x (.) (x . e_w^T), the input-gradient combination
+    // dX = G_m.W_m + 2 x (.) (G_v.W_v) fused into the second product's epilogue; NULL: plain output
+    const float* comb_x; const float* comb_add;
+    int ld_cx, ld_ca;
     // lbbnn_lrt_gemm_finalize: fin.n > 0 => the grid has one extra row of workgroups (blockIdx.y == gridDim.y - 1) whose
     // first workgroup does the KL finalize of the network (kl_piggy.h) while the tiles are computed; the rest of the row exits
     FinalizePiggy fin;
@@ -125,6 +129,18 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& a, const EpiCtx& c, co
         float mean = am[r] + oc.bm[r];
         if (!MEAN_ONLY) { sd[r] = sqrtf(av[r] * oc.vs[r] + oc.bv[r]); mean += sd[r] * e[r]; }
         res[r] = a.relu ? fmaxf(mean, 0.f) : mean;
+    }
+    if (MEAN_ONLY && a.comb_x) {
+        const float* cx = a.comb_x + (size_t)b * a.ld_cx + o;
+        const float* ca = a.comb_add + (size_t)b * a.ld_ca + o;
+        if (c.ovec && ((a.ld_cx | a.ld_ca) & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.comb_x) | reinterpret_cast<uintptr_t>(a.comb_add)) & 15u) == 0) {
+            const float4 vx = *reinterpret_cast<const float4*>(cx), va = *reinterpret_cast<const float4*>(ca);
+            res[0] = va.x + 2.f * vx.x * res[0]; res[1] = va.y + 2.f * vx.y * res[1];
+            res[2] = va.z + 2.f * vx.z * res[2]; res[3] = va.w + 2.f * vx.w * res[3];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (o + r < a.O) res[r] = ca[r] + 2.f * cx[r] * res[r];
+        }
     }
     if (!MEAN_ONLY && a.std_out) {
         float* sp = a.std_out + (size_t)b * a.O + o;
@@ -889,7 +905,8 @@ static int lrt_gemm_impl(const float* x, int ldx, const void* e_w, const void* v
                          const float* bias_mean, const float* bias_var, const float* var_scale,
                          const float* eps, const uint64_t* rng, uint32_t rng_stream, int64_t row_offset,
                          float* out, int ldo, float* std_out, int B, int I, int O, int flags, void* stream, int kchunk = 0,
-                         const FinalizePiggy* fin = nullptr, bool* hosted = nullptr) {
+                         const FinalizePiggy* fin = nullptr, bool* hosted = nullptr,
+                         const float* comb_x = nullptr, int ld_cx = 0, const float* comb_add = nullptr, int ld_ca = 0) {
     if (B == 0 && I > 0 && O > 0) return 0;        // empty batch (torch.mm of 0 rows, LBBNN-GP-MF-LRT.py:172): nothing to do
     if (!x || !e_w || !out) return LBBNN_E_NULL;
     if (B <= 0 || I <= 0 || O <= 0 || ldx < I || ldo < O) return LBBNN_E_SHAPE;
@@ -911,6 +928,7 @@ static int lrt_gemm_impl(const float* x, int ldx, const void* e_w, const void* v
     a.log_softmax = (flags & LBBNN_F_LOG_SOFTMAX) ? 1 : 0;
     a.kchunk = kchunk; a.split_stride = (long long)B * ldo;
     if (fin) a.fin = *fin; else a.fin = FinalizePiggy{};
+    a.comb_x = comb_x; a.comb_add = comb_add; a.ld_cx = ld_cx; a.ld_ca = ld_ca;
 
     const bool xvec = ((I & 3) == 0) && ((ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0);
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -979,6 +997,18 @@ extern "C" int lbbnn_lrt_gemm_finalize(const float* x, int ldx, const void* e_w,
     if (hosted) return 0;
     // this GEMM's kernel cannot host the extra workgroup (small tile configuration, skinny output, LDS): same work, own launch
     return launch_kl_finalize_all(fin.l, fin.active, n, nullptr, 0, kl_total, static_cast<hipStream_t>(stream));
+}
+
+// Mean-only product with the input-gradient combination in its epilogue (include/lbbnn.h)
+extern "C" int lbbnn_lrt_gemm_combine(const float* x, int ldx, const void* w_op, int ld, const float* comb_x, int ld_cx,
+                                      const float* comb_add, int ld_ca, float* out, int ldo, int B, int I, int O, int flags,
+                                      void* stream) {
+    if (!comb_x || !comb_add) return LBBNN_E_NULL;
+    if (ld_cx < O || ld_ca < O) return LBBNN_E_SHAPE;
+    if (flags & ~LBBNN_F_SPLIT16) return LBBNN_E_FLAGS;
+    if (O <= 16) return LBBNN_E_SHAPE;                       // (the skinny kernel has its own epilogue)
+    return lrt_gemm_impl(x, ldx, w_op, nullptr, ld, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0, out, ldo, nullptr,
+                         B, I, O, flags | LBBNN_F_MEAN_ONLY, stream, 0, nullptr, nullptr, comb_x, ld_cx, comb_add, ld_ca);
 }
 
 // Split-K plain product on the bf16x3 kernel: out[z] = x[:, Kz] . w[:, Kz]^T for the k ranges Kz = [z*kchunk, (z+1)*kchunk).

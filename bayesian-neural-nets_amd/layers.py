@@ -195,7 +195,11 @@ class _BayesLinearFn(torch.autograd.Function):
                 w_shape = torch.empty((O, I), device="meta")       # shape carrier for _hip_matmul_nt
                 gx = _hip_matmul_nt(g, None, w_shape, op=e_t)
                 if stochastic:
-                    gx = ops.dx_combine(gx, _hip_matmul_nt(g_v, None, w_shape, op=v_t), x)
+                    if I > 16 and x.stride(1) == 1:
+                        # dX = G_m.W_m + 2 x (.) (G_v.W_v): the combination is the second product's epilogue
+                        gx = ops.lrt_gemm_combine(g_v, v_t, K=O, N=I, comb_x=x, comb_add=gx, split=split_v)
+                    else:
+                        gx = ops.dx_combine(gx, _hip_matmul_nt(g_v, None, w_shape, op=v_t), x)
             else:
                 ws = layer._workspace()
                 bw = ws.backward_operands()
@@ -964,7 +968,11 @@ class _NetworkBase(nn.Module):
         all_kl = all(c[1] for c in cfgs)
         shared = {"hosted": False, "keep": keep,
                   "fin_all": (descs, len(layers), rng.data_ptr() if rng is not None else None, None) if all_kl else None}
-        snap = rng.clone() if rng is not None else None
+        # one Philox snapshot per step for every backward re-draw (the dense pre-flow took it already if it ran)
+        snap = None
+        if rng is not None:
+            pf = layers[0]._preflow
+            snap = pf["rng"] if (pf is not None and pf.get("rng") is not None) else rng.clone()
         for i, (l, c) in enumerate(zip(layers, cfgs)):
             l._preprep = {"cfg": c, "split": l._split_now, "kl": kls[i], "first": i == 0, "shared": shared, "snap": snap}
 

@@ -313,6 +313,20 @@ def lrt_gemm(x, e_w, var_w, *, I: int, O: int, bias_mean=None, bias_var=None, va
     return out
 
 
+def lrt_gemm_combine(a, op, *, K: int, N: int, comb_x, comb_add, split: bool = False):
+    """lbbnn_lrt_gemm_combine: comb_add + 2 * comb_x (.) (a (M,K) @ op^T), op = [N][operand_ld(K)]; writes into comb_add's
+    storage (returned)."""
+    M = a.shape[0]
+    if a.stride(1) != 1:
+        a = a.contiguous()
+    rc = _lib.lib().lbbnn_lrt_gemm_combine(
+        _ptr_rows(a, "a"), a.stride(0), _ptr(op), operand_ld(K), _ptr_rows(comb_x, "comb_x"), comb_x.stride(0),
+        _ptr_rows(comb_add, "comb_add"), comb_add.stride(0), comb_add.data_ptr(), comb_add.stride(0), M, K, N,
+        F_SPLIT16 if split else 0, _stream())
+    _lib.check(rc, "lbbnn_lrt_gemm_combine")
+    return comb_add
+
+
 # ----------------------------------------------------------------------------------------- K3
 def _ptr_array(ts: Sequence[torch.Tensor]):
     arr = (ctypes.c_void_p * max(len(ts), 1))()

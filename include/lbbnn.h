@@ -516,6 +516,13 @@ int64_t lbbnn_output_grad_workspace(int B, int O);
 int lbbnn_output_grad(const lbbnn_outgrad_args_t* args, void* stream);
 /* gx (B,I dense) += 2 * x (B,I; row stride ldx) * gxv (B,I dense): the input gradient of the variance GEMM folded
  * into dX = G_m.W_m + 2 x (.) (G_v.W_v)  (d/dx of (x^2).var_w^T, LBBNN-GP-MF-LRT.py:173). */
+/* out = comb_add + 2 * comb_x (.) (x . w_op^T): the mean-only product of lbbnn_lrt_gemm with lbbnn_dx_combine fused into
+ * its epilogue -- dX = G_m.W_m + 2 x (.) (G_v.W_v) is the second product's output directly (comb_add = G_m.W_m,
+ * comb_x = the layer input).  comb_x / comb_add: (B,O) with row strides ld_cx / ld_ca; out may alias comb_add.
+ * O > 16 (LBBNN_E_SHAPE otherwise); flags: LBBNN_F_SPLIT16 as for lbbnn_lrt_gemm. */
+int lbbnn_lrt_gemm_combine(const float* x, int ldx, const void* w_op, int ld, const float* comb_x, int ld_cx,
+                           const float* comb_add, int ld_ca, float* out, int ldo, int B, int I, int O, int flags,
+                           void* stream);
 int lbbnn_dx_combine(float* gx, const float* gxv, const float* x, int ldx, int B, int I, void* stream);
 
 /* lbbnn_adam_step -- torch.optim.Adam's update (the optimizer of the reference's training scripts,
