@@ -1426,6 +1426,27 @@ def test_dense_masks_drawn_in_kernel(bnn, dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N,split", [(256, 1200, 784, True), (130, 96, 200, False), (64, 40, 33, False), (4096, 1200, 1200, True)])
+def test_gemm_combine_epilogue(bnn, dev, M, K, N, split):
+    """lbbnn_lrt_gemm_combine: add + 2 x (.) (a . w) against fp64, and against the two-step form it replaces
+    (mean-only GEMM, then lbbnn_dx_combine) -- same products, one rounding order apart."""
+    from bnn_amd import ops
+    g = torch.Generator().manual_seed(12)
+    a = torch.randn(M, K, generator=g).to(dev)
+    w = (0.1 * torch.randn(K, N, generator=g)).to(dev)
+    x = torch.rand(M, N, generator=g).to(dev)
+    add = torch.randn(M, N, generator=g).to(dev)
+    ref = add.double() + 2 * x.double() * (a.double() @ w.double())
+    split = split and ops.split_eligible(K, N)
+    op = ops.transpose_operand(w, split=split)
+    two_step = ops.dx_combine(add.clone(), ops.lrt_gemm(a, op, None, I=K, O=N, mean_only=True, split=split), x)
+    fused = ops.lrt_gemm_combine(a, op, K=K, N=N, comb_x=x, comb_add=add.clone(), split=split)
+    tol = 2e-5 if split else 2e-6
+    assert rel_err(fused.double().cpu(), ref.cpu()) < tol
+    assert rel_err(fused.cpu(), two_step.cpu()) < 1e-6
+
+
+@pytest.mark.gpu
 def test_gemm_random_shape_sweep():
     """tools/gemm_fuzz.py: 40 random (B, I, O) shapes through K1 + the dual-moment GEMM in both precisions against fp64
     (tails in every dimension, clamped rows, split eligibility boundaries)."""
