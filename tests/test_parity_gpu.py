@@ -1447,6 +1447,20 @@ def test_gemm_combine_epilogue(bnn, dev, M, K, N, split):
 
 
 @pytest.mark.gpu
+def test_dense_layer_random_shape_sweep():
+    """tools/layer_fuzz.py with FLOW=any: 18 random layers across planar / RNVP / MNF-type flows (unaligned B / I / O down to
+    I = 5, 1-3 transforms, both precisions): output, KL and every gradient of the HIP backward (incl.
+    lbbnn_mnf_flow_dense_backward) against fp64 autograd of the oracle."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FLOW="any")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "layer_fuzz.py"), "7", "18"], capture_output=True, text=True,
+                       timeout=600, cwd=root, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "random layers ok" in r.stdout
+
+
+@pytest.mark.gpu
 def test_gemm_random_shape_sweep():
     """tools/gemm_fuzz.py: 40 random (B, I, O) shapes through K1 + the dual-moment GEMM in both precisions against fp64
     (tails in every dimension, clamped rows, split eligibility boundaries)."""
