@@ -1447,6 +1447,43 @@ def test_gemm_combine_epilogue(bnn, dev, M, K, N, split):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("family", ["lrt", "Planar"])
+def test_network_training_path_equals_per_layer_path(bnn, dev, family):
+    """The training forward of a network (K3 / K1 of all layers in one launch per kind, every KL tail in the first GEMM's
+    launch, one shared RNG offset) against driving the same layers one by one: loss and every gradient bitwise equal."""
+    for prec in ("fp32", "bf16x3"):
+        bnn.set_precision(prec)
+        torch.manual_seed(0)
+        dims = (40, 64, 32, 10)
+        net = (bnn.lrt.BayesianNetwork(dims) if family == "lrt" else
+               bnn.mnf.BayesianNetwork(dims, 2, z_flow_type=family, r_flow_type=family)).to(dev).train()
+        x = torch.rand(48, 40, device=dev)
+        y = torch.randint(0, 10, (48,), device=dev)
+        res = []
+        for mode in ("net", "layers"):
+            bnn.manual_seed(5, 3)
+            net.zero_grad(set_to_none=True)
+            if mode == "net":
+                out, kl = net(x, sample=True), None
+                kl = net.kl()
+            else:
+                h = x
+                for i, l in enumerate((net.l1, net.l2, net.l3)):
+                    l._advance_rng = False
+                    h = l.forward(h, True, _relu=(i < 2))
+                    l._advance_rng = True
+                out = torch.nn.functional.log_softmax(h, dim=1)
+                kl = net.l1.kl + net.l2.kl + net.l3.kl
+            loss = torch.nn.functional.nll_loss(out, y, reduction="sum") + kl / 10
+            loss.backward()
+            res.append((float(loss.detach()), {n: p.grad.clone() for n, p in net.named_parameters()}))
+        assert res[0][0] == res[1][0], (prec, res[0][0], res[1][0])
+        for n in res[0][1]:
+            assert torch.equal(res[0][1][n], res[1][1][n]), (prec, n)
+    bnn.set_precision("fp32")
+
+
+@pytest.mark.gpu
 def test_dense_layer_random_shape_sweep():
     """tools/layer_fuzz.py with FLOW=any: 18 random layers across planar / RNVP / MNF-type flows (unaligned B / I / O down to
     I = 5, 1-3 transforms, both precisions): output, KL and every gradient of the HIP backward (incl.
