@@ -963,16 +963,22 @@ class _NetworkBase(nn.Module):
             kl = torch.empty((), dtype=torch.float32, device=dev) if c[1] else None
             kls.append(kl)
             keep.append(l._fill_desc(descs[i], c, kl))
-        _lib.check(_lib.lib().lbbnn_layers_operands(descs, len(layers), rng.data_ptr() if rng is not None else None,
-                                                    torch.cuda.current_stream(dev).cuda_stream), "lbbnn_layers_operands")
-        all_kl = all(c[1] for c in cfgs)
-        shared = {"hosted": False, "keep": keep,
-                  "fin_all": (descs, len(layers), rng.data_ptr() if rng is not None else None, None) if all_kl else None}
-        # one Philox snapshot per step for every backward re-draw (the dense pre-flow took it already if it ran)
+        # one Philox snapshot per step for every backward re-draw: the dense pre-flow took it already if it ran, else the
+        # K1 launch writes it (advance 0: the shared offset is advanced once, after the last layer)
         snap = None
         if rng is not None:
             pf = layers[0]._preflow
-            snap = pf["rng"] if (pf is not None and pf.get("rng") is not None) else rng.clone()
+            snap = pf["rng"] if (pf is not None and pf.get("rng") is not None) else None
+        k1_snap = None
+        if rng is not None and snap is None:
+            snap = k1_snap = torch.empty(4, dtype=torch.int64, device=dev)
+        _lib.check(_lib.lib().lbbnn_layers_operands_snap(descs, len(layers), rng.data_ptr() if rng is not None else None,
+                                                         k1_snap.data_ptr() if k1_snap is not None else
+                                                         (rng.data_ptr() + 16 if rng is not None else None), 0,
+                                                         torch.cuda.current_stream(dev).cuda_stream), "lbbnn_layers_operands_snap")
+        all_kl = all(c[1] for c in cfgs)
+        shared = {"hosted": False, "keep": keep,
+                  "fin_all": (descs, len(layers), rng.data_ptr() if rng is not None else None, None) if all_kl else None}
         for i, (l, c) in enumerate(zip(layers, cfgs)):
             l._preprep = {"cfg": c, "split": l._split_now, "kl": kls[i], "first": i == 0, "shared": shared, "snap": snap}
 
