@@ -39,11 +39,20 @@ def make_graphed_train_step(net, optimizer, loss_fn, example_x, example_y, warmu
     torch.cuda.current_stream(dev).wait_stream(side)
     graph = torch.cuda.CUDAGraph()
     optimizer.zero_grad(set_to_none=True)
+    # the warm-up ran on a side stream, the capture runs on torch's capture stream: the AccumulateGrad nodes created during
+    # warm-up therefore sit on another (non-default) stream than the captured backward -- intended, as in torch's own
+    # whole-network capture recipe; newer torch versions warn about it
+    _quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+    if _quiet is not None:
+        _quiet(False)
     with torch.cuda.graph(graph):
         static_loss = loss_fn(net, static_x, static_y)
         with ov():
             static_loss.backward()
         optimizer.step()
+
+    if _quiet is not None:
+        _quiet(True)
 
     def step(x, y):
         static_x.copy_(x)
