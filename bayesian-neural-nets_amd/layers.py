@@ -57,7 +57,10 @@ def join_vector_backward():
 
 
 class vector_backward_overlap:
-    """Context manager: backward passes inside defer their vector-sized chains; issued (batched over layers) on exit."""
+    """Context manager: backward passes inside defer their vector-sized chains; issued (batched over layers) on exit.
+    The gradients of the vector-sized parameters (q0_*, r0_*, flow parameters, biases) are complete only after the exit:
+    do not combine with anything that READS gradients during the backward pass (gradient hooks, DistributedDataParallel's
+    bucketed all-reduce); bnn_amd.parallel's explicit all_reduce_grads() after the block is fine."""
 
     def __enter__(self):
         self._was = _OVERLAP["on"]
