@@ -719,9 +719,14 @@ __global__ __launch_bounds__(SK_WAVES * 64) void lrt_gemm_skinny_kernel(const Ge
     __shared__ __attribute__((aligned(16))) float red[SK_WAVES][2][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int lr = lane & 15, q = lane >> 4;
-    const int b0 = blockIdx.x * 16;
+#ifdef LAB_SK_ROWS           // tools/lab experiment: fewer batch rows per workgroup (more workgroups, two per CU)
+    constexpr int SKR = LAB_SK_ROWS;
+#else
+    constexpr int SKR = 16;
+#endif
+    const int b0 = blockIdx.x * SKR;
     const int b = b0 + lr;
-    const bool brow = b < a.B, orow = lr < a.O;
+    const bool brow = b < a.B && lr < SKR, orow = lr < a.O;
     floatx4 accm = {0.f, 0.f, 0.f, 0.f}, accv = {0.f, 0.f, 0.f, 0.f};
     const int nchunks = (a.I + BK - 1) / BK;
     for (int cb = wv; cb < nchunks; cb += SK_WAVES * SK_NCH) {
@@ -945,7 +950,11 @@ static int lrt_gemm_impl(const float* x, int ldx, const void* e_w, const void* v
     }
     if (O <= 16) {
         a.fin.n = 0;
+#ifdef LAB_SK_ROWS
+        dim3 grid((B + LAB_SK_ROWS - 1) / LAB_SK_ROWS), block(SK_WAVES * 64);
+#else
         dim3 grid((B + 15) / 16), block(SK_WAVES * 64);
+#endif
         if (mean_only) {
             if (xvec) hipLaunchKernelGGL((lrt_gemm_skinny_kernel<true, true>), grid, block, 0, s, a);
             else      hipLaunchKernelGGL((lrt_gemm_skinny_kernel<true, false>), grid, block, 0, s, a);
