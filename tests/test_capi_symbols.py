@@ -61,3 +61,31 @@ def test_argument_checks_return_codes_without_launching(lib):
     assert lib.lbbnn_log_softmax_rows(fake, 100, fake, 100, 4, 65, None) == -2
     assert lib.lbbnn_mnf_flow_planar(fake, fake, None, None, None, 0, None, None, None, 0, fake, fake,
                                      None, 0, fake, fake, fake, 20000, 1, None) == -2
+
+
+def test_ctypes_struct_layouts_match_the_header(tmp_path):
+    """Every struct of include/lbbnn.h that the Python side mirrors with ctypes has the same size and the same offset of
+    its last member when compiled by gcc from the header itself (an ABI drift here would corrupt kernel arguments)."""
+    import subprocess
+    from bnn_amd import _lib
+    pairs = [("lbbnn_priors_t", _lib.Priors, "bias_sigma_prior"), ("lbbnn_planar_flow_t", _lib.PlanarFlow, "T"),
+             ("lbbnn_layer_desc_t", _lib.LayerDesc, "flows_done"), ("lbbnn_dense_transform_t", _lib.DenseTransform, "mask_kl"),
+             ("lbbnn_gate_args_t", _lib.GateArgs, None), ("lbbnn_wpb_args_t", _lib.WpbArgs, None),
+             ("lbbnn_adam_list_t", _lib.AdamList, None), ("lbbnn_copy_list_t", _lib.CopyList, None),
+             ("lbbnn_dense_layer_t", _lib.DenseLayer, "draw_masks"), ("lbbnn_dense_grad_t", _lib.DenseGrad, "b_b"),
+             ("lbbnn_outgrad_args_t", _lib.OutGradArgs, "relu"), ("lbbnn_flow_step_t", _lib.FlowStep, "M"),
+             ("lbbnn_flow_chain_t", _lib.FlowChain, "n"), ("lbbnn_planar_grad_t", _lib.PlanarGrad, "b"),
+             ("lbbnn_flow_bwd_args_t", _lib.FlowBwdArgs, "layer_id"), ("lbbnn_dense_bwd_args_t", _lib.DenseBwdArgs, "layer_id")]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "%s"' % os.path.join(ROOT, "include", "lbbnn.h"), "int main(void) {"]
+    for cname, _, last in pairs:
+        lines.append('printf("%s %%zu %%zu\\n", sizeof(%s), %s);' % (cname, cname, "offsetof(%s, %s)" % (cname, last) if last else "(size_t)0"))
+    lines += ["return 0; }"]
+    src = tmp_path / "sizes.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-std=c99", "-o", str(exe), str(src)], check=True)
+    out = dict((l.split()[0], (int(l.split()[1]), int(l.split()[2]))) for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls, last in pairs:
+        assert ctypes.sizeof(cls) == out[cname][0], (cname, ctypes.sizeof(cls), out[cname][0])
+        if last:
+            assert getattr(cls, last).offset == out[cname][1], (cname, last)
