@@ -89,3 +89,26 @@ def test_ctypes_struct_layouts_match_the_header(tmp_path):
         assert ctypes.sizeof(cls) == out[cname][0], (cname, ctypes.sizeof(cls), out[cname][0])
         if last:
             assert getattr(cls, last).offset == out[cname][1], (cname, last)
+
+
+def test_new_entry_points_argument_checks(lib):
+    """Round-1 additions: early argument checks (nothing is launched, so this runs without a GPU) and size helpers."""
+    from bnn_amd import _lib
+    fake = ctypes.c_void_p(4096)
+    assert lib.lbbnn_mnf_flow_planar_backward_batch(None, 1, None) == -1
+    assert lib.lbbnn_mnf_flow_planar_backward_batch((_lib.FlowBwdArgs * 1)(), 0, None) == -2
+    assert lib.lbbnn_mnf_flow_planar_backward_batch((_lib.FlowBwdArgs * 1)(), 5, None) == -2
+    assert lib.lbbnn_mnf_flow_dense_backward_batch(None, 1, None) == -1
+    assert lib.lbbnn_mnf_flow_dense_backward_batch((_lib.DenseBwdArgs * 1)(), 0, None) == -2
+    assert lib.lbbnn_mnf_flow_dense_backward((_lib.DenseBwdArgs * 1)(), None) == -5          # neither eps nor rng
+    assert lib.lbbnn_lrt_gemm_combine(fake, 8, fake, 32, None, 8, fake, 8, fake, 8, 4, 8, 32, 0, None) == -1
+    assert lib.lbbnn_lrt_gemm_combine(fake, 8, fake, 32, fake, 8, fake, 8, fake, 8, 4, 8, 8, 0, None) == -2   # O <= 16
+    assert lib.lbbnn_weight_operands_t(None, fake, fake, None, fake, fake, 32, 4, 4, 0, None) == -1
+    assert lib.lbbnn_weight_operands_t(fake, fake, fake, None, fake, fake, 30, 4, 4, 0, None) == -3
+    assert lib.lbbnn_weight_operands_t(fake, fake, fake, None, fake, fake, 32, 4, 4, 0x100, None) == -4
+    assert lib.lbbnn_layers_operands_snap((_lib.LayerDesc * 1)(), 1, fake, None, 1, None) == -1      # rng without a snapshot slot
+    assert lib.lbbnn_layers_operands_snap(None, 1, None, None, 0, None) == -1
+    # kept intermediates of the dense flows: ZF | ZK ((Tz+1) x I each), ZR (Tr x I), 4 x 128 hidden floats per (transform, path)
+    assert lib.lbbnn_flow_dense_save_size(1200, 2, 2) == 1200 * (2 * 3 + 2) + 4 * 2 * 4 * 128
+    assert lib.lbbnn_flow_dense_save_size(0, 2, 2) == 0
+    assert lib.lbbnn_mnf_flow_dense_backward_workspace(1200) == 2 * 1200 + 2 * 75 * 128 + 2 * 128
