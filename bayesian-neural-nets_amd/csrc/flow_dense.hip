@@ -170,6 +170,7 @@ struct StageBatch { StageArgs l[LBBNN_MAX_LAYERS]; };
 __global__ __launch_bounds__(NTC) void dense_stage_c_kernel(const StageBatch bt, int use_lds) {
     extern __shared__ __attribute__((aligned(16))) float wl[];      // the three H x H middle matrices (use_lds)
     __shared__ float hs[2][HMAX];
+    __shared__ float ps[HMAX];           // second-half partial dots of the middle layers
     __shared__ double scratch[4];
     __shared__ float znew[CB];
     const LBBNN_CONST_AS StageArgs& a = kernarg_as<StageBatch>()->l[blockIdx.z];
@@ -261,17 +262,26 @@ __global__ __launch_bounds__(NTC) void dense_stage_c_kernel(const StageBatch bt,
     if (rnvp) {
 #pragma unroll
         for (int l = 0; l < 3; ++l) {
-            if (tid < H) {
-                // four independent partial sums: a single accumulator made this a chain of H dependent LDS round trips
+            // two threads per output unit (each half of the k range), four independent partial sums each: a single
+            // accumulator made this a chain of H dependent LDS round trips
+            const int j = tid & 127, half = tid >> 7;
+            const int kmid = (H + 1) >> 1, k0 = half ? kmid : 0, k1 = half ? H : kmid;
+            float s = 0.f;
+            if (j < H) {
                 const float* hv = hs[cur];
                 auto dot = [&](const float* w) {
                     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-                    int k = 0;
-                    for (; k + 4 <= H; k += 4) { s0 += w[k] * hv[k]; s1 += w[k + 1] * hv[k + 1]; s2 += w[k + 2] * hv[k + 2]; s3 += w[k + 3] * hv[k + 3]; }
-                    for (; k < H; ++k) s0 += w[k] * hv[k];
+                    int k = k0;
+                    for (; k + 4 <= k1; k += 4) { s0 += w[k] * hv[k]; s1 += w[k + 1] * hv[k + 1]; s2 += w[k + 2] * hv[k + 2]; s3 += w[k + 3] * hv[k + 3]; }
+                    for (; k < k1; ++k) s0 += w[k] * hv[k];
                     return (s0 + s1) + (s2 + s3);
                 };
-                float s = use_lds ? dot(wl + l * H * H + tid * H) : dot(a.tr.w_mid[l] + (size_t)tid * H);   // LDS | global walk
+                s = use_lds ? dot(wl + l * H * H + j * H) : dot(a.tr.w_mid[l] + (size_t)j * H);       // LDS | global walk
+                if (half) ps[j] = s;
+            }
+            __syncthreads();
+            if (tid < H) {
+                s += ps[tid];
                 s += bm[l];
                 s = (l < 2) ? (s >= 0.f ? s : 0.1f * s) : s;                       // last LeakyReLU dropped (:185)
                 hs[cur ^ 1][tid] = s;
