@@ -237,53 +237,6 @@ def _flow(z, spec, masks):
     return _dense(z, kind, tr, masks)
 
 
-def lrt_param_graph(P, *, stochastic, want_kl, priors):
-    """Parameter-side graph of the LRT layer: the GEMM operands and the KL as differentiable torch tensors.
-    The backward multiplies the operand gradients (computed by the HIP GEMMs) into this graph."""
-    alpha = _alpha(P["lambdal"])
-    g = {"Wm": P["weight_mu"] * alpha, "bmean": P["bias_mu"], "Wv": None, "bvar": None, "kl": None}
-    sigma = None
-    if stochastic:
-        sigma = _sigma(P["weight_rho"])
-        g["Wv"] = sigma ** 2 * alpha ** 2
-        g["bvar"] = _sigma(P["bias_rho"]) ** 2
-    if want_kl:
-        sigma = _sigma(P["weight_rho"]) if sigma is None else sigma
-        g["kl"] = _kl_bias(P["bias_mu"], P["bias_rho"], priors) + _kl_weight(P["weight_mu"], sigma, alpha, priors)
-    return g
-
-
-def mnf_param_graph(P, zf, rf, noise, *, stochastic, want_kl, priors):
-    """Parameter-side graph of the MNF layer (LBBNN-GP-MF-MNF.py:190-239 minus the two x GEMMs)."""
-    alpha = _alpha(P["lambdal"])
-    q0_std = P["q0_log_var"].exp().sqrt()
-    z_k, _ = _flow(P["q0_mean"] + q0_std * noise["eps_z"], zf, noise.get("zmask"))
-    g = {"Wm": P["weight_mu"] * alpha * z_k, "bmean": P["bias_mu"], "Wv": None, "bvar": None, "kl": None}
-    sigma = None
-    if stochastic:
-        sigma = _sigma(P["weight_rho"])
-        g["Wv"] = sigma ** 2 * alpha ** 2
-        g["bvar"] = _sigma(P["bias_rho"]) ** 2
-    if want_kl:
-        sigma = _sigma(P["weight_rho"]) if sigma is None else sigma
-        z0 = P["q0_mean"] + q0_std * noise["eps_z2"]
-        z2, log_det_q = _flow(z0, zf, noise.get("zmask2"))
-        log_q0 = (-0.5 * math.log(math.pi) - 0.5 * P["q0_log_var"]
-                  - 0.5 * ((z0 - P["q0_mean"]) ** 2 / P["q0_log_var"].exp())).sum()
-        log_q = -log_det_q + log_q0
-        W_mean = z2 * P["weight_mu"] * alpha
-        W_var = sigma ** 2 * alpha ** 2
-        act = torch.tanh(P["r0_c"] @ W_mean.T + (P["r0_c"] ** 2 @ W_var.T).sqrt() * noise["eps_act"])
-        m = act.mean()
-        mean_r, log_var_r = P["r0_b1"] * m, P["r0_b2"] * m
-        z_b, log_det_r = _flow(z2, rf, noise.get("rmask"))
-        log_rb = (-0.5 * math.log(math.pi) - 0.5 * log_var_r
-                  - 0.5 * ((z_b[-1] - mean_r) ** 2 / log_var_r.exp())).sum()
-        g["kl"] = (_kl_bias(P["bias_mu"], P["bias_rho"], priors)
-                   + _kl_weight(P["weight_mu"] * z2, sigma, alpha, priors) + log_q - (log_det_r + log_rb))
-    return g
-
-
 def lrt_vector_graph(P, *, stochastic, want_kl, priors):
     """Bias-only part of the LRT layer; the (O,I) chain is lbbnn_weight_pass_backward's."""
     return {"z_k": None, "z2": None, "bmean": P["bias_mu"],
@@ -319,68 +272,6 @@ def mnf_vector_graph(P, zf, rf, noise, act_mu, act_var, *, stochastic, want_kl, 
         g["z2"] = z2
         g["kl"] = _kl_bias(P["bias_mu"], P["bias_rho"], priors) + (-log_det_q + log_q0) - (log_det_r + log_rb)
     return g
-
-
-def lrt_torch(x, P, noise, *, stochastic, want_kl, priors, relu):
-    """LBBNN-GP-MF-LRT.py:166-197 as differentiable torch ops. P: dict of tensors."""
-    alpha = _alpha(P["lambdal"])
-    e_w = P["weight_mu"] * alpha
-    out = x @ e_w.T + P["bias_mu"]
-    sigma = None
-    if stochastic:
-        sigma = _sigma(P["weight_rho"])
-        var_b = (x ** 2) @ (sigma ** 2 * alpha ** 2).T + _sigma(P["bias_rho"]) ** 2
-        out = out + torch.sqrt(var_b) * noise["eps_out"]
-    if relu:
-        out = torch.relu(out)
-    kl = None
-    if want_kl:
-        sigma = _sigma(P["weight_rho"]) if sigma is None else sigma
-        kl = _kl_bias(P["bias_mu"], P["bias_rho"], priors) + _kl_weight(P["weight_mu"], sigma, alpha, priors)
-    return out, kl
-
-
-def mnf_planar_torch(x, P, zf, rf, noise, *, stochastic, want_kl, priors, relu):
-    """LBBNN-GP-MF-MNF.py:190-239, only the kept z row.
-
-    zf / rf: (kind, transforms): planar -> list of (u, w, bias); RNVP/MNF -> list of parameter dicts.
-    noise: eps_z (I,), eps_out (B,O), eps_z2 (I,), eps_act (O,) [+ zmask / zmask2 / rmask lists of (I,)].
-    """
-    alpha = _alpha(P["lambdal"])
-    q0_std = P["q0_log_var"].exp().sqrt()
-    z_k, _ = _flow(P["q0_mean"] + q0_std * noise["eps_z"], zf, noise.get("zmask"))
-    e_w = P["weight_mu"] * alpha
-    out = (x * z_k) @ e_w.T + P["bias_mu"]
-    sigma = None
-    if stochastic:
-        sigma = _sigma(P["weight_rho"])
-        var_b = (x ** 2) @ (sigma ** 2 * alpha ** 2).T + _sigma(P["bias_rho"]) ** 2
-        out = out + torch.sqrt(var_b) * noise["eps_out"]
-    if relu:
-        out = torch.relu(out)
-    kl = None
-    if want_kl:
-        sigma = _sigma(P["weight_rho"]) if sigma is None else sigma
-        z0 = P["q0_mean"] + q0_std * noise["eps_z2"]
-        z2, log_det_q = _flow(z0, zf, noise.get("zmask2"))
-        log_q0 = (-0.5 * math.log(math.pi) - 0.5 * P["q0_log_var"]
-                  - 0.5 * ((z0 - P["q0_mean"]) ** 2 / P["q0_log_var"].exp())).sum()
-        log_q = -log_det_q + log_q0
-        W_mean = z2 * P["weight_mu"] * alpha
-        W_var = sigma ** 2 * alpha ** 2
-        act_mu = P["r0_c"] @ W_mean.T
-        act_var = P["r0_c"] ** 2 @ W_var.T
-        act = torch.tanh(act_mu + act_var.sqrt() * noise["eps_act"])
-        m = act.mean()
-        mean_r = P["r0_b1"] * m
-        log_var_r = P["r0_b2"] * m
-        z_b, log_det_r = _flow(z2, rf, noise.get("rmask"))
-        log_rb = (-0.5 * math.log(math.pi) - 0.5 * log_var_r
-                  - 0.5 * ((z_b[-1] - mean_r) ** 2 / log_var_r.exp())).sum()
-        log_r = log_det_r + log_rb
-        kl = (_kl_bias(P["bias_mu"], P["bias_rho"], priors)
-              + _kl_weight(P["weight_mu"] * z2, sigma, alpha, priors) + log_q - log_r)
-    return out, kl
 
 
 def base_torch(x, cgamma, tau_w, tau_b, P, noise, *, mode, want_lp, exact, alpha_attr, gamma_alpha):

@@ -19,6 +19,7 @@ There is no CPU path: parameters may be *constructed* on CPU (as the reference d
 ``forward`` needs them on a HIP device.
 """
 import itertools
+import weakref
 from typing import Dict, Optional
 
 import torch
@@ -45,11 +46,29 @@ _MASKS_IN_KERNEL = _os.environ.get("LBBNN_TORCH_MASKS", "0") != "1"
 # (lbbnn_mnf_flow_dense_backward_batch) instead of one per layer.  OFF unless a caller that also FLUSHES before the
 # optimizer step turns it on (graphs.make_graphed_train_step, or `with layers.vector_backward_overlap(): loss.backward()`):
 # the gradients such a backward returns are only complete after join_vector_backward().
-_OVERLAP = {"on": False, "planar": [], "dense": []}
+_OVERLAP = {"on": False, "planar": [], "dense": [], "adopt": []}
+
+
+def _drop_deferred():
+    for k in ("planar", "dense", "adopt"):
+        _OVERLAP[k].clear()
 
 
 def join_vector_backward():
-    """Issue the deferred vector-sized backward chains of all layers (no-op if there are none)."""
+    """Issue the deferred vector-sized backward chains of all layers (no-op if there are none).
+
+    A deferred chain writes into the tensors its layer's backward RETURNED; that is only sound if autograd adopted each of
+    them as the parameter's ``.grad`` (AccumulateGrad takes over a gradient it holds the only reference to).  This is
+    checked here for every deferred gradient before anything is launched: a parameter whose ``.grad`` is not the very
+    tensor the chain will write (it was copied, summed with another contribution, or the pass was ``autograd.grad``)
+    would otherwise receive garbage while the kernel writes freed memory -- that raises instead."""
+    bad = [name for (name, p, ptr) in _OVERLAP["adopt"] if p.grad is None or p.grad.data_ptr() != ptr]
+    if bad:
+        _drop_deferred()
+        raise RuntimeError("bnn_amd: a deferred vector-backward gradient was not adopted as .grad (%s ...): the backward "
+                           "pass ran under conditions vector_backward_overlap does not support; nothing was launched, "
+                           "the gradients of this step are incomplete" % ", ".join(bad[:3]))
+    _OVERLAP["adopt"].clear()
     if _OVERLAP["planar"]:
         ops.mnf_flow_planar_backward_flush(_OVERLAP["planar"])
     if _OVERLAP["dense"]:
@@ -67,19 +86,51 @@ class vector_backward_overlap:
         _OVERLAP["on"] = True
         return self
 
-    def __exit__(self, *exc):
+    def __exit__(self, exc_type, exc, tb):
         _OVERLAP["on"] = self._was
+        if exc_type is not None:
+            # the backward pass did not finish: autograd has released (some of) the tensors the filed chains would write
+            _drop_deferred()
+            return False
         join_vector_backward()
         return False
 
 
-def _deferral_ok(layer):
-    """Deferred chains write their outputs AFTER the backward function has returned them, so autograd must adopt those
-    tensors rather than read them: the parameters' .grad must be None (zero_grad(set_to_none=True)) and the backward must
-    not be building a graph.  Otherwise the chains run in place, as without the context manager."""
-    if not _OVERLAP["on"] or torch.is_grad_enabled():
+class _NodeToken:
+    """One per autograd forward of a layer; ``multi`` is set on every live token of a layer as soon as a second one
+    appears, i.e. when the layer takes part more than once in the graph a backward pass will walk."""
+    __slots__ = ("multi", "__weakref__")
+
+    def __init__(self):
+        self.multi = False
+
+
+def _has_grad_hooks(p):
+    return bool(getattr(p, "_backward_hooks", None)) or bool(getattr(p, "_post_accumulate_grad_hooks", None))
+
+
+def _deferral_ok(layer, token):
+    """Deferred chains write their outputs AFTER the backward function has returned them, so autograd must ADOPT those
+    tensors as ``.grad`` rather than read them.  That is the case only when
+      * the backward is not building a graph,
+      * every vector-sized parameter's ``.grad`` is None (``zero_grad(set_to_none=True)``),
+      * the layer was run ONCE in the graph being walked (a second application -- a multi-sample ELBO, a loss that calls
+        the net twice -- makes autograd SUM the two returned tensors before any flush: one unwritten operand, the other
+        freed afterwards),
+      * no tensor hook or post-accumulate hook would read the gradient during the pass.
+    Otherwise the chains run in place, as without the context manager."""
+    if not _OVERLAP["on"] or torch.is_grad_enabled() or token is None or token.multi:
         return False
-    return all(p.grad is None for p in layer._param_list()[3:])
+    vec = layer._param_list()[3:]
+    return all(p.grad is None and p.requires_grad and p.is_leaf and not _has_grad_hooks(p) for p in vec)
+
+
+def _file_adoption_checks(layer, grads):
+    """Remember (parameter, address of the returned gradient) for join_vector_backward's adoption check."""
+    vec = layer._param_list()[3:]
+    assert len(vec) == len(grads)
+    for k, (p, g) in enumerate(zip(vec, grads)):
+        _OVERLAP["adopt"].append(("%s[%d]" % (type(layer).__name__, k), p, g.data_ptr()))
 
 
 _layer_ids = itertools.count()
@@ -123,6 +174,14 @@ class _BayesLinearFn(torch.autograd.Function):
             if cfg[1]:
                 saved["act_mu"], saved["act_var"], saved["z_kl"], saved["scal"] = ws.act_mu, ws.act_var, ws.z_kl, ws.scal
         ctx.layer, ctx.cfg, ctx.saved = layer, cfg, saved
+        # how many autograd nodes of this layer are alive: the deferral of its vector chain needs exactly one
+        live = layer.__dict__.setdefault("_live_nodes", weakref.WeakSet())
+        ctx.token = _NodeToken()
+        if len(live):
+            ctx.token.multi = True
+            for t in live:
+                t.multi = True
+        live.add(ctx.token)
         std = saved.pop("std", None)
         ctx.has_std = std is not None
         ctx.save_for_backward(x, out, *([std] if std is not None else []), *params)
@@ -133,6 +192,10 @@ class _BayesLinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out, g_kl):
         layer, cfg = ctx.layer, ctx.cfg
+        token = getattr(ctx, "token", None)
+        can_defer = _deferral_ok(layer, token)
+        if token is not None:
+            layer.__dict__.get("_live_nodes", set()).discard(token)
         stochastic, want_kl, relu = cfg
         tens = list(ctx.saved_tensors)
         x, out = tens[0], tens[1]
@@ -227,12 +290,14 @@ class _BayesLinearFn(torch.autograd.Function):
                 P["q0_mean"], P["q0_log_var"], zp, rp, eps_fwd=e1, eps_kl=e2,
                 rng=rng_snap, layer_id=layer._layer_id, r0_b1=P["r0_b1"], r0_b2=P["r0_b2"], aux=aux,
                 dz_fwd=dz_k, dz_kl=dz2, g_kl=g_kl, bias_mu=P["bias_mu"], bias_rho=P["bias_rho"], g_sum=g_sum,
-                gv_sum=gv_sum, priors=layer.priors, defer=_OVERLAP["planar"] if _deferral_ok(layer) else None)
+                gv_sum=gv_sum, priors=layer.priors, defer=_OVERLAP["planar"] if can_defer else None)
             G["r0_c"] = dr0c if dr0c is not None else torch.zeros_like(P["q0_mean"])
             vgrads = [G[n] for n in layer._vec_names]
             for key in ("z_flow", "r_flow"):
                 for g3 in G[key]:
                     vgrads += list(g3)
+            if can_defer:
+                _file_adoption_checks(layer, vgrads)
             return (None, gx, None, dmu, drho, dlam, *vgrads)
         if dense:
             masks = ctx.saved["masks"]
@@ -249,13 +314,16 @@ class _BayesLinearFn(torch.autograd.Function):
                 rd, Tr, 0 if layer.r_flow.kind == "RNVP" else 1, rest[nz:], save=ctx.saved["dense_save"],
                 eps_fwd=e1, eps_kl=e2, rng=rng_f, layer_id=layer._layer_id, r0_b1=P["r0_b1"], r0_b2=P["r0_b2"], aux=aux,
                 dz_fwd=dz_k, dz_kl=dz2, g_kl=g_kl, bias_mu=P["bias_mu"], bias_rho=P["bias_rho"], g_sum=g_sum,
-                gv_sum=gv_sum, priors=layer.priors, defer=_OVERLAP["dense"] if _deferral_ok(layer) else None,
+                gv_sum=gv_sum, priors=layer.priors, defer=_OVERLAP["dense"] if can_defer else None,
                 keep=(k1, k2))
             del k1, k2
             G["r0_c"] = dr0c if dr0c is not None else torch.zeros_like(P["q0_mean"])
             if not want_kl:
                 G["r_flow"] = [torch.zeros_like(p) for p in rest[nz:]]
-            return (None, gx, None, dmu, drho, dlam, *[G[n] for n in layer._vec_names], *G["z_flow"], *G["r_flow"])
+            vgrads = [*[G[n] for n in layer._vec_names], *G["z_flow"], *G["r_flow"]]
+            if can_defer:
+                _file_adoption_checks(layer, vgrads)
+            return (None, gx, None, dmu, drho, dlam, *vgrads)
         outs, gouts = [vg["bmean"]], [g_sum]
         if stochastic:
             outs.append(vg["bvar"]); gouts.append(gv_sum)
@@ -524,14 +592,6 @@ class LRTBayesianLinear(_BayesLinearBase):
             return {}
         return {"eps_out": ops.philox_normal(saved["rng"], ops.STREAM_EPS_OUT * 64 + self._layer_id,
                                              B, self.out_features, self.row_offset)}
-
-    def _forward_torch(self, x, ps, cfg, noise):
-        P = dict(zip(self._names, ps))
-        return _grad.lrt_torch(x, P, noise, stochastic=cfg[0], want_kl=cfg[1], priors=self.priors, relu=cfg[2])
-
-    def _param_graph(self, ps, cfg, noise):
-        P = dict(zip(self._names, ps))
-        return _grad.lrt_param_graph(P, stochastic=cfg[0], want_kl=cfg[1], priors=self.priors)
 
     _vec_names = ("bias_mu", "bias_rho")
 
@@ -828,16 +888,6 @@ class MNFBayesianLinear(_BayesLinearBase):
                     rest = rest[len(names):]
                 specs.append((flow.kind, trs))
         return P, specs
-
-    def _forward_torch(self, x, ps, cfg, noise):
-        P, specs = self._unpack_params(ps)
-        return _grad.mnf_planar_torch(x, P, specs[0], specs[1], noise, stochastic=cfg[0], want_kl=cfg[1],
-                                      priors=self.priors, relu=cfg[2])
-
-    def _param_graph(self, ps, cfg, noise):
-        P, specs = self._unpack_params(ps)
-        return _grad.mnf_param_graph(P, specs[0], specs[1], noise, stochastic=cfg[0], want_kl=cfg[1],
-                                     priors=self.priors)
 
     _vec_names = _names[3:]
 

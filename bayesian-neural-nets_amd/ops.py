@@ -240,9 +240,9 @@ def weight_pass_backward(mu, rho, lambdal, dWm, dWv=None, *, z_fwd=None, z_kl=No
 
 # ----------------------------------------------------------------------------------------- K2
 # When set to a GemmEventLog, every lrt_gemm launch is bracketed by HIP events recorded on the launch stream and
-# (B, I, O, start, end) is logged -- bench.py's per-kernel roofline timing.  The events are created up front:
-# creating them inside the timed loop was measured at ~35 us each on some hosts, i.e. the measurement slowed the
-# step it measures.
+# (B, I, O, start, end) is logged -- bench.py's per-kernel roofline pass (run OUTSIDE its timed region).
+# torch.cuda.Event creates the HIP event lazily at its first record(): the constructor therefore records every pooled
+# event once and synchronises, so no event is created (or first touched by the runtime) between two bracketed launches.
 class GemmEventLog(list):
     """``every``: bracket only every n-th launch group of ``group`` launches (the event records themselves cost host
     time: 6 per step made an otherwise GPU-bound eager loop host-bound)."""
@@ -250,6 +250,10 @@ class GemmEventLog(list):
     def __init__(self, launches: int, group: int = 1, every: int = 1):
         super().__init__()
         self._pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
+        for s, e in self._pool:
+            s.record()
+            e.record()
+        torch.cuda.synchronize()
         self._group, self._every, self._n = group, every, 0
 
     def take(self):

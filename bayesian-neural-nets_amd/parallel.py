@@ -12,6 +12,7 @@ loss_r over ranks gives the gradient of  nll(global batch) + kl / num_batches,  
 reference's ``train()`` (LBBNN-GP-MF-MNF.py:268-272) computes on the whole batch; the KL (parameters
 only, identical on every rank) is counted once.
 """
+import os
 from typing import Iterable, List, Tuple
 
 import torch
@@ -32,7 +33,15 @@ class GradBucket:
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else torch.device("cpu")
-        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        # the buffer is padded to a multiple of 8 ranks x 4 floats so that it also splits evenly (and 16-B aligned) for
+        # the reduce-scatter + all-gather form of the exchange at any world size up to one node's 8 GPUs
+        self.padded = -(-max(self.numel, 1) // 32) * 32
+        self._store = torch.zeros(self.padded, dtype=torch.float32, device=dev)
+        self.flat = self._store[:self.numel]
+        self.mode = os.environ.get("LBBNN_DP_COLLECTIVE", "all_reduce")
+        if self.mode not in ("all_reduce", "rs_ag"):
+            raise ValueError("LBBNN_DP_COLLECTIVE must be 'all_reduce' or 'rs_ag'")
+        self.last = None
 
     def _slices(self):
         off = 0
@@ -90,7 +99,18 @@ class GradBucket:
         (use ``views()`` with ``bnn_amd.optim.Adam.step(grads=...)``)."""
         self.pack()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            world = dist.get_world_size(group)
+            if self.mode == "rs_ag" and self.padded % world == 0:
+                # xGMI is a full point-to-point mesh: reduce-scatter + all-gather moves 1/world of the bucket per peer
+                # over every link at once, where a ring all-reduce pushes 2(world-1)/world of it through one link
+                # (SURVEY.md section 5); which of the two RCCL runs faster is measured, not assumed: bench.py --train
+                shard = self._store.view(world, -1)[dist.get_rank(group)]
+                dist.reduce_scatter_tensor(shard, self._store, op=dist.ReduceOp.SUM, group=group)
+                dist.all_gather_into_tensor(self._store, shard, group=group)
+                self.last = "reduce_scatter_tensor + all_gather_into_tensor (%d B per rank shard)" % (shard.numel() * 4)
+            else:
+                dist.all_reduce(self._store, op=dist.ReduceOp.SUM, group=group)
+                self.last = "all_reduce (%d B)" % (self._store.numel() * 4)
         if unpack:
             self.unpack()
 
@@ -115,6 +135,28 @@ class DataParallelELBO:
             # replicas must start identical: broadcast rank 0's parameters once
             for p in net.parameters():
                 dist.broadcast(p.data, src=0, group=group)
+        self.sync_rng()
+
+    def sync_rng(self):
+        """The contract of the sharded forward -- the SAME z on every rank, a KL identical on every rank, rank-distinct
+        eps through ``row_offset`` -- holds only while every rank's Philox {seed, offset} pair is the same: rank 0's pair
+        is broadcast here (construction) and may be re-broadcast by the caller after rank-local work that drew noise on
+        some ranks only (an evaluation pass on rank 0)."""
+        p0 = next(iter(self.net.parameters()), None)
+        if self.world > 1 and p0 is not None and p0.is_cuda:
+            from . import ops
+            st = ops.RngState.get(p0.device)
+            live = st.t[:2].clone()
+            dist.broadcast(live, src=0, group=self.group)
+            st.t[:2].copy_(live)
+
+    def bucket_numel(self) -> int:
+        return self.bucket.numel
+
+    def describe_collective(self) -> str:
+        backend = dist.get_backend(self.group) if (dist.is_available() and dist.is_initialized()) else "none"
+        return "%s over %d rank(s), backend %s" % (self.bucket.last or ("no exchange (world 1)" if self.world == 1
+                                                                       else self.bucket.mode), self.world, backend)
 
     def shard(self, *tensors):
         B = tensors[0].shape[0]
