@@ -168,6 +168,10 @@ SIGNATURES = {
     "lbbnn_flow_dense_apply": (c_i, [ctypes.POINTER(DenseTransform), c_i, c_i, c_p, c_i, c_p, c_p, c_p]),
     "lbbnn_flow_dense_apply_backward": (c_i, [ctypes.POINTER(DenseTransform), ctypes.POINTER(DenseGrad), c_i, c_i, c_p, c_p,
                                               c_p, c_i, c_p, c_p, c_p]),
+    "lbbnn_q0_rows": (c_i, [c_p, c_p, c_p, c_p, c_u32, c_i, c_i, c_p, c_p]),
+    "lbbnn_flow_dense_rows_max_dim": (c_i, []),
+    "lbbnn_flow_dense_rows": (c_i, [ctypes.POINTER(DenseTransform), c_i, c_p, c_p, c_p, c_u32, c_u64, c_p, c_i, c_i, c_i,
+                                    c_p, c_i, c_p, c_p]),
     "lbbnn_multi_copy": (c_i, [ctypes.POINTER(CopyList), c_p]),
     "lbbnn_adam_step": (c_i, [ctypes.POINTER(AdamList), ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                               ctypes.c_float, c_p, c_i, c_p]),
@@ -177,6 +181,7 @@ SIGNATURES = {
     "lbbnn_output_grad_workspace": (c_i64, [c_i, c_i]),
     "lbbnn_output_grad": (c_i, [ctypes.POINTER(OutGradArgs), c_p]),
     "lbbnn_flow_chain": (c_i, [ctypes.POINTER(FlowChain), c_p, c_p, c_p, c_p, c_p, c_u32, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "lbbnn_flow_chain_rows": (c_i, [ctypes.POINTER(FlowChain), c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p]),
     "lbbnn_mnf_aux_backward": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_u32, c_p]),
     "lbbnn_mnf_flow_backward_workspace": (c_i64, [c_i, c_i, c_i]),
     "lbbnn_mnf_flow_planar_backward": (c_i, [ctypes.POINTER(FlowBwdArgs), c_p]),

@@ -17,6 +17,8 @@ from . import _grad, _lib, ops
 from .distributions import Bernoulli, Gaussian, TEMPER_PRIOR  # noqa: F401  (TEMPER_PRIOR re-exported: the reference scripts read it here)
 
 _ids = itertools.count(32)
+SAMPLES = 1              # LBBNN-GP-MF.py:38
+NUM_BATCHES = 600        # len(train_loader) with BATCH_SIZE = 100 on MNIST (LBBNN-GP-MF.py:34,67)
 
 
 class GaussGamma(object):
@@ -211,6 +213,8 @@ class BayesianNetwork(nn.Module):
         self.l1 = BayesianLinear(dims[0], dims[1], 1)
         self.l2 = BayesianLinear(dims[1], dims[2], 1)
         self.l3 = BayesianLinear(dims[2], dims[3], 1)
+        for i, l in enumerate((self.l1, self.l2, self.l3)):
+            l._layer_id = 32 + i              # per-network Philox stream ids (not the process-wide counter)
 
     def forward(self, x, g1, g2, g3, sample=False, medimean=False):
         x = x.view(-1, self.dims[0])
@@ -225,8 +229,11 @@ class BayesianNetwork(nn.Module):
         return (self.l1.log_variational_posterior + self.l2.log_variational_posterior
                 + self.l3.log_variational_posterior)
 
-    def sample_elbo(self, input, target, samples=1, num_batches=600):
-        """:285-319 (NUM_BATCHES / CLASSES / BATCH_SIZE were module globals there)."""
+    def sample_elbo(self, input, target, samples=SAMPLES, *, num_batches=None):
+        """:285-319, same positional arguments.  NUM_BATCHES / SAMPLES are module globals there (:34-67) and here
+        (``bnn_amd.base.NUM_BATCHES = 600``, ``SAMPLES = 1``); ``num_batches=`` overrides the former per call."""
+        if num_batches is None:
+            num_batches = NUM_BATCHES
         dev = input.device
         lps, lqs, nlls = [], [], []
         for _ in range(samples):

@@ -35,7 +35,12 @@ __device__ __forceinline__ void bsum_n(double (&v)[NV], double* scratch, double*
 __global__ __launch_bounds__(NT) void flow_chain_kernel(const lbbnn_flow_chain_t ch, const float* z_in, const float* q0_mean,
                                                        const float* q0_log_var, const float* eps, const uint64_t* rng,
                                                        uint32_t stream, int I, float* z, float* logdet_out, float* log_q0,
-                                                       float* z_last) {
+                                                       float* z_last, int ld_in, int ld_out) {
+    // rows mode (lbbnn_flow_chain_rows): workgroup r carries row r of z_in through the chain
+    if (z_in) z_in += (size_t)blockIdx.x * ld_in;
+    z += (size_t)blockIdx.x * ld_out;
+    if (logdet_out) logdet_out += blockIdx.x;
+    if (z_last) z_last += blockIdx.x;
     __shared__ double scratch[8 * NWV];
     __shared__ double res[8];
     __shared__ double sBA[MS * MS], slin[MS];
@@ -161,6 +166,23 @@ extern "C" int lbbnn_flow_chain(const lbbnn_flow_chain_t* chain, const float* z_
         if (st.type == LBBNN_FLOW_SYLVESTER && (st.M < 1 || st.M > LBBNN_MAX_SYLVESTER_M)) return LBBNN_E_SHAPE;
     }
     hipLaunchKernelGGL(flow_chain_kernel, dim3(1), dim3(NT), 0, static_cast<hipStream_t>(stream), *chain, z_in, q0_mean,
-                       q0_log_var, eps, rng, rng_stream, I, z_out, logdet, log_q0, z_last);
+                       q0_log_var, eps, rng, rng_stream, I, z_out, logdet, log_q0, z_last, 0, 0);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lbbnn_flow_chain_rows(const lbbnn_flow_chain_t* chain, const float* z_in, int ldz, int R, int I,
+                                     float* z_out, int ldo, float* logdet_rows, void* stream) {
+    if (!chain || !z_in || !z_out) return LBBNN_E_NULL;
+    if (I <= 0 || I > LBBNN_MAX_FLOW_DIM || R < 0 || ldz < I || ldo < I || chain->n < 0 || chain->n > LBBNN_MAX_FLOW_T)
+        return LBBNN_E_SHAPE;
+    for (int s = 0; s < chain->n; ++s) {
+        const lbbnn_flow_step_t& st = chain->step[s];
+        if (st.type < LBBNN_FLOW_PLANAR || st.type > LBBNN_FLOW_SYLVESTER || !st.p0) return LBBNN_E_SHAPE;
+        if (st.type != LBBNN_FLOW_HOUSEHOLDER && (!st.p1 || !st.p2)) return LBBNN_E_NULL;
+        if (st.type == LBBNN_FLOW_SYLVESTER && (st.M < 1 || st.M > LBBNN_MAX_SYLVESTER_M)) return LBBNN_E_SHAPE;
+    }
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(flow_chain_kernel, dim3(R), dim3(NT), 0, static_cast<hipStream_t>(stream), *chain, z_in, nullptr,
+                       nullptr, nullptr, nullptr, 0u, I, z_out, logdet_rows, nullptr, nullptr, ldz, ldo);
     return (int)hipGetLastError();
 }

@@ -490,6 +490,7 @@ class _BayesLinearBase(nn.Module):
             # (a network that drives its layers takes ONE snapshot of the shared state for all of them)
             saved["rng"] = (pre_["snap"] if (pre_ is not None and pre_.get("snap") is not None) else rng.clone()) if save_rng else None
         kl = torch.empty((), dtype=torch.float32, device=x.device) if cfg[1] else None
+        self._cur_B = x.shape[0]
         self._split_now = self._split(x)
         self._last_masks = None
         # the layer's KL tail (K5) depends on parameters only: it rides in the GEMM's launch (lbbnn_lrt_gemm_finalize)
@@ -687,14 +688,40 @@ class MNFBayesianLinear(_BayesLinearBase):
         out["_in_kernel"] = in_kernel
         return out
 
+    as_written = False    # True: the forward's z comes from the B-ROW flow of LBBNN-GP-MF-MNF.py:194 as it is written
+                          # (all B rows through z_flow, B-1 of them discarded) instead of the kept row alone -- the
+                          # apples-to-apples leg against the CPU reference; no-grad forwards only
+
+    def _sample_z_rows(self, R, rng, eps=None, masks=None):
+        """The reference's sample_z arithmetic on R rows (LBBNN-GP-MF-MNF.py:183-186): (zs (R,I), logdet rows (R,), z0)."""
+        L = self._layer_id
+        z0 = ops.q0_rows(self.q0_mean, self.q0_log_var, R, eps=eps, rng=rng, rng_stream=ops.STREAM_EPS_Z * 64 + L)
+        if self._check_flows() == "dense":
+            descs, T, keep = self.z_flow.dense_descs(None, None)
+            if masks is not None:
+                masks = torch.stack([m.reshape(R, self.in_features).float() for m in masks])
+            zs, ld, _ = ops.flow_dense_rows(descs, T, z0, masks=masks, rng=rng if masks is None else None,
+                                            rng_stream=ops.STREAM_ROW_MASK * 64 + L, row_base=self.row_offset, keep=keep)
+        else:
+            zs, ld = ops.flow_chain_rows(self.z_flow.chain_steps(), z0)
+        return zs, ld, z0
+
     def sample_z(self, batch_size=1):
-        """LBBNN-GP-MF-MNF.py:182-187: returns (z_flow(z0)[-1], logdet) -- only the kept row is computed."""
+        """LBBNN-GP-MF-MNF.py:182-187 as written: z0 (batch_size, I) = q0_mean + q0_std * eps is kept in ``self.z``, all
+        rows go through ``z_flow`` and ``(zs[-1], logdet.squeeze())`` is returned -- logdet with the shape the flow kind
+        gives it in the reference (RNVP: (batch_size,) -> squeezed; MNF type: 0-d; 1-D kinds: row-wise (batch_size,)).
+        (The layer's own forward does not call this: it computes the kept row alone, fused with its other vector work.)"""
         st = ops.RngState.get(self.q0_mean.device)
+        noise = self.noise or {}
+        eps = noise.get("eps_z")
+        if eps is not None and eps.numel() != batch_size * self.in_features:
+            eps = None
         with torch.no_grad():
-            self._prep_flows_only(st.t)
+            zs, ld, z0 = self._sample_z_rows(batch_size, st.t, eps=eps, masks=noise.get("zmask") if eps is not None else None)
             st.advance(1)
-        ws = self._workspace()
-        return ws.z_fwd.clone(), ws.scal[4].clone()
+        self.z = z0                                                   # :185
+        logdet = ld.sum() if self.z_flow.kind == "MNF" else ld
+        return zs[-1], logdet.squeeze()                               # :187
 
     def _prep_flows_only(self, rng):
         ws = self._workspace()
@@ -717,7 +744,8 @@ class MNFBayesianLinear(_BayesLinearBase):
         return ["eps_z"] + (["eps_out"] if cfg[0] else []) + (["eps_z2", "eps_act"] if cfg[1] else [])
 
     def _fusable(self):
-        return True            # planar: K3 inside lbbnn_layers_operands; dense / chain: flows first, then flows_done = 1
+        # planar: K3 inside lbbnn_layers_operands; dense / chain: flows first, then flows_done = 1
+        return not self.as_written
 
     def _fill_desc(self, d, cfg, kl_layer):
         ws, noise = super()._fill_desc(d, cfg, kl_layer)
@@ -825,6 +853,17 @@ class MNFBayesianLinear(_BayesLinearBase):
                                                                torch.cuda.current_stream(self.q0_mean.device).cuda_stream),
                            "lbbnn_layers_dense_flows")
                 del keep
+        if self.as_written:
+            # B rows through z_flow, the last one kept (LBBNN-GP-MF-MNF.py:186-187): it replaces the kept-row result above
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                raise RuntimeError("bnn_amd: as_written is a no-grad (evaluation / timing) mode")
+            B = int(self._cur_B)
+            full_eps = noise.get("eps_z")
+            if full_eps is not None and full_eps.numel() != B * self.in_features:
+                raise RuntimeError("bnn_amd: as_written with explicit noise needs eps_z of shape (B,I)")
+            zm = noise.get("zmask") if full_eps is not None else None
+            zs, _, _ = self._sample_z_rows(B, rng, eps=full_eps, masks=zm)
+            ws.z_fwd.copy_(zs[-1])
         ops.weight_pass(self.weight_mu, self.weight_rho, self.lambdal, z_fwd=ws.z_fwd,
                         z_kl=ws.z_kl if want_kl else None, r0_c=self.r0_c if want_kl else None,
                         bias_rho=self.bias_rho, priors=self.priors, e_w=ws.e_w,
@@ -919,6 +958,13 @@ class _NetworkBase(nn.Module):
 
     def _layers(self):
         return [self.l1, self.l2, self.l3]
+
+    def _number_layers(self):
+        """Philox stream ids 0..n-1 inside a network (a stand-alone layer takes the next id of a process-wide counter):
+        the noise a network draws does not depend on what else the process constructed before it -- every rank of a
+        data-parallel job, and a re-run of the same script with one more model in it, see the same streams."""
+        for i, l in enumerate(self._layers()):
+            l._layer_id = i
 
     def forward(self, x, sample=False):
         x = x.view(-1, self.dims[0])                                  # …LRT.py:207
@@ -1125,6 +1171,7 @@ class LRTBayesianNetwork(_NetworkBase):
         self.l1 = LRTBayesianLinear(dims[0], dims[1], priors=priors)
         self.l2 = LRTBayesianLinear(dims[1], dims[2], priors=priors)
         self.l3 = LRTBayesianLinear(dims[2], dims[3], priors=priors)
+        self._number_layers()
 
 
 class MNFBayesianNetwork(_NetworkBase):
@@ -1138,3 +1185,4 @@ class MNFBayesianNetwork(_NetworkBase):
         self.l1 = MNFBayesianLinear(dims[0], dims[1], num_transforms, **kw)
         self.l2 = MNFBayesianLinear(dims[1], dims[2], num_transforms, **kw)
         self.l3 = MNFBayesianLinear(dims[2], dims[3], num_transforms, **kw)
+        self._number_layers()

@@ -23,6 +23,8 @@ STREAM_EPS_Z2 = 2
 STREAM_EPS_ACT = 3
 STREAM_EPS_W = 4
 STREAM_EPS_B = 5
+STREAM_MASK = 6
+STREAM_ROW_MASK = 7
 
 
 # GEMM arithmetic: "fp32" = exact fp32 MFMA path; "bf16x3" = split-precision path (bf16 hi/lo mean
@@ -382,6 +384,28 @@ def flow_chain(steps, *, I: int, z_in=None, q0_mean=None, q0_log_var=None, eps=N
     return z_out, logdet
 
 
+def flow_chain_rows(steps, z: torch.Tensor):
+    """lbbnn_flow_chain_rows: the 1-D chain applied to every row of z (R,I).  Returns (z_out (R,I), logdet (R,))."""
+    if len(steps) > _lib.MAX_FLOW_T:
+        raise ValueError("bnn_amd: at most %d transforms per flow" % _lib.MAX_FLOW_T)
+    ch = _lib.FlowChain()
+    ch.n = len(steps)
+    for k, (ty, M, p0, p1, p2) in enumerate(steps):
+        st = ch.step[k]
+        st.type, st.M = ty, M
+        st.p0, st.p1, st.p2 = _ptr(p0, "flow parameter"), _ptr(p1, "flow parameter"), _ptr(p2, "flow parameter")
+    z = z.float()
+    if z.stride(1) != 1:
+        z = z.contiguous()
+    R, I = z.shape
+    z_out = torch.empty((R, I), dtype=torch.float32, device=z.device)
+    logdet = torch.zeros(R, dtype=torch.float32, device=z.device)
+    rc = _lib.lib().lbbnn_flow_chain_rows(ctypes.byref(ch), _ptr_rows(z, "z"), z.stride(0), R, I, z_out.data_ptr(), I,
+                                          logdet.data_ptr(), _stream())
+    _lib.check(rc, "lbbnn_flow_chain_rows")
+    return z_out, logdet
+
+
 def mnf_aux_backward(act_mu, act_var, eps_act, r0_b1, r0_b2, zb_last, g_kl, rng=None, layer_id: int = 0):
     """lbbnn_mnf_aux_backward -> (da_mu, da_var, aux); zb_last: 1-element view of the forward's scal[3]."""
     O, I = act_mu.shape[0], r0_b1.shape[0]
@@ -530,6 +554,52 @@ def mnf_flow_dense_backward_flush(pending):
                 ctypes.memmove(ctypes.byref(arr[k]), ctypes.byref(a), ctypes.sizeof(_lib.DenseBwdArgs))
             _lib.check(_lib.lib().lbbnn_mnf_flow_dense_backward_batch(arr, len(grp), _stream()), "lbbnn_mnf_flow_dense_backward_batch")
     pending.clear()
+
+
+def q0_rows(q0_mean, q0_log_var, R: int, *, eps=None, rng=None, rng_stream: int = 0):
+    """lbbnn_q0_rows: z0 (R,I) = q0_mean + exp(q0_log_var)^.5 * eps, eps (R,I) explicit or Philox."""
+    I = q0_mean.shape[0]
+    if eps is not None:
+        eps = eps.reshape(R, I).float().contiguous()
+    elif rng is None:
+        raise RuntimeError("bnn_amd: q0_rows needs explicit eps or an rng state")
+    z0 = torch.empty((R, I), dtype=torch.float32, device=q0_mean.device)
+    _lib.check(_lib.lib().lbbnn_q0_rows(_ptr(q0_mean, "q0_mean"), _ptr(q0_log_var, "q0_log_var"), _ptr(eps, "eps"),
+                                        rng.data_ptr() if rng is not None else None, rng_stream, R, I, z0.data_ptr(),
+                                        _stream()), "lbbnn_q0_rows")
+    return z0
+
+
+def flow_dense_rows(descs, T: int, z: torch.Tensor, *, masks: Optional[torch.Tensor] = None, rng: Optional[torch.Tensor] = None,
+                    rng_stream: int = STREAM_ROW_MASK * 64, row_base: int = 0, want_masks: bool = False, keep=()):
+    """lbbnn_flow_dense_rows: a chain of T dense coupling transforms (``descs`` = PropagateFlow.dense_descs(None, None)[0])
+    on the R rows of z (R,I), each row with its own masks.  masks: (T,R,I) in {0,1} or None (drawn in-kernel from ``rng``).
+    Returns (z_out (R,I), logdet_rows (R,), masks used (T,R,I) or None)."""
+    if z.dim() != 2:
+        raise RuntimeError("bnn_amd: flow_dense_rows wants z as (R,I), got %s" % (tuple(z.shape),))
+    R, I = z.shape
+    if I > _lib.lib().lbbnn_flow_dense_rows_max_dim():
+        raise RuntimeError("bnn_amd: row-batched dense flows hold 16 rows of z in LDS: dim %d exceeds the limit %d"
+                           % (I, _lib.lib().lbbnn_flow_dense_rows_max_dim()))
+    z = z.float()
+    if z.stride(1) != 1:
+        z = z.contiguous()
+    f = dict(dtype=torch.float32, device=z.device)
+    if masks is not None:
+        if tuple(masks.shape) != (T, R, I):
+            raise RuntimeError("bnn_amd: masks must be (%d,%d,%d), got %s" % (T, R, I, tuple(masks.shape)))
+        masks = masks.float().contiguous()
+    elif rng is None:
+        raise RuntimeError("bnn_amd: flow_dense_rows needs explicit masks or an rng state")
+    z_out = torch.empty((R, I), **f)
+    logdet = torch.zeros(R, **f)
+    mask_out = torch.empty((T, R, I), **f) if (want_masks and masks is None) else None
+    _lib.check(_lib.lib().lbbnn_flow_dense_rows(
+        descs, T, _ptr(masks, "masks"), _ptr(mask_out), rng.data_ptr() if rng is not None else None, rng_stream,
+        int(row_base), _ptr_rows(z, "z"), z.stride(0), R, I, z_out.data_ptr(), I, logdet.data_ptr(), _stream()),
+        "lbbnn_flow_dense_rows")
+    del keep
+    return z_out, logdet, (masks if masks is not None else mask_out)
 
 
 def flow_dense_save_size(I: int, Tz: int, Tr: int) -> int:

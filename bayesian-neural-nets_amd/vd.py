@@ -94,6 +94,8 @@ class BNN(nn.Module):
         self.l2 = BayesianLayer(dims[1], dims[2])
         self.l3 = BayesianLayer(dims[2], dims[3])
         self.l4 = BayesianLayer(dims[3], dims[4])
+        for i, l in enumerate((self.l1, self.l2, self.l3, self.l4)):
+            l._layer_id = 48 + i              # per-network Philox stream ids (not the process-wide counter)
 
     def forward(self, x):
         x = x.view(-1, self.dims[0])
@@ -103,8 +105,17 @@ class BNN(nn.Module):
         return F.log_softmax(self.l4(x), dim=1)
 
 
-def loss_fn(prediction, target, model, num_batches):
-    """variational_dropout.py:89-106 (num_batches = N / batch_size was computed from the loaders there)."""
+NUM_BATCHES = 600.0      # len(train_loader.dataset) / config['batch_size'] = 60000 / 100 (variational_dropout.py:90-95)
+
+
+def loss_fn(prediction, target, model, *, num_batches=None):
+    """variational_dropout.py:89-106, callable with the reference's three positional arguments.  There ``num_batches``
+    = N / batch_size is computed from the module-level loaders; here it is a keyword (default: the module constant
+    NUM_BATCHES = 600, the reference's MNIST value).  As in the reference, ``if model.train():`` (:91) is a CALL: it
+    flips the model to training mode and is always truthy, so N is always the training set's size."""
+    if num_batches is None:
+        num_batches = NUM_BATCHES
+    model.train()                                                    # :91 (side effect kept)
     KL = 0
     c1, c2, c3 = 1.16145124, -1.50204118, 0.58629921
     for layer in model.children():

@@ -18,7 +18,10 @@ How the number is taken (round 2; the round-1 line did not reproduce under the d
      5 % or 0.5 s has passed ("settle" in the JSON).
   2. the timed region: barrier + synchronize, EXACTLY K steps, barrier + synchronize; MAX over
      ranks; ms_per_step = elapsed / K.  One pre-created, pre-recorded HIP event marks each step
-     boundary inside the region (ms_per_step_median/min/max: an outlier step is visible).
+     boundary inside the region (ms_per_step_median/min/max: an outlier step is visible).  A region
+     in which one step took > 10x the median step (a single ~40 ms stall hits a run on this pool
+     now and then, whatever is running) is timed again, at most twice; every attempt is listed in
+     "timed_attempts" and the reported one is the first without such a step.
   3. AFTER the timed region, a separate pass brackets every GEMM launch with HIP events on the
      launch stream ("roofline", sampled_in = "separate pass after the timed region").  A roofline
      that contradicts the timed region (share of step > 1, launch longer than a step) is not
@@ -176,7 +179,38 @@ def settle(run_step):
                     "first_chunk_ms_per_step": times[0], "last_chunks_ms_per_step": times[-3:]}
 
 
-def timed_region(run_step, steps, sync, step_events):
+STALL_FACTOR = 10.0     # a step this many times longer than the region's median step is an external stall
+MAX_ATTEMPTS = 3
+
+
+def timed_region(run_step, steps, sync, step_events, attempts=None, world=1):
+    """The timed region, repeated (at most MAX_ATTEMPTS times) while a step inside it took more than STALL_FACTOR x the
+    region's median step.  Why: on this pool a single ~40 ms stall hits a run now and then -- round 1's driver line
+    (37 ms inside one GEMM launch's bracket, every other step normal) and a round-2 run of the fp32 leg (48 ms for 20
+    steps that take 7.7) -- unrelated to the step being timed.  Every attempt is listed in the JSON line
+    ("timed_attempts"); the reported value is the first attempt without such a step (the last one if all have one).
+    With N > 1 all ranks must agree on repeating: the decision is all-reduced (MAX)."""
+    while True:
+        elapsed, per_step = _timed_region_once(run_step, steps, sync, step_events)
+        stalled = False
+        rec = {"ms_per_step": elapsed / steps * 1e3}
+        if per_step:
+            srt = sorted(per_step)
+            rec["max_step_ms"], rec["median_step_ms"] = srt[-1], srt[len(srt) // 2]
+            stalled = srt[-1] > STALL_FACTOR * srt[len(srt) // 2]
+        if world > 1:
+            import torch.distributed as dist
+            flag = torch.tensor([1.0 if stalled else 0.0], device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            stalled = bool(flag.item() > 0)
+        rec["stall"] = stalled
+        if attempts is not None:
+            attempts.append(rec)
+        if not stalled or (attempts is not None and len(attempts) >= MAX_ATTEMPTS) or attempts is None:
+            return elapsed, per_step
+
+
+def _timed_region_once(run_step, steps, sync, step_events):
     """barrier + synchronize, EXACTLY ``steps`` steps, barrier + synchronize.  Returns (elapsed seconds, per-step ms)."""
     marks = _recorded_events(steps + 1) if step_events else None
     sync()
@@ -270,7 +304,8 @@ def forward_leg(args, bnn_amd, ops, net, x, sync, precision, world):
                 out, kl = step()
             run = graph.replay
         leg["settle"] = settle(run)
-        elapsed, per_step = timed_region(run, args.steps, sync, not args.no_step_events)
+        leg["attempts"] = []
+        elapsed, per_step = timed_region(run, args.steps, sync, not args.no_step_events, leg["attempts"], world)
         if not args.graph:
             out, kl = step()
         sync()
@@ -311,7 +346,8 @@ def train_leg(args, bnn_amd, net, x, sync, world, rank):
     sync()
     st = settle(step)
     steps = max(5, min(args.steps, 50))
-    elapsed, per_step = timed_region(step, steps, sync, not args.no_step_events)
+    attempts = []
+    elapsed, per_step = timed_region(step, steps, sync, not args.no_step_events, attempts, world)
     loss = step()
     sync()
     assert torch.isfinite(loss)
@@ -323,7 +359,7 @@ def train_leg(args, bnn_amd, net, x, sync, world, rank):
     res = {"what": "data-parallel training step (eager): ELBO forward, HIP backward, one flat fp32 gradient bucket "
                    "all-reduced over RCCL (%d elements), bnn_amd.optim.Adam" % dp.bucket_numel(),
            "value": x.shape[0] * world * steps / elapsed, "unit": "samples/s", "steps": steps,
-           "ms_per_step": elapsed / steps * 1e3, "settle": st,
+           "ms_per_step": elapsed / steps * 1e3, "settle": st, "timed_attempts": attempts,
            "bucket_bytes": dp.bucket_numel() * 4, "collective": dp.describe_collective()}
     step_stats(res, per_step)
     return res
@@ -397,7 +433,7 @@ def main():
                                    "training-mode ELBO forward (activations + log_softmax + kl), in-kernel Philox noise" % B,
                        "global_batch": B * world, "parallelism": "dp%d (replicated parameters, no forward collective)" % world},
             "gflop_per_step_algorithmic": 4.0 * B * sum_io / 1e9,
-            "settle": main_leg["settle"],
+            "settle": main_leg["settle"], "timed_attempts": main_leg["attempts"],
         }
         step_stats(res, main_leg["per_step"])
         if main_leg["events"]:
@@ -410,7 +446,8 @@ def main():
             leg = legs["fp32"]
             sec = {"dtype": "f32", "what": "the same step with the exact-fp32 MFMA GEMM (reference precision), same process",
                    "value": total / leg["elapsed"], "unit": "samples/s", "steps": args.steps,
-                   "ms_per_step": leg["elapsed"] / args.steps * 1e3, "settle": leg["settle"]}
+                   "ms_per_step": leg["elapsed"] / args.steps * 1e3, "settle": leg["settle"],
+                   "timed_attempts": leg["attempts"]}
             step_stats(sec, leg["per_step"])
             if leg["events"]:
                 roof, why = roofline_object(leg["events"], "fp32", sec["ms_per_step"], sampled_in)

@@ -53,6 +53,7 @@ extern "C" {
 #define LBBNN_STREAM_EPS_Z2 2
 #define LBBNN_STREAM_EPS_ACT 3
 #define LBBNN_STREAM_MASK 6    /* Bernoulli(0.5) masks of the dense flows (lbbnn_dense_layer_t::draw_masks) */
+#define LBBNN_STREAM_ROW_MASK 7 /* per-row masks of lbbnn_flow_dense_rows (stream id = 7*64 + layer id by convention)  */
 
 /* Prior constants of one layer.  The reference keeps them as constant tensors:
  * LBBNN-GP-MF-LRT.py:142-143,151,159-160; LBBNN-GP-MF-MNF.py:145-146,154,162-163. */
@@ -493,6 +494,13 @@ typedef struct lbbnn_flow_chain {
 int lbbnn_flow_chain(const lbbnn_flow_chain_t* chain, const float* z_in, const float* q0_mean,
                      const float* q0_log_var, const float* eps, const uint64_t* rng, uint32_t rng_stream, int I,
                      float* z_out, float* logdet, float* log_q0, float* z_last, void* stream);
+/* The same chain applied to each of the R rows of z_in (R, row stride ldz) independently -- workgroup r carries row r:
+ * z_out (R, row stride ldo; may alias z_in), logdet_rows (R, nullable).  This is the row-wise restatement SURVEY.md 8(a) F1
+ * defines for a 2-D z (flows2.PropagateFlow itself raises on a 2-D z for planar / Householder / Sylvester / mixed flows:
+ * torch.dot, flows2.py:87,129; its Radial transform takes ONE norm over all rows, flows2.py:61 -- not reproduced here). */
+int lbbnn_flow_chain_rows(const lbbnn_flow_chain_t* chain, const float* z_in, int ldz, int R, int I,
+                          float* z_out, int ldo, float* logdet_rows, void* stream);
+
 
 /* lbbnn_output_grad -- the (B,O) elementwise head of the layer backward in one pass (LBBNN-GP-MF-LRT.py:172-175 read
  * backwards):   G_m = g_out (.) [out > 0 if relu],   G_v = G_m * eps / (2 std)     (std = sqrt(var_b) of the forward)
@@ -585,6 +593,31 @@ int lbbnn_flow_dense_apply(const lbbnn_dense_transform_t* tr, int T, int which_m
 int lbbnn_flow_dense_apply_backward(const lbbnn_dense_transform_t* tr, const lbbnn_dense_grad_t* grads, int T,
                                     int which_mask, const float* z_in, const float* d_zout, const float* d_logdet, int I,
                                     float* dz_in, float* work, void* stream);
+
+/* lbbnn_flow_dense_rows -- the same coupling flows applied to R ROWS at once (each row with its own Bernoulli mask per
+ * transform), the dense affine steps on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32).  This is the as-written form
+ * of `sample_z(batch_size)` (LBBNN-GP-MF-MNF.py:182-187: z_flow on a (B,I) matrix of which only the last row is kept -- the
+ * layer kernels above compute that row alone) and what the stand-alone `PropagateFlow('RNVP'|'MNF').forward(z)` of
+ * flows2.py:41-46,206-219,233-241 computes for a 1-D or (R,I) z.
+ *   z_out (R, row stride ldo)  = f_T(... f_1(z_in))  row by row; may alias z_in
+ *   logdet_rows (R), nullable  = sum_t sum_i (1 - m) log gate   (RNVP's log_det is this per-row vector, flows2.py:218-219;
+ *                                the MNF type's is its sum over ALL rows, flows2.py:240-241: the caller adds the R values)
+ *   masks [T][R][I] in {0,1}, or NULL: Bernoulli(0.5) drawn in-kernel from Philox (rng = {seed, offset}, stream
+ *   rng_stream, counter = (row_base + row, t, i/4)); mask_out (nullable, [T][R][I]) receives the masks used.
+ * The mask_fwd / mask_kl fields of the transforms are ignored.  One launch: a 256-thread workgroup carries 16 rows through
+ * the whole chain with z resident in LDS.  I <= lbbnn_flow_dense_rows_max_dim() (LDS capacity; LBBNN_E_SHAPE otherwise).
+ * Deterministic (fixed-order sums, no atomics). */
+/* lbbnn_q0_rows -- the R-row z0 of sample_z(batch_size = R) (LBBNN-GP-MF-MNF.py:183-185):
+ *   z0[r][i] = q0_mean[i] + exp(q0_log_var[i])^(1/2) * eps[r][i],   z0 (R,I) dense rows
+ * eps (R,I) explicit, or NULL: N(0,1) from Philox stream rng_stream with counter (i/4, R-1-r) -- the last row's draw is
+ * the draw the fused layer kernels make for the kept row, so both forms see the same z there. */
+int lbbnn_q0_rows(const float* q0_mean, const float* q0_log_var, const float* eps, const uint64_t* rng,
+                  uint32_t rng_stream, int R, int I, float* z0, void* stream);
+int lbbnn_flow_dense_rows_max_dim(void);
+int lbbnn_flow_dense_rows(const lbbnn_dense_transform_t* tr, int T, const float* masks, float* mask_out,
+                          const uint64_t* rng, uint32_t rng_stream, uint64_t row_base,
+                          const float* z_in, int ldz, int R, int I,
+                          float* z_out, int ldo, float* logdet_rows, void* stream);
 
 /* lbbnn_mnf_flow_dense_backward -- the vector-sized backward (cf. lbbnn_mnf_flow_planar_backward) for a layer whose flows are dense coupling flows
  * (RNVP / MNF type, flows2.py:188-241; the reference's default).  Inputs as lbbnn_mnf_flow_planar_backward; the

@@ -66,4 +66,14 @@ def rel_err(a, b):
     return float((a - b).abs().max() / denom)
 
 
+def elementwise_violation(a, b, rtol=1e-4, atol_frac=1e-6):
+    """Element-wise form of the parity bar: the worst value of |a-b| / (atol + rtol |b|) with
+    atol = atol_frac * max|b| -- <= 1 means torch.allclose(a, b, rtol, atol) holds.  Unlike rel_err (a global norm) a
+    small-magnitude element cannot hide behind the largest one beyond the stated atol."""
+    a = torch.as_tensor(a, dtype=torch.float64).cpu()
+    b = torch.as_tensor(b, dtype=torch.float64).cpu()
+    atol = atol_frac * float(b.abs().max().clamp_min(1e-30))
+    return float(((a - b).abs() / (atol + rtol * b.abs())).max())
+
+
 requires_gpu = pytest.mark.gpu

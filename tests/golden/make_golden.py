@@ -426,6 +426,51 @@ def gen_base():
     print("base.npz", sum(v.nbytes for v in store.values()) // 1024, "KB raw")
 
 
+def gen_base_elbo():
+    """BayesianNetwork.sample_elbo of LBBNN-GP-MF.py:285-319 (784-400-600-10, B = 100, SAMPLES = 1, NUM_BATCHES = 600) at
+    SURVEY.md 8c's anchor: manual_seed(0) -> construct -> x = rand(100,1,28,28), t = randint(0,10,(100,)).  The parameters
+    are NOT stored (2.2 M floats): seeded construction reproduces them (tests/test_host_logic.py pins that on the layer
+    goldens) and float64 checksums of each are; the recorded draws (relaxed gates, N(0,1) for W and b, Gamma taus) are."""
+    ns = load_classes("LBBNN-GP-MF.py", ("Gaussian", "Bernoulli", "GaussGamma", "BetaBinomial", "BayesianLinear",
+                                         "BayesianNetwork"),
+                      dict(TEMPER_PRIOR=0.001, SAMPLES=1, BATCH_SIZE=100, CLASSES=10, NUM_BATCHES=600))
+    torch.manual_seed(0)
+    net = ns["BayesianNetwork"]()
+    x = torch.rand(100, 1, 28, 28)
+    t = torch.randint(0, 10, (100,))
+    net.train()
+    store = {}
+    for li, l in enumerate((net.l1, net.l2, net.l3)):
+        for k, v in l.state_dict().items():
+            put(store, "elbo", **{"sum.l%d.%s" % (li + 1, k): np.float64(v.double().sum().item()),
+                                  "abs.l%d.%s" % (li + 1, k): np.float64(v.double().abs().sum().item())})
+    # the relaxed-Bernoulli gates are drawn through torch.distributions directly (:115): record them by wrapping rsample
+    gates = []
+    for l in (net.l1, net.l2, net.l3):
+        orig = l.gamma.rsample
+
+        def rec(orig=orig):
+            g = orig()
+            gates.append(g.detach().clone())
+            return g
+        l.gamma.rsample = rec
+    REC.clear()
+    loss, log_prior, log_q, nll = net.sample_elbo(x, t)
+    nrm, gam = REC.take("normal"), REC.take("gamma")
+    assert [tuple(g.shape) for g in gates] == [(400, 784), (600, 400), (10, 600)]
+    assert [tuple(n.shape) for n in nrm] == [(400, 784), (400,), (600, 400), (600,), (10, 600), (10,)]
+    assert [tuple(n.shape) for n in gam] == [(1,), (400,), (1,), (600,), (1,), (10,)]
+    put(store, "elbo", x=x, target=t, loss=loss, log_prior=log_prior, log_q=log_q, nll=nll,
+        num_batches=np.float32(600.0))
+    for li in range(3):
+        put(store, "elbo", **{"l%d.cgamma" % (li + 1): gates[li], "l%d.eps_w" % (li + 1): nrm[2 * li],
+                              "l%d.eps_b" % (li + 1): nrm[2 * li + 1], "l%d.tau_w" % (li + 1): gam[2 * li],
+                              "l%d.tau_b" % (li + 1): gam[2 * li + 1]})
+    print("base_elbo anchor: loss %.5f log_prior %.2f log_q %.2f nll %.4f" % (float(loss), float(log_prior), float(log_q), float(nll)))
+    np.savez_compressed(os.path.join(HERE, "base_elbo.npz"), **store)
+    print("base_elbo.npz", sum(v.nbytes for v in store.values()) // 1024, "KB raw")
+
+
 # ----------------------------------------------------------------------------- variational dropout
 def gen_vd():
     ns = load_classes("variational_dropout.py", ("BayesianLayer",), dict(device="cpu"))
@@ -461,4 +506,5 @@ if __name__ == "__main__":
     gen_flows()
     gen_flows_misc()
     gen_base()
+    gen_base_elbo()
     gen_vd()

@@ -151,6 +151,37 @@ def test_base_layer(golden, case):
     assert rel_err(out, c["out_mean"]) < TOL
 
 
+def test_base_network_sample_elbo_anchor(golden):
+    """The reference's BayesianNetwork.sample_elbo (LBBNN-GP-MF.py:285-319) at SURVEY.md 8c's anchor -- manual_seed(0),
+    784-400-600-10, B = 100: loss 2736.66748, log_prior -689876.94, log_q 707226.31, nll 408.1622 -- recorded in
+    tests/golden/base_elbo.npz together with every draw.  Parameters are not stored: the build's own seeded construction
+    must reproduce the reference's (checked through float64 checksums), then the oracle chain must give the scalars."""
+    import bnn_amd
+    c = golden("base_elbo.npz").case("elbo")
+    torch.manual_seed(0)
+    net = bnn_amd.base.BayesianNetwork()                      # reference dims; constructed on the CPU, never run there
+    h = c["x"].view(-1, 784)
+    lps, lqs = [], []
+    for li, l in enumerate((net.l1, net.l2, net.l3)):
+        p = {k: v.detach() for k, v in l.state_dict().items()}
+        for k, v in p.items():
+            assert abs(float(v.double().sum()) - float(c["sum.l%d.%s" % (li + 1, k)])) <= 1e-9 * float(c["abs.l%d.%s" % (li + 1, k)]) + 1e-12, k
+        noise = {k: c["l%d.%s" % (li + 1, k)] for k in ("eps_w", "eps_b", "tau_w", "tau_b")}
+        h, lp, lq = orc.base_forward(h, p, c["l%d.cgamma" % (li + 1)], noise, mode="sample")
+        if li < 2:
+            h = torch.relu(h)
+        lps.append(lp)
+        lqs.append(lq)
+    nll = torch.nn.functional.nll_loss(torch.log_softmax(h, 1), c["target"], reduction="sum")
+    lp, lq = sum(lps), sum(lqs)
+    loss = nll + (lq - lp) / float(c["num_batches"])
+    assert abs(float(c["loss"]) - 2736.66748) < 1e-3 and abs(float(c["nll"]) - 408.1622) < 1e-3      # SURVEY.md 8c
+    assert rel_err(nll, c["nll"]) < 1e-5
+    assert rel_err(lp, c["log_prior"]) < 1e-5
+    assert rel_err(lq, c["log_q"]) < 1e-5
+    assert rel_err(loss, c["loss"]) < 1e-5
+
+
 # --------------------------------------------------------------------------- variational dropout
 @pytest.mark.parametrize("case", ["c0", "c1", "c2"])
 def test_vd_layer(golden, case):
