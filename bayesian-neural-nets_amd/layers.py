@@ -534,6 +534,8 @@ class _BayesLinearBase(nn.Module):
         params = self._param_list()
         try:
             if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
+                if getattr(self, "as_written", False):
+                    raise RuntimeError("bnn_amd: as_written is a no-grad (evaluation / timing) mode")
                 out, kl = _BayesLinearFn.apply(self, x, cfg, *params)
             else:
                 self._preflow = None
@@ -855,8 +857,6 @@ class MNFBayesianLinear(_BayesLinearBase):
                 del keep
         if self.as_written:
             # B rows through z_flow, the last one kept (LBBNN-GP-MF-MNF.py:186-187): it replaces the kept-row result above
-            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-                raise RuntimeError("bnn_amd: as_written is a no-grad (evaluation / timing) mode")
             B = int(self._cur_B)
             full_eps = noise.get("eps_z")
             if full_eps is not None and full_eps.numel() != B * self.in_features:

@@ -559,7 +559,72 @@ def test_mnf_layer_dense_flows_vs_golden(bnn, dev, golden, case):
         out = layer(x, sample=True)
         assert torch.isfinite(out).all() and torch.isfinite(layer.kl)
         z, ld = layer.sample_z(B)
-        assert z.shape == (I,) and torch.isfinite(z).all() and torch.isfinite(ld)
+        assert z.shape == (I,) and torch.isfinite(z).all() and torch.isfinite(ld).all()
+        assert ld.shape == ((B,) if kind == "RNVP" else ()) and layer.z.shape == (B, I)     # …MNF.py:185-187, flows2.py:219,241
+
+
+@pytest.mark.parametrize("case", ["c0", "c1", "c4", "c5", "c6", "c7"])
+def test_sample_z_and_forward_as_written_vs_golden(bnn, dev, golden, case):
+    """``sample_z(batch_size)`` AS WRITTEN (LBBNN-GP-MF-MNF.py:182-187): all batch_size rows through z_flow, z0 kept in
+    ``self.z``, (zs[-1], logdet.squeeze()) returned with the reference's logdet shape -- against the oracle's restatement on
+    the reference layer's recorded (B,I) draws and masks; then ``as_written = True``: the layer forward whose z comes from
+    that B-row flow must give the reference layer's recorded output like the default kept-row forward does."""
+    c = golden("mnf.npz").case(case)
+    B, I, O, T = [int(v) for v in c["shape"]]
+    kind = str(c["kind"]) if "kind" in c else "Planar"
+    p = sub(c, "p.")
+    layer = _load_layer(bnn.mnf.BayesianLinear(I, O, T, z_flow_type=kind, r_flow_type=kind), p, dev).train()
+    dense = kind in ("RNVP", "MNF")
+    eps_z = c["eps_z"]
+    assert tuple(eps_z.shape) == (B, I)
+    masks = [c["zmask%d" % t] for t in range(T)] if dense else None
+    layer.noise = {"eps_z": eps_z.to(dev)}
+    if dense:
+        layer.noise["zmask"] = [m.to(dev) for m in masks]
+    z, ld = layer.sample_z(B)
+    zr, ldr, z0r = orc.mnf_sample_z(p, eps_z, orc.flow_from_state("z_flow", kind, p, T), masks)
+    assert z.shape == zr.shape and rel_err(z, zr) < TIGHT
+    assert ld.shape == ldr.shape and float((ld.cpu() - ldr).abs().max()) < 1e-6 + 2e-5 * float(ldr.abs().max())
+    assert layer.z.shape == (B, I) and rel_err(layer.z, z0r) < TIGHT
+    # the forward, both ways
+    n = {k: c[k].to(dev) for k in ("eps_z", "eps_out", "eps_z2", "eps_act")}
+    if dense:
+        n["zmask"] = [c["zmask%d" % t].to(dev) for t in range(T)]
+        n["zmask2"] = [c["zmask2_%d" % t].to(dev) for t in range(T)]
+        n["rmask"] = [c["rmask%d" % t].to(dev) for t in range(T)]
+    layer.noise = n
+    with torch.no_grad():
+        ref_path = layer(c["x"].to(dev), sample=True)
+        kl_kept = layer.kl.clone()
+        layer.as_written = True
+        out = layer(c["x"].to(dev), sample=True)
+    assert rel_err(out, c["out_train"]) < TIGHT and rel_err(layer.kl, c["kl"]) < TIGHT
+    assert rel_err(out, ref_path) < TIGHT and torch.equal(layer.kl, kl_kept)
+    with pytest.raises(RuntimeError):
+        layer(c["x"].to(dev).requires_grad_(True), sample=True)            # as_written is an evaluation / timing mode
+
+
+def test_as_written_layers_in_kernel_noise_match_kept_row_path(bnn, dev):
+    """Planar flows, in-kernel Philox noise, the headline layer sizes at B = 512: the as-written B-row z flow draws the
+    kept row's eps from the same counters as the fused kept-row kernel, so both forwards of a layer agree (to rounding:
+    the row kernel sums in another order) -- the discarded B-1 rows change nothing, as in the reference."""
+    torch.manual_seed(13)
+    net = bnn.mnf.BayesianNetwork((784, 1200, 1200, 10), 2, z_flow_type="Planar", r_flow_type="Planar").to(dev).train()
+    x = torch.rand(512, 784, device=dev)
+    with torch.no_grad():
+        for l in (net.l1, net.l2, net.l3):
+            l.as_written = False
+            bnn.manual_seed(7, 0)
+            a = l(x, sample=True).clone()
+            kl_a = l.kl.clone()
+            l.as_written = True
+            bnn.manual_seed(7, 0)
+            b = l(x, sample=True)
+            assert rel_err(b, a) < 2e-5 and rel_err(l.kl, kl_a) < 1e-6
+            x = torch.relu(a)
+        # and the network runs with every layer in that mode
+        out = net(torch.rand(512, 784, device=dev), sample=True)
+        assert torch.isfinite(out).all() and torch.isfinite(net.kl())
 
 
 def test_dense_flow_backward_matches_oracle_autograd(bnn, dev, golden):
@@ -1345,7 +1410,7 @@ def test_propagate_flow_dense_standalone_vs_reference_golden(bnn, dev, golden, c
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,R,I,T", [("RNVP", 4096, 1200, 2), ("MNF", 4096, 784, 2), ("RNVP", 37, 50, 3), ("MNF", 1, 7, 1),
-                                        ("RNVP", 16, 2048, 1)])
+                                        ("RNVP", 16, 1760, 1)])
 def test_flow_dense_rows_in_kernel_masks_vs_oracle(bnn, dev, kind, R, I, T):
     """The as-written row mode at the headline size (B = 4096 rows, I = 1200 / 784; SURVEY.md section 7 'R = B') and odd
     shapes: masks drawn in-kernel (Philox), returned, and fed to the oracle's row-batched restatement."""
