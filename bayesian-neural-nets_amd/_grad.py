@@ -4,11 +4,10 @@ What still enters here from ``autograd.Function.backward`` (never from a forward
   * layers whose flows are 1-D chains (Radial / Householder / Sylvester / mixed): ``mnf_vector_graph`` over (I,) / (O,)
     vectors, with the noise the forward kernels drew re-created by ``lbbnn_philox_normal``;
   * the LRT layer's two bias terms (``lrt_vector_graph``);
-  * the baseline LBBNN and variational-dropout layers (``base_torch`` and friends);
+  * the baseline LBBNN layer (``base_torch``) -- the variational-dropout layer's backward is all HIP since round 2;
   * RNVP / MNF-type layers only when ``LBBNN_DENSE_TORCH_BWD=1`` asks for it (A/B timing, second opinion in tests).
 Everything (O,I)- or (B,O)-sized -- and, for planar and dense-flow MNF layers, every vector-sized gradient too -- is
-computed by the HIP kernels (``layers._BayesLinearFn.backward``).  The whole-layer functions at the end
-(``lrt_torch``, ``mnf_planar_torch``) are kept as cross-checks for the tests.
+computed by the HIP kernels (``layers._BayesLinearFn.backward``).
 """
 import math
 
@@ -311,8 +310,3 @@ def base_torch(x, cgamma, tau_w, tau_b, P, noise, *, mode, want_lp, exact, alpha
         qb = (-math.log(math.sqrt(2 * math.pi)) - torch.log(sb) - (bias - P["bias_mu"]) ** 2 / (2 * sb ** 2)).sum()
         lq = full + bern + qb
     return out, lp, lq
-
-
-def vd_torch(x, theta, alpha, zeta):
-    """variational_dropout.py:63-68."""
-    return x @ theta + torch.sqrt((x ** 2) @ (theta ** 2) * alpha) * zeta

@@ -107,7 +107,8 @@ MAX_DENSE_T = 8
 class OutGradArgs(ctypes.Structure):
     """lbbnn_outgrad_args_t"""
     _fields_ = [(n, c_p) for n in ("g_out", "out", "std", "eps", "rng", "gm", "gv", "gmT", "gvT", "g_sum", "gv_sum", "work")] + \
-               [("row_offset", c_i64), ("rng_stream", c_u32)] + [(n, c_i) for n in ("B", "O", "ldg", "ldo", "relu")]
+               [("row_offset", c_i64), ("rng_stream", c_u32)] + [(n, c_i) for n in ("B", "O", "ldg", "ldo", "relu")] + \
+               [("gv_scale", c_p)]
 
 
 class FlowStep(ctypes.Structure):
@@ -172,6 +173,7 @@ SIGNATURES = {
     "lbbnn_flow_dense_rows_max_dim": (c_i, []),
     "lbbnn_flow_dense_rows": (c_i, [ctypes.POINTER(DenseTransform), c_i, c_p, c_p, c_p, c_u32, c_u64, c_p, c_i, c_i, c_i,
                                     c_p, c_i, c_p, c_p]),
+    "lbbnn_format_operand": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p]),
     "lbbnn_multi_copy": (c_i, [ctypes.POINTER(CopyList), c_p]),
     "lbbnn_adam_step": (c_i, [ctypes.POINTER(AdamList), ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                               ctypes.c_float, c_p, c_i, c_p]),
@@ -197,6 +199,12 @@ SIGNATURES = {
     "lbbnn_layers_operands_snap": (c_i, [ctypes.POINTER(LayerDesc), c_i, c_p, c_p, c_u64, c_p]),
     "lbbnn_lrt_gemm_finalize": (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_u32, c_i64,
                                       c_p, c_i, c_p, c_i, c_i, c_i, c_i, ctypes.POINTER(LayerDesc), c_i, c_p, c_p, c_p]),
+    "lbbnn_lrt_gemm_finalize_adv": (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_u32, c_i64,
+                                          c_p, c_i, c_p, c_i, c_i, c_i, c_i, ctypes.POINTER(LayerDesc), c_i, c_p, c_p,
+                                          c_p, c_u64, c_p]),
+    "lbbnn_ensemble_operands": (c_i, [ctypes.POINTER(LayerDesc), c_i, c_i, c_p, c_u64, c_p]),
+    "lbbnn_lrt_gemm_members": (c_i, [c_p, c_i, c_i64, c_p, c_i64, c_p, c_i, c_p, c_p, c_p, c_u32, c_i64, c_u64,
+                                     c_p, c_i, c_i64, c_i, c_i, c_i, c_i, c_i, c_p]),
     "lbbnn_layers_operands": (c_i, [ctypes.POINTER(LayerDesc), c_i, c_p, c_p]),
     "lbbnn_layers_finalize": (c_i, [ctypes.POINTER(LayerDesc), c_i, c_p, ctypes.c_uint64, c_p, c_p]),
     "lbbnn_forward_finish": (c_i, [c_p, c_u64, c_p, c_i, c_p, c_p]),

@@ -203,6 +203,29 @@ __global__ __launch_bounds__(256) void transpose_operand_kernel(const float* __r
 
 }  // namespace
 
+// (R,C) -> operand [R][ld] without a transpose: row r of dst = row r of src (squared if asked), zero tail, fp32 or split.
+// The input-gradient operands of a variational-dropout layer: theta (n,m) IS W^T for dX = G . theta^T.
+__global__ __launch_bounds__(256) void format_operand_kernel(const float* __restrict__ src, int R, int C, int lds_src,
+                                                             void* dst, int ld, int square, int split) {
+    const int r = blockIdx.y;
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < ld; c += gridDim.x * 256) {
+        float v = c < C ? src[(size_t)r * lds_src + c] : 0.f;
+        if (square) v *= v;
+        store_operand(dst, split, R, ld, r, c, v);
+    }
+}
+
+extern "C" int lbbnn_format_operand(const float* src, int R, int C, int lds_src, void* dst, int ld, int square, int flags,
+                                    void* stream) {
+    if (!src || !dst) return LBBNN_E_NULL;
+    if (R <= 0 || C <= 0 || lds_src < C) return LBBNN_E_SHAPE;
+    if (ld < C || (ld & 31)) return LBBNN_E_ALIGN;
+    if (flags & ~LBBNN_F_SPLIT16) return LBBNN_E_FLAGS;
+    hipLaunchKernelGGL(format_operand_kernel, dim3((ld + 1023) / 1024, R), dim3(256), 0, static_cast<hipStream_t>(stream), src, R,
+                       C, lds_src, dst, ld, square ? 1 : 0, (flags & LBBNN_F_SPLIT16) ? 1 : 0);
+    return (int)hipGetLastError();
+}
+
 extern "C" int lbbnn_transpose_operand(const float* src, int R, int C, int lds_src, void* dst, int ld,
                                        int square, int flags, void* stream) {
     if (!src || !dst) return LBBNN_E_NULL;

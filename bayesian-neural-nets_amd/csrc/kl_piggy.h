@@ -99,6 +99,8 @@ __device__ __forceinline__ void kl_finalize_piggy(const LBBNN_CONST_AS FinalizeP
         __syncthreads();                                         // the next layer restages sm
     }
     if (t == 0 && A.total) *A.total = total;
+    // the forward's RNG advance (lbbnn_lrt_gemm_finalize_adv): no kernel of this launch reads the LIVE offset
+    if (t == 0 && A.rng_adv) A.rng_adv[1] += A.adv;
 }
 
 }  // namespace lbbnn

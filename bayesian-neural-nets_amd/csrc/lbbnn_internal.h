@@ -30,6 +30,17 @@ struct FlowArgs {
     int I; int want_kl; uint32_t layer;
 };
 
+// In-kernel planar flows of one layer for the row kernel of the weight pass (weight_pass.hip): Tz + Tr <= 4 transforms,
+// z flow first.  on == 0: the layer's z vectors (if any) come from memory (WeightPassArgs::z_fwd / z_kl).
+struct InFlow {
+    const float* q0_mean; const float* q0_log_var; const float* eps_fwd; const float* eps_kl;
+    const uint64_t* rng;
+    float* z_fwd; float* z_kl; float* scal;
+    const float* u[4]; const float* w[4]; const float* b[4];
+    int Tz, Tr, want_kl, on;
+    uint32_t layer;
+};
+
 struct FinalizeArgs {
     const float* kl_rows; const float* bias_mu; const float* bias_rho;
     const float* act_mu; const float* act_var; const float* eps_act;
@@ -41,7 +52,8 @@ struct FinalizeArgs {
 };
 
 // K5 of up to LBBNN_MAX_LAYERS layers + their total, as carried by a GEMM launch (lbbnn_lrt_gemm_finalize)
-struct FinalizePiggy { FinalizeArgs l[LBBNN_MAX_LAYERS]; int active[LBBNN_MAX_LAYERS]; int n; float* total; };
+struct FinalizePiggy { FinalizeArgs l[LBBNN_MAX_LAYERS]; int active[LBBNN_MAX_LAYERS]; int n; float* total;
+                       uint64_t* rng_adv; uint64_t adv; };     // rng_adv != NULL: the piggy workgroup also does rng_adv[1] += adv
 
 // Select element `idx` of a by-value kernel-argument array WITHOUT dynamic indexing: a runtime index into a
 // kernarg struct array makes hipcc copy the array to scratch memory (measured: 64 B/lane of scratch in K1);
@@ -62,8 +74,13 @@ LBBNN_HIDDEN int make_weight_pass_args(WeightPassArgs& a, const float* mu, const
                                        float* kl_rows, float* act_mu, float* act_var, float* bias_var, int O, int I,
                                        int split = 0);
 LBBNN_HIDDEN int launch_weight_pass(const WeightPassArgs* a, int n, hipStream_t s, uint64_t* rng = nullptr,
-                                    uint64_t* rng_snap = nullptr, uint64_t advance = 0);
-LBBNN_HIDDEN int launch_flow_planar(const FlowArgs* a, int n, hipStream_t s);
+                                    uint64_t* rng_snap = nullptr, uint64_t advance = 0, const InFlow* flows = nullptr,
+                                    int members = 1);
+// planar flows of a layer computed inside the weight pass's workgroups instead of by launch_flow_planar (advance must be 0)
+LBBNN_HIDDEN bool in_flow_eligible(const FlowArgs& f, const WeightPassArgs& w);
+LBBNN_HIDDEN void make_in_flow(InFlow& o, const FlowArgs& f);
+LBBNN_HIDDEN int launch_flow_planar(const FlowArgs* a, int n, hipStream_t s, int members = 1, unsigned long long m_adv = 0,
+                                    long long z_ms = 0);
 LBBNN_HIDDEN int launch_kl_finalize_all(const FinalizeArgs* a, const int* active, int n, uint64_t* rng, uint64_t advance,
                                         float* kl_total, hipStream_t s);
 LBBNN_HIDDEN int launch_kl_finalize(const FinalizeArgs* a, int n, hipStream_t s);

@@ -53,16 +53,45 @@ struct GemmArgs {
     // lbbnn_lrt_gemm_finalize: fin.n > 0 => the grid has one extra row of workgroups (blockIdx.y == gridDim.y - 1) whose
     // first workgroup does the KL finalize of the network (kl_piggy.h) while the tiles are computed; the rest of the row exits
     FinalizePiggy fin;
+    // lbbnn_lrt_gemm_members: gridDim.z = members; member m = blockIdx.z is the same product on x + m*x_ms, e_w + m*w_ms
+    // (var_w shared), out + m*o_ms, its noise drawn at Philox offset rng[1] + m*m_adv -- an ensemble of forwards
+    // (test_ensemble, LBBNN-GP-MF-MNF.py:286-294) in one launch, every member bit-identical to its own launch
+    int members;
+    long long x_ms, w_ms, o_ms;
+    unsigned long long m_adv, m_off;     // m_off: filled in by member_view()
 };
 
-// XCD-aware tile assignment (cdna guide T1).  Workgroups are dealt round-robin over the 8 XCDs, each with
-// its own L2; with the natural order the 15 workgroups that share one x tile land on 8 different L2s.
-// Remap the linear id so that each XCD owns a contiguous run of tiles in (b-tile major, o-tile minor)
-// order: an XCD then works on ~4 x tiles x all W tiles and every x tile is fetched into ONE L2.
-// Bijective when the grid size is a multiple of 8 (identity otherwise).  Speed only, never correctness.
+__device__ __forceinline__ GemmArgs member_view(const GemmArgs& in) {
+    GemmArgs a = in;
+    a.m_off = 0;
+    if (in.members > 1) {
+        const long long m = blockIdx.z;
+        a.x = in.x + m * in.x_ms; a.e_w = in.e_w + m * in.w_ms; a.out = in.out + m * in.o_ms;
+        a.m_off = (unsigned long long)m * in.m_adv;
+    }
+    return a;
+}
+
+// XCD-aware tile assignment (cdna guide T1).  Workgroups are dealt round-robin over the 8 XCDs, each with its own L2;
+// with the natural order the 15 workgroups that share one x tile land on 8 different L2s.  The linear id is remapped
+// so that an XCD owns a 2-D block of the tile grid: the b tiles are cut into 4 groups, each group's tiles (o-major
+// order) into two halves -- XCD (bg, half) then fetches a QUARTER of the x tiles and HALF of the weight tiles into its
+// L2 (fabric traffic 4 W + 2 x per launch; a contiguous b-major run per XCD, the round-1 map, streams ALL weight tiles
+// through every L2: 8 W + x = 113 MB at the 1200 x 1200 layer against 86 MB).  Falls back to the b-major run when the
+// b-tile count is not a multiple of 4, and to the identity when the grid is not a multiple of 8.  Bijective in both
+// forms; speed only, never correctness.
 __device__ __forceinline__ void tile_of_block(int& ox, int& by, int extra_rows = 0) {
-    const int nx = gridDim.x, n = gridDim.x * (gridDim.y - extra_rows);
+    const int nx = gridDim.x, ny = gridDim.y - extra_rows, n = nx * ny;
     int t = blockIdx.y * nx + blockIdx.x;
+#ifndef LAB_XCD_1D
+    if ((n & 7) == 0 && (ny & 3) == 0) {
+        const int xcd = t & 7, s = t >> 3, per = n >> 3, q = ny >> 2;      // per: tiles per XCD, q: b tiles per group
+        const int idx = (xcd & 1) * per + s;                              // position inside the b group, o-major
+        ox = idx / q;
+        by = (xcd >> 1) * q + idx % q;
+        return;
+    }
+#endif
     if ((n & 7) == 0) t = (t & 7) * (n >> 3) + (t >> 3);
     ox = t % nx; by = t / nx;
 }
@@ -75,7 +104,7 @@ __device__ __forceinline__ EpiCtx make_epi_ctx(const GemmArgs& a) {
     c.ovec = ((a.O & 3) == 0) && ((a.ldo & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0) &&
              (!a.eps || (reinterpret_cast<uintptr_t>(a.eps) & 15u) == 0);
     c.seed = 0; c.offs = 0;
-    if (!MEAN_ONLY && !a.eps) { c.seed = a.rng[0]; c.offs = a.rng[1]; }
+    if (!MEAN_ONLY && !a.eps) { c.seed = a.rng[0]; c.offs = a.rng[1] + a.m_off; }
     return c;
 }
 
@@ -169,7 +198,8 @@ __device__ __forceinline__ void store4(const GemmArgs& a, const EpiCtx& c, int b
 // Only a K tail (I % 16 != 0) takes the guarded path, and only for the x rows (the weight operands
 // are zero-padded to ld by the weight pass).
 template <int TO, int TB, int WB, bool MEAN_ONLY, bool XVEC>
-__global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_f32_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_f32_kernel(const GemmArgs a_in) {
+    const GemmArgs a = member_view(a_in);
     constexpr int NT = WB * 64;
     constexpr int BN = TO * 16;          // output features per block
     constexpr int BM = TB * WB * 16;     // batch rows per block
@@ -353,7 +383,8 @@ constexpr int DROW = 16;                     // floats per LDS row in the DMA im
 __device__ __forceinline__ int swz(int rowgrp) { return (0x78 >> (2 * (rowgrp & 3))) & 3; }   // F = {0,2,3,1}
 
 template <int TO, int TB, int WB, bool MEAN_ONLY>
-__global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_f32_dma_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_f32_dma_kernel(const GemmArgs a_in) {
+    const GemmArgs a = member_view(a_in);
     constexpr int BN = TO * 16, BM = TB * WB * 16;
     constexpr int NW = MEAN_ONLY ? 1 : 2;
     constexpr int ROWS = BM + NW * BN;
@@ -514,7 +545,8 @@ constexpr int BKS = 32;
 __device__ __forceinline__ int swzx(int r) { return (((r >> 1) & 3) << 1) | ((r >> 3) & 1); }
 
 template <int TO, int TB, int WB, bool MEAN_ONLY>
-__global__ __launch_bounds__(WB * 64, (TB * TO > 10) ? 1 : (WB == 8 ? 4 : 2)) void lrt_gemm_bf16x3_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(WB * 64, (TB * TO > 10) ? 1 : (WB == 8 ? 4 : 2)) void lrt_gemm_bf16x3_kernel(const GemmArgs a_in) {
+    const GemmArgs a = member_view(a_in);
     constexpr int BN = TO * 16, BM = TB * WB * 16;
     constexpr int NWR = MEAN_ONLY ? 1 : 2;               // weight regions: e_w (, var_w); a row = [hi 64 B | lo 64 B]
     constexpr int XB = BM * 128;                         // bytes of the X region
@@ -715,7 +747,8 @@ constexpr int SK_WAVES = 16;
 constexpr int SK_NCH = 5;      // chunks per wave per batch: covers I <= 16*16*5 = 1280 in one batch
 
 template <bool MEAN_ONLY, bool XVEC>
-__global__ __launch_bounds__(SK_WAVES * 64) void lrt_gemm_skinny_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(SK_WAVES * 64) void lrt_gemm_skinny_kernel(const GemmArgs a_in) {
+    const GemmArgs a = member_view(a_in);
     __shared__ __attribute__((aligned(16))) float red[SK_WAVES][2][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int lr = lane & 15, q = lane >> 4;
@@ -843,9 +876,9 @@ inline int launch_one(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s
 template <int TO, int TB, int WB>
 int launch_cfg(GemmArgs& a, bool mean_only, bool xvec, hipStream_t s, bool* hosted) {
     constexpr int BN = TO * 16, BM = TB * WB * 16;
-    dim3 grid((a.O + BN - 1) / BN, (a.B + BM - 1) / BM);
+    dim3 grid((a.O + BN - 1) / BN, (a.B + BM - 1) / BM, a.members > 1 ? a.members : 1);
     dim3 block(WB * 64);
-    const long nblocks = (long)grid.x * grid.y;
+    const long nblocks = (long)grid.x * grid.y * grid.z;
     static const bool no_dma = getenv("LBBNN_GEMM_NO_DMA") != nullptr;     // A/B knob for bench sweeps
     const int fin_n = a.fin.n;
     a.fin.n = 0;
@@ -873,7 +906,8 @@ int launch_cfg(GemmArgs& a, bool mean_only, bool xvec, hipStream_t s, bool* host
 template <int TO, int TB, int WB>
 int launch_split_cfg(GemmArgs& a, bool mean_only, hipStream_t s, bool* hosted) {
     constexpr int BN = TO * 16, BM = TB * WB * 16;
-    dim3 grid((a.O + BN - 1) / BN, (a.B + BM - 1) / BM, a.kchunk ? (a.I + a.kchunk - 1) / a.kchunk : 1);
+    dim3 grid((a.O + BN - 1) / BN, (a.B + BM - 1) / BM,
+              a.kchunk ? (a.I + a.kchunk - 1) / a.kchunk : (a.members > 1 ? a.members : 1));
     dim3 block(WB * 64);
     const long nblocks = (long)grid.x * grid.y * grid.z;
     const size_t l_full = lds_request(2u * (BM * 128 + 2 * BN * 128), nblocks);
@@ -911,7 +945,9 @@ static int lrt_gemm_impl(const float* x, int ldx, const void* e_w, const void* v
                          const float* eps, const uint64_t* rng, uint32_t rng_stream, int64_t row_offset,
                          float* out, int ldo, float* std_out, int B, int I, int O, int flags, void* stream, int kchunk = 0,
                          const FinalizePiggy* fin = nullptr, bool* hosted = nullptr,
-                         const float* comb_x = nullptr, int ld_cx = 0, const float* comb_add = nullptr, int ld_ca = 0) {
+                         const float* comb_x = nullptr, int ld_cx = 0, const float* comb_add = nullptr, int ld_ca = 0,
+                         int members = 1, long long x_ms = 0, long long w_ms = 0, long long o_ms = 0,
+                         unsigned long long m_adv = 0) {
     if (B == 0 && I > 0 && O > 0) return 0;        // empty batch (torch.mm of 0 rows, LBBNN-GP-MF-LRT.py:172): nothing to do
     if (!x || !e_w || !out) return LBBNN_E_NULL;
     if (B <= 0 || I <= 0 || O <= 0 || ldx < I || ldo < O) return LBBNN_E_SHAPE;
@@ -934,6 +970,8 @@ static int lrt_gemm_impl(const float* x, int ldx, const void* e_w, const void* v
     a.kchunk = kchunk; a.split_stride = (long long)B * ldo;
     if (fin) a.fin = *fin; else a.fin = FinalizePiggy{};
     a.comb_x = comb_x; a.comb_add = comb_add; a.ld_cx = ld_cx; a.ld_ca = ld_ca;
+    a.members = members; a.x_ms = x_ms; a.w_ms = w_ms; a.o_ms = o_ms; a.m_adv = m_adv; a.m_off = 0;
+    if (members > 1 && (kchunk || fin || eps || std_out || comb_x)) return LBBNN_E_FLAGS;
 
     const bool xvec = ((I & 3) == 0) && ((ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0);
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -953,7 +991,7 @@ static int lrt_gemm_impl(const float* x, int ldx, const void* e_w, const void* v
 #ifdef LAB_SK_ROWS
         dim3 grid((B + LAB_SK_ROWS - 1) / LAB_SK_ROWS), block(SK_WAVES * 64);
 #else
-        dim3 grid((B + 15) / 16), block(SK_WAVES * 64);
+        dim3 grid((B + 15) / 16, 1, a.members > 1 ? a.members : 1), block(SK_WAVES * 64);
 #endif
         if (mean_only) {
             if (xvec) hipLaunchKernelGGL((lrt_gemm_skinny_kernel<true, true>), grid, block, 0, s, a);
@@ -988,24 +1026,72 @@ extern "C" int lbbnn_lrt_gemm_train(const float* x, int ldx, const void* e_w, co
 }
 
 // lbbnn_lrt_gemm with the KL finalize of a whole network carried by one extra workgroup of the same launch (include/lbbnn.h)
-extern "C" int lbbnn_lrt_gemm_finalize(const float* x, int ldx, const void* e_w, const void* var_w, int ld,
-                                       const float* bias_mean, const float* bias_var, const float* var_scale,
-                                       const float* eps, const uint64_t* rng, uint32_t rng_stream, int64_t row_offset,
-                                       float* out, int ldo, float* std_out, int B, int I, int O, int flags,
-                                       const lbbnn_layer_desc_t* layers, int n, const uint64_t* fin_rng, float* kl_total,
-                                       void* stream) {
+static int gemm_finalize_impl(const float* x, int ldx, const void* e_w, const void* var_w, int ld,
+                              const float* bias_mean, const float* bias_var, const float* var_scale,
+                              const float* eps, const uint64_t* rng, uint32_t rng_stream, int64_t row_offset,
+                              float* out, int ldo, float* std_out, int B, int I, int O, int flags,
+                              const lbbnn_layer_desc_t* layers, int n, const uint64_t* fin_rng, float* kl_total,
+                              uint64_t* rng_live, uint64_t advance, void* stream) {
     if (((flags & LBBNN_F_MEAN_ONLY) || (flags & LBBNN_F_LOG_SOFTMAX)) && std_out) return LBBNN_E_FLAGS;
+    if (n == 0) {
+        // nothing to finalize (a forward without KL): the plain GEMM, then the advance as the tiny launch it is
+        const int rc = lrt_gemm_impl(x, ldx, e_w, var_w, ld, bias_mean, bias_var, var_scale, eps, rng, rng_stream, row_offset,
+                                     out, ldo, std_out, B, I, O, flags, stream, 0);
+        if (rc || !rng_live || !advance) return rc;
+        return lbbnn_rng_advance(rng_live, advance, stream);
+    }
     FinalizePiggy fin{};
     if (const int rc = fill_finalize_args(layers, n, fin_rng, fin.l, fin.active)) return rc;
     if (kl_total) for (int i = 0; i < n; ++i) if (!fin.active[i]) return LBBNN_E_NULL;   // a total needs every layer's KL
     fin.n = n; fin.total = kl_total;
+    fin.rng_adv = advance ? rng_live : nullptr; fin.adv = advance;
     bool hosted = false;
     const int rc = lrt_gemm_impl(x, ldx, e_w, var_w, ld, bias_mean, bias_var, var_scale, eps, rng, rng_stream, row_offset,
                                  out, ldo, std_out, B, I, O, flags, stream, 0, &fin, &hosted);
     if (rc) return rc;
     if (hosted) return 0;
     // this GEMM's kernel cannot host the extra workgroup (small tile configuration, skinny output, LDS): same work, own launch
-    return launch_kl_finalize_all(fin.l, fin.active, n, nullptr, 0, kl_total, static_cast<hipStream_t>(stream));
+    return launch_kl_finalize_all(fin.l, fin.active, n, advance ? rng_live : nullptr, advance, kl_total,
+                                  static_cast<hipStream_t>(stream));
+}
+
+extern "C" int lbbnn_lrt_gemm_finalize(const float* x, int ldx, const void* e_w, const void* var_w, int ld,
+                                       const float* bias_mean, const float* bias_var, const float* var_scale,
+                                       const float* eps, const uint64_t* rng, uint32_t rng_stream, int64_t row_offset,
+                                       float* out, int ldo, float* std_out, int B, int I, int O, int flags,
+                                       const lbbnn_layer_desc_t* layers, int n, const uint64_t* fin_rng, float* kl_total,
+                                       void* stream) {
+    if (n <= 0) return LBBNN_E_SHAPE;
+    return gemm_finalize_impl(x, ldx, e_w, var_w, ld, bias_mean, bias_var, var_scale, eps, rng, rng_stream, row_offset, out, ldo,
+                              std_out, B, I, O, flags, layers, n, fin_rng, kl_total, nullptr, 0, stream);
+}
+
+extern "C" int lbbnn_lrt_gemm_finalize_adv(const float* x, int ldx, const void* e_w, const void* var_w, int ld,
+                                           const float* bias_mean, const float* bias_var, const float* var_scale,
+                                           const float* eps, const uint64_t* rng, uint32_t rng_stream, int64_t row_offset,
+                                           float* out, int ldo, float* std_out, int B, int I, int O, int flags,
+                                           const lbbnn_layer_desc_t* layers, int n, const uint64_t* fin_rng, float* kl_total,
+                                           uint64_t* rng_live, uint64_t advance, void* stream) {
+    if (n < 0 || (n > 0 && !layers)) return LBBNN_E_SHAPE;
+    if (advance && !rng_live) return LBBNN_E_NULL;
+    return gemm_finalize_impl(x, ldx, e_w, var_w, ld, bias_mean, bias_var, var_scale, eps, rng, rng_stream, row_offset, out, ldo,
+                              std_out, B, I, O, flags, layers, n, fin_rng, kl_total, rng_live, advance, stream);
+}
+
+// An ensemble of `members` forwards of one layer in ONE launch (include/lbbnn.h)
+extern "C" int lbbnn_lrt_gemm_members(const float* x, int ldx, int64_t x_mstride, const void* e_w, int64_t w_mstride,
+                                      const void* var_w, int ld, const float* bias_mean, const float* bias_var,
+                                      const uint64_t* rng, uint32_t rng_stream, int64_t row_offset, uint64_t member_advance,
+                                      float* out, int ldo, int64_t o_mstride, int B, int I, int O, int flags, int members,
+                                      void* stream) {
+    if (members < 1 || members > 65535) return LBBNN_E_SHAPE;
+    if (x_mstride < 0 || w_mstride < 0 || o_mstride < (int64_t)B * ldo) return LBBNN_E_SHAPE;
+    if ((x_mstride & 3) || (w_mstride & 3) || (o_mstride & 3)) return LBBNN_E_ALIGN;       // every member 16-B aligned (pad the stride)
+    if (flags & LBBNN_F_SPLIT16)                                                           // 32-bit buffer offsets
+        if (((size_t)(B - 1) * ldx + I) * 4 >= 0x7FFFFFF0u) return LBBNN_E_SHAPE;
+    return lrt_gemm_impl(x, ldx, e_w, var_w, ld, bias_mean, bias_var, nullptr, nullptr, rng, rng_stream, row_offset, out, ldo,
+                         nullptr, B, I, O, flags, stream, 0, nullptr, nullptr, nullptr, 0, nullptr, 0, members,
+                         (long long)x_mstride, (long long)w_mstride, (long long)o_mstride, member_advance);
 }
 
 // Mean-only product with the input-gradient combination in its epilogue (include/lbbnn.h)

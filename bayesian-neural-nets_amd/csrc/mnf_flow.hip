@@ -19,7 +19,9 @@ namespace {
 using namespace lbbnn;
 
 typedef lbbnn_planar_flow_t PlanarSet;
-struct FlowBatch { FlowArgs l[LBBNN_MAX_LAYERS]; };
+struct FlowBatch { FlowArgs l[LBBNN_MAX_LAYERS];
+                   // ensemble (fast kernel only): gridDim.z members, member m draws at offset rng[1] + m*m_adv, writes z_fwd + m*z_ms
+                   unsigned long long m_adv; long long z_ms; };
 struct FinalizeBatch { FinalizeArgs l[LBBNN_MAX_LAYERS]; };
 
 // Apply the T planar transforms of `ps` to the LDS-resident z (flows2.py:86-95); returns sum of log-dets.
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(kFastThreads) void mnf_flow_planar_fast_kernel(cons
         if (tid == 0) s_bias[t] = (t < Tz ? a.zf.b[t] : a.rf.b[t - Tz])[0];
     }
     uint64_t seed = 0, offs = 0;
-    if (!eps) { seed = a.rng[0]; offs = a.rng[1]; }
+    if (!eps) { seed = a.rng[0]; offs = a.rng[1] + (uint64_t)blockIdx.z * kernarg_as<FlowBatch>()->m_adv; }
     const uint32_t stream = (klblk ? LBBNN_STREAM_EPS_Z2 : LBBNN_STREAM_EPS_Z) * 64u + a.layer;
     dma_wait_all();
 #ifdef LAB_STAMPS
@@ -312,7 +314,7 @@ __global__ __launch_bounds__(kFastThreads) void mnf_flow_planar_fast_kernel(cons
         }
     }
     // z after the z flow (the layer's z_k / z2); the r-flow steps only add to the scalar z_b[-1]
-    float* zo = klblk ? a.z_kl : a.z_fwd;
+    float* zo = (klblk ? a.z_kl : a.z_fwd) + (long long)blockIdx.z * kernarg_as<FlowBatch>()->z_ms;
 #pragma unroll 1
     for (int i = tid; i < I; i += kFastThreads) {
         float v = z[i];
@@ -621,15 +623,16 @@ bool fill_set(PlanarSet& ps, const float* const* u, const float* const* w, const
 
 namespace lbbnn {
 
-int launch_flow_planar(const FlowArgs* a, int n, hipStream_t s) {
+int launch_flow_planar(const FlowArgs* a, int n, hipStream_t s, int members, unsigned long long m_adv, long long z_ms) {
     FlowBatch bt;
+    bt.m_adv = m_adv; bt.z_ms = z_ms;
     int maxI = 0; bool small_t = true, any_kl = false;
     for (int i = 0; i < n; ++i) {
         bt.l[i] = a[i];
         maxI = a[i].I > maxI ? a[i].I : maxI;
         any_kl = any_kl || a[i].want_kl;
     }
-    const dim3 grid(any_kl ? 2 : 1, n), block(256);
+    const dim3 grid(any_kl ? 2 : 1, n, members > 1 ? members : 1), block(256);
     (void)small_t;
     size_t need = 0;
     for (int i = 0; i < n; ++i) {
@@ -648,8 +651,10 @@ int launch_flow_planar(const FlowArgs* a, int n, hipStream_t s) {
         bool fast = true;
         for (int i = 0; i < n; ++i) fast = fast && (a[i].zf.T + (a[i].want_kl ? a[i].rf.T : 0) <= kFastT);
         if (fast) hipLaunchKernelGGL(mnf_flow_planar_fast_kernel, grid, dim3(kFastThreads), need, s, bt);
+        else if (members > 1) return LBBNN_E_SHAPE;                     // the member dimension exists in the fast form only
         else      hipLaunchKernelGGL(mnf_flow_planar_lds_kernel, grid, block, need, s, bt);
     } else {
+        if (members > 1) return LBBNN_E_SHAPE;
         hipLaunchKernelGGL(mnf_flow_planar_kernel, grid, block, (size_t)maxI * sizeof(float), s, bt);
     }
     return (int)hipGetLastError();

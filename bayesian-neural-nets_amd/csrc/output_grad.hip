@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256) void output_grad_kernel(const lbbnn_outgrad_ar
                 gm[q] = (a.relu && !(y[q] > 0.f)) ? 0.f : g[q];
                 if (stoch) gv[q] = gm[q] * e[q] / (2.f * sd[q]);
                 if (o + q >= a.O) { gm[q] = 0.f; gv[q] = 0.f; }
+                else if (stoch && a.gv_scale) gv[q] *= a.gv_scale[o + q];
             }
             const size_t id = (size_t)b * a.O + o;
             if (vec) {

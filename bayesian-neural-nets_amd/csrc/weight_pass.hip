@@ -6,10 +6,25 @@
 // spends ~25 separate full-matrix aten passes on the same values.
 //
 // Roofline: HBM.  Algorithmic bytes per weight: 12 read + 8 written (fp32 operands).
-// Mapping: one 256-thread workgroup per output row o; thread t owns float4 column groups
-// t, t+256, ... so a wave reads 1 KiB contiguous per instruction.  Row sums use a fixed-order
-// wave butterfly + LDS, so kl_rows / act_* are bitwise reproducible.
+//
+// Two kernels:
+//   weight_rows_kernel (rows whose length is a multiple of 4, 16-B aligned, ld <= 2048: every layer of the BASELINE
+//     configurations)  -- round 2.  ONE WAVE PER ROW, four rows per 256-thread workgroup: a lane owns the float4 column
+//     groups lane, lane + 64, ... so a wave reads 1 KiB contiguous per instruction, has all of its row's loads in flight
+//     at once (15 x 16 B per lane at I = 1200) and reduces its row sums with DPP moves alone -- no barrier, no LDS
+//     round trip per row.  603 workgroups cover the headline net, all resident at once (<= 3 per CU).
+//     The per-column vectors z_fwd, z_kl, r0_c are staged ONCE per workgroup in LDS (round 1 re-read them from L2 for
+//     every row).  For planar MNF layers the workgroup computes them ITSELF (in_flow): z0 = q0_mean + q0_std eps for both
+//     draws, the <= 19 dot products of the planar chains reduced once, the tanh / log-det chain as scalars -- the K3
+//     kernel of round 1 (one latency-bound workgroup pair per layer, 13 us + a launch boundary AHEAD of K1 on the
+//     critical path) is gone from the fused forward; the first workgroup of a layer also writes what K3 wrote
+//     (z_fwd, z_kl, scal[0..4]) for K5 and for the backward pass.
+//     Split (bf16 hi | lo) operands leave as full 16-B units: lane pairs swap halves by DPP, so a wave-store covers
+//     1 KiB contiguous (round 1: four 8-B stores per lane into every other 16-B unit; WRITE_SIZE 2.5x the bytes).
+//   weight_pass_kernel: the generic form (any I, any alignment), one 256-thread workgroup per row.
+// Row sums have a fixed order in both => kl_rows / act_* are bitwise reproducible.
 #include <cmath>
+#include <cstdlib>
 #include "lbbnn_device.h"
 #include "lbbnn_internal.h"
 
@@ -196,6 +211,304 @@ __global__ __launch_bounds__(256) void weight_pass_kernel(const WeightPassBatch 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ round-2 row kernel
+struct ElemConst { float mu_prior, log_sp, log_ap, log_1map, inv_2sp2; };
+
+__device__ __forceinline__ Elem weight_elem_c(float mu, float rho, float lam, float zf, float zk, float rc,
+                                              bool want_kl, bool want_act, const ElemConst& c) {
+    Elem e;
+    const float alpha = __frcp_rn(1.0f + __expf(-lam));
+    const float sigma = softplus_fast(rho);
+    const float ea = mu * alpha;
+    e.ew = ea * zf;
+    e.vw = (sigma * sigma) * (alpha * alpha);
+    e.kl = 0.f; e.amu = 0.f; e.avar = 0.f;
+    if (want_kl) {
+        const float d = mu * zk - c.mu_prior;
+        const float one_m = 1.f - alpha;
+        e.kl = alpha * ((c.log_sp - __logf(sigma)) - 0.5f + (__logf(alpha) - c.log_ap)
+                        + (sigma * sigma + d * d) * c.inv_2sp2)
+             + one_m * (__logf(one_m) - c.log_1map);
+    }
+    if (want_act) {
+        e.amu = rc * ((zk * mu) * alpha);
+        e.avar = (rc * rc) * e.vw;
+    }
+    return e;
+}
+
+constexpr int kInT = 4;                                  // in-kernel planar flows: Tz + Tr <= 4 (the K3 fast form's limit)
+constexpr int kInNV = 3 * kInT + kInT * (kInT - 1) / 2 + kInT + 1;      // A_k | UW | X | A_f | LQ0 = 23 sums (19 used at T = 2 + 2)
+constexpr int kRowG = 8;                                 // float4 groups per lane: ld <= 64 * 4 * 8 = 2048
+constexpr int kRowB = 5;                                 // ... of which this many are loaded together
+
+struct WeightRowsBatch {
+    WeightPassArgs l[LBBNN_MAX_LAYERS];
+    InFlow f[LBBNN_MAX_LAYERS];
+    int wg_end[LBBNN_MAX_LAYERS];
+    int n;
+    uint64_t* rng; uint64_t* rng_snap; uint64_t advance;
+    int members;                 // ensemble (lbbnn_ensemble_operands): gridDim.y members; member m reads z_fwd + m*ld and writes
+                                 // e_w + m*O*ld; var_w / bias_var are written by member 0 only; no KL outputs
+};
+
+__device__ __forceinline__ float4 ld4(const float* p, int j) { return reinterpret_cast<const float4*>(p)[j]; }
+__device__ __forceinline__ float dot4(const float4 a, const float4 b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
+__device__ __forceinline__ float4 fma4(const float4 u, float s, const float4 z) {
+    return make_float4(z.x + u.x * s, z.y + u.y * s, z.z + u.z * s, z.w + u.w * s);
+}
+__device__ __forceinline__ uint32_t dpp_xor1(uint32_t v) { return (uint32_t)dpp_mov<0xB1>((int)v); }   // lane ^ 1
+
+__global__ __launch_bounds__(256, 3) void weight_rows_kernel(const WeightRowsBatch bt_) {
+    const LBBNN_CONST_AS WeightRowsBatch* bt = kernarg_as<WeightRowsBatch>();
+    extern __shared__ __attribute__((aligned(16))) float sm[];          // zf[P] | zk[P] | rc[P]
+    __shared__ double red[kInNV][4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (bt->rng_snap && blockIdx.x == 0 && tid == 0) {                   // see weight_pass_kernel
+        const uint64_t sd = bt->rng[0], of = bt->rng[1];
+        bt->rng_snap[0] = sd; bt->rng_snap[1] = of;
+        if (bt->advance) bt->rng[1] = of + bt->advance;                  // (never together with in_flow: the host checks)
+    }
+    int li = 0;
+#pragma unroll
+    for (int t = 0; t < LBBNN_MAX_LAYERS - 1; ++t) if (t + 1 < bt->n && (int)blockIdx.x >= bt->wg_end[t]) li = t + 1;
+    const LBBNN_CONST_AS WeightPassArgs& a = bt->l[li];
+    const LBBNN_CONST_AS InFlow& f = bt->f[li];
+    const int wg0 = li ? bt->wg_end[li - 1] : 0;
+    const bool first_wg = (int)blockIdx.x == wg0;
+    const int I = a.I, P = a.ld, nq = P >> 2, iq = I >> 2;
+    const int mem = blockIdx.y;                                          // 0 unless an ensemble launch
+    float* zf_s = sm; float* zk_s = sm + P; float* rc_s = sm + 2 * P;
+    const bool want_kl = a.kl_rows != nullptr, want_act = a.act_mu != nullptr;
+    const float4 one4 = make_float4(1.f, 1.f, 1.f, 1.f), zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const int o = 4 * ((int)blockIdx.x - wg0) + wv;
+    const bool has_row = o < a.O;
+    const int G = (nq + 63) >> 6;                                        // wave-uniform, <= kRowG
+    const size_t rowoff = (size_t)o * I;
+    // (Measured and dropped, round 2: requesting the row AHEAD of the prologue -- held in registers: 98 spilled VGPRs at the
+    // 168-register budget three workgroups per CU need; touched line by line with unused asm loads: 35.7 us against 33.6.)
+
+    // ---------------------------------------------------------------- per-column vectors of this layer -> LDS
+    if (f.on) {
+        const int Tz = f.Tz, NT = f.Tz + f.Tr;
+        const bool klb = f.want_kl != 0;
+        uint64_t seed = 0, offs = 0;
+        if (!f.eps_fwd || (klb && !f.eps_kl)) { seed = f.rng[0]; offs = f.rng[1]; }
+        double acc[kInNV];
+#pragma unroll
+        for (int k = 0; k < kInNV; ++k) acc[k] = 0.0;
+        // (the sweep parks z0 of both draws in LDS and the update re-reads u: keeping them in registers across the
+        // reduction spilled at the 168-VGPR budget that three workgroups per CU need)
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+            const int j = tid + 256 * h;
+            if (j < iq) {
+                const float4 qm = ld4(f.q0_mean, j), lv = ld4(f.q0_log_var, j);
+                float ef[4], ek[4] = {0.f, 0.f, 0.f, 0.f};
+                if (f.eps_fwd) { const float4 e = ld4(f.eps_fwd, j); ef[0] = e.x; ef[1] = e.y; ef[2] = e.z; ef[3] = e.w; }
+                else philox_normal4(seed, offs, LBBNN_STREAM_EPS_Z * 64u + f.layer, (uint64_t)j, 0u, ef);
+                if (klb) {
+                    if (f.eps_kl) { const float4 e = ld4(f.eps_kl, j); ek[0] = e.x; ek[1] = e.y; ek[2] = e.z; ek[3] = e.w; }
+                    else philox_normal4(seed, offs, LBBNN_STREAM_EPS_Z2 * 64u + f.layer, (uint64_t)j, 0u, ek);
+                }
+                const float qmv[4] = {qm.x, qm.y, qm.z, qm.w}, lvv[4] = {lv.x, lv.y, lv.z, lv.w};
+                float a0[4], a1[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float ev = expf(lvv[c]), sd = sqrtf(ev);
+                    a0[c] = qmv[c] + sd * ef[c];                                    // …MNF.py:183-185
+                    a1[c] = qmv[c] + sd * ek[c];
+                    if (klb) {
+                        const float d = a1[c] - qmv[c];
+                        acc[kInNV - 1] += (double)(-0.5f * 1.1447298858494002f - 0.5f * lvv[c] - 0.5f * ((d * d) / ev));   // :213-214
+                    }
+                }
+                const float4 z0f = make_float4(a0[0], a0[1], a0[2], a0[3]), z0k = make_float4(a1[0], a1[1], a1[2], a1[3]);
+                reinterpret_cast<float4*>(zf_s)[j] = z0f;
+                reinterpret_cast<float4*>(zk_s)[j] = z0k;
+                float4 u4[kInT], w4[kInT];
+#pragma unroll
+                for (int t = 0; t < kInT; ++t) {
+                    u4[t] = zero4; w4[t] = zero4;                 // (if, not ?: -- a select between float4 OBJECTS goes through scratch)
+                    if (t < NT) { u4[t] = ld4(f.u[t], j); w4[t] = ld4(f.w[t], j); }
+                }
+                int qx = 2 * kInT;
+#pragma unroll
+                for (int t = 0; t < kInT; ++t) {
+                    acc[t] += (double)dot4(w4[t], z0k);                             // A_k[t]
+                    acc[kInT + t] += (double)dot4(u4[t], w4[t]);                    // UW[t]
+#pragma unroll
+                    for (int s2 = 0; s2 < t; ++s2) acc[qx++] += (double)dot4(w4[t], u4[s2]);      // X[t][s]
+                    acc[2 * kInT + kInT * (kInT - 1) / 2 + t] += (double)dot4(w4[t], z0f);        // A_f[t]
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kInNV; ++k) acc[k] = wave_sum(acc[k]);
+        if (lane == 0)
+#pragma unroll
+            for (int k = 0; k < kInNV; ++k) red[k][wv] = acc[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kInNV; ++k) acc[k] = (red[k][0] + red[k][1]) + (red[k][2] + red[k][3]);
+        // the scalar chains (flows2.py:87-95), every thread redundantly: forward draw (z flow only), KL draw (z then r flow)
+        float thf[kInT], thk[kInT], ldf = 0.f, ldq = 0.f, ldr = 0.f;
+        {
+            int qx = 2 * kInT;
+#pragma unroll
+            for (int t = 0; t < kInT; ++t) {
+                double inf = acc[2 * kInT + kInT * (kInT - 1) / 2 + t], ink = acc[t];
+#pragma unroll
+                for (int s2 = 0; s2 < t; ++s2) { const double x = acc[qx++]; inf += (double)thf[s2] * x; ink += (double)thk[s2] * x; }
+                thf[t] = 0.f; thk[t] = 0.f;
+                if (t < NT) {
+                    const float bias = f.b[t][0], uw = (float)acc[kInT + t];
+                    if (t < Tz) {
+                        thf[t] = tanhf((float)inf + bias);
+                        ldf += logf(fabsf(1.f + (1.f - thf[t] * thf[t]) * uw));
+                    }
+                    if (klb) {
+                        thk[t] = tanhf((float)ink + bias);
+                        const float ld = logf(fabsf(1.f + (1.f - thk[t] * thk[t]) * uw));
+                        if (t < Tz) ldq += ld; else ldr += ld;
+                    }
+                }
+            }
+        }
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+            const int j = tid + 256 * h;
+            if (j < nq) {
+                float4 zf = zero4, zk = zero4;
+                float ulast[kInT] = {0.f, 0.f, 0.f, 0.f};
+                if (j < iq) {
+                    zf = reinterpret_cast<const float4*>(zf_s)[j];                    // this thread's own z0 (no barrier needed)
+                    zk = reinterpret_cast<const float4*>(zk_s)[j];
+#pragma unroll
+                    for (int t = 0; t < kInT; ++t)
+                        if (t < NT) {
+                            const float4 u = ld4(f.u[t], j);
+                            ulast[t] = u.w;
+                            if (t < Tz) { zf = fma4(u, thf[t], zf); zk = fma4(u, thk[t], zk); }
+                        }
+                }
+                float4 rc = one4;
+                if (a.r0_c && j < iq) rc = ld4(a.r0_c, j);
+                if (!klb) zk = one4;
+                reinterpret_cast<float4*>(zf_s)[j] = zf;
+                reinterpret_cast<float4*>(zk_s)[j] = zk;
+                reinterpret_cast<float4*>(rc_s)[j] = rc;
+                if (first_wg && j < iq) {                                             // what K3 wrote, for K5 / backward
+                    reinterpret_cast<float4*>(f.z_fwd)[j] = zf;
+                    if (klb) {
+                        reinterpret_cast<float4*>(f.z_kl)[j] = zk;
+                        if (j == iq - 1) {                                            // z_b[-1]: last ELEMENT (:224)
+                            float v = zk.w;
+#pragma unroll
+                            for (int t = 0; t < kInT; ++t) if (t >= Tz && t < NT) v += ulast[t] * thk[t];
+                            f.scal[3] = v;
+                        }
+                    }
+                }
+            }
+        }
+        if (first_wg && tid == 0 && f.scal) {
+            f.scal[4] = ldf;                                                          // logdet of sample_z(B) (:187)
+            if (klb) { f.scal[0] = ldq; f.scal[1] = (float)acc[kInNV - 1]; f.scal[2] = ldr; }
+        }
+    } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int j = tid + 256 * h;
+            if (j < nq) {
+                const bool in = j < iq;
+                float4 zf = one4, zk = one4, rc = one4;
+                if (a.z_fwd && in) zf = ld4(a.z_fwd + (size_t)mem * P, j);
+                if (a.z_kl && in) zk = ld4(a.z_kl, j);
+                if (a.r0_c && in) rc = ld4(a.r0_c, j);
+                reinterpret_cast<float4*>(zf_s)[j] = zf;
+                reinterpret_cast<float4*>(zk_s)[j] = zk;
+                reinterpret_cast<float4*>(rc_s)[j] = rc;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------- one row per wave
+    if (!has_row) return;
+    const ElemConst ec = {a.mu_prior, a.log_sp, a.log_ap, a.log_1map, a.inv_2sp2};
+    float kl = 0.f, amu = 0.f, avar = 0.f;
+    const bool split = a.split != 0;
+    float* const ewp = a.e_w ? a.e_w + (size_t)mem * a.O * P : nullptr;
+    float* const vwp = mem == 0 ? a.var_w : nullptr;
+    // kRowB float4 groups per lane at a time, all of their loads in flight together: rows up to 64 * 4 * 5 = 1280 floats
+    // (every layer of the BASELINE configs but the 3072 / 4096-wide VD ones, which take the generic kernel) are one batch
+    for (int g0 = 0; g0 < G; g0 += kRowB) {
+        float4 mu[kRowB], rho[kRowB], lam[kRowB];
+#pragma unroll
+        for (int g = 0; g < kRowB; ++g) {
+            const int j = lane + 64 * (g0 + g);
+            if (g0 + g < G && j < iq) { mu[g] = ld4(a.mu + rowoff, j); rho[g] = ld4(a.rho + rowoff, j); lam[g] = ld4(a.lambdal + rowoff, j); }
+        }
+#pragma unroll
+        for (int g = 0; g < kRowB; ++g) {
+            if (g0 + g >= G) break;
+            const int j = lane + 64 * (g0 + g);
+            float4 ew = zero4, vw = zero4;
+            if (j < iq) {
+                const float4 zf = reinterpret_cast<const float4*>(zf_s)[j], zk = reinterpret_cast<const float4*>(zk_s)[j];
+                const float4 rc = reinterpret_cast<const float4*>(rc_s)[j];
+                const Elem e0 = weight_elem_c(mu[g].x, rho[g].x, lam[g].x, zf.x, zk.x, rc.x, want_kl, want_act, ec);
+                const Elem e1 = weight_elem_c(mu[g].y, rho[g].y, lam[g].y, zf.y, zk.y, rc.y, want_kl, want_act, ec);
+                const Elem e2 = weight_elem_c(mu[g].z, rho[g].z, lam[g].z, zf.z, zk.z, rc.z, want_kl, want_act, ec);
+                const Elem e3 = weight_elem_c(mu[g].w, rho[g].w, lam[g].w, zf.w, zk.w, rc.w, want_kl, want_act, ec);
+                ew = make_float4(e0.ew, e1.ew, e2.ew, e3.ew);
+                vw = make_float4(e0.vw, e1.vw, e2.vw, e3.vw);
+                kl += (e0.kl + e1.kl) + (e2.kl + e3.kl);
+                amu += (e0.amu + e1.amu) + (e2.amu + e3.amu);
+                avar += (e0.avar + e1.avar) + (e2.avar + e3.avar);
+            }
+            if (!split) {
+                if (j < nq) {
+                    if (ewp) reinterpret_cast<float4*>(ewp + (size_t)o * P)[j] = ew;
+                    if (vwp) reinterpret_cast<float4*>(vwp + (size_t)o * P)[j] = vw;
+                }
+            } else {
+                // 16-B units: the even lane of a pair holds k = 8m..8m+3, the odd lane k = 8m+4..8m+7; the even lane stores
+                // the hi unit (its hi half | the partner's), the odd lane the lo unit next to it -- a wave covers 1 KiB contiguous
+                const bool odd = lane & 1;
+                const size_t at = split_hi_index((size_t)o, 4 * (j & ~1), P) + (odd ? kSplitLoOffset : 0);
+                uint2 hi, lo;
+                split4(ew, hi, lo);
+                {
+                    const uint32_t r0 = dpp_xor1(odd ? hi.x : lo.x), r1 = dpp_xor1(odd ? hi.y : lo.y);
+                    const uint4 unit = make_uint4(odd ? r0 : hi.x, odd ? r1 : hi.y, odd ? lo.x : r0, odd ? lo.y : r1);
+                    if (ewp && j < nq) *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(ewp) + at) = unit;
+                }
+                if (vwp) {
+                    split4(vw, hi, lo);
+                    const uint32_t r0 = dpp_xor1(odd ? hi.x : lo.x), r1 = dpp_xor1(odd ? hi.y : lo.y);
+                    const uint4 unit = make_uint4(odd ? r0 : hi.x, odd ? r1 : hi.y, odd ? lo.x : r0, odd ? lo.y : r1);
+                    if (j < nq) *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(vwp) + at) = unit;
+                }
+            }
+        }
+    }
+    if (want_kl || want_act) {
+        kl = wave_sum(kl); amu = wave_sum(amu); avar = wave_sum(avar);
+        if (lane == 0) {
+            if (want_kl) a.kl_rows[o] = kl;
+            if (want_act) { a.act_mu[o] = amu; a.act_var[o] = avar; }
+        }
+    }
+    if (lane == 0 && mem == 0 && a.bias_var && a.bias_rho) {
+        const float sb = softplus_ref(a.bias_rho[o]);
+        a.bias_var[o] = sb * sb;                      // bias.sigma**2, LBBNN-GP-MF-LRT.py:173
+    }
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace
@@ -228,7 +541,55 @@ int make_weight_pass_args(WeightPassArgs& a, const float* mu, const float* rho, 
     return 0;
 }
 
-int launch_weight_pass(const WeightPassArgs* a, int n, hipStream_t s, uint64_t* rng, uint64_t* rng_snap, uint64_t advance) {
+bool in_flow_eligible(const FlowArgs& f, const WeightPassArgs& w) {
+    const int nt = f.zf.T + (f.want_kl ? f.rf.T : 0);
+    return w.vec && w.ld <= 64 * 4 * kRowG && nt <= kInT && aligned16(f.q0_mean) && aligned16(f.q0_log_var) &&
+           (!f.eps_fwd || aligned16(f.eps_fwd)) && (!f.eps_kl || aligned16(f.eps_kl)) && aligned16(f.z_fwd) &&
+           (!f.want_kl || aligned16(f.z_kl)) && [&] {
+               for (int t = 0; t < f.zf.T; ++t) if (!aligned16(f.zf.u[t]) || !aligned16(f.zf.w[t])) return false;
+               for (int t = 0; t < (f.want_kl ? f.rf.T : 0); ++t) if (!aligned16(f.rf.u[t]) || !aligned16(f.rf.w[t])) return false;
+               return true;
+           }();
+}
+
+void make_in_flow(InFlow& o, const FlowArgs& f) {
+    o = InFlow{};
+    o.on = 1;
+    o.q0_mean = f.q0_mean; o.q0_log_var = f.q0_log_var; o.eps_fwd = f.eps_fwd; o.eps_kl = f.want_kl ? f.eps_kl : nullptr;
+    o.rng = f.rng; o.z_fwd = f.z_fwd; o.z_kl = f.z_kl; o.scal = f.scal;
+    o.Tz = f.zf.T; o.Tr = f.want_kl ? f.rf.T : 0; o.want_kl = f.want_kl; o.layer = f.layer;
+    for (int t = 0; t < o.Tz; ++t) { o.u[t] = f.zf.u[t]; o.w[t] = f.zf.w[t]; o.b[t] = f.zf.b[t]; }
+    for (int t = 0; t < o.Tr; ++t) { o.u[o.Tz + t] = f.rf.u[t]; o.w[o.Tz + t] = f.rf.w[t]; o.b[o.Tz + t] = f.rf.b[t]; }
+}
+
+int launch_weight_pass(const WeightPassArgs* a, int n, hipStream_t s, uint64_t* rng, uint64_t* rng_snap, uint64_t advance,
+                       const InFlow* flows, int members) {
+    bool rows_ok = true;
+    for (int i = 0; i < n; ++i) rows_ok = rows_ok && a[i].vec && a[i].ld <= 64 * 4 * kRowG;
+    // LBBNN_K1_ROWS=0 (environment, read once): A/B switch for measurements -- the one-row-per-workgroup kernel of round 1
+    static const bool rows_allowed = [] { const char* e = getenv("LBBNN_K1_ROWS"); return !(e && e[0] == '0'); }();
+    rows_ok = rows_ok && rows_allowed;
+    if (rows_ok) {
+        WeightRowsBatch bt{};
+        bt.rng = rng; bt.rng_snap = (rng && rng_snap) ? rng_snap : nullptr; bt.advance = advance;
+        int wgs = 0, maxld = 0;
+        for (int i = 0; i < n; ++i) {
+            bt.l[i] = a[i];
+            if (flows) bt.f[i] = flows[i];
+            if (bt.f[i].on && advance) return LBBNN_E_FLAGS;     // the in-kernel flows read the live offset in every workgroup
+            wgs += (a[i].O + 3) / 4; bt.wg_end[i] = wgs;
+            maxld = a[i].ld > maxld ? a[i].ld : maxld;
+        }
+        for (int i = n; i < LBBNN_MAX_LAYERS; ++i) bt.wg_end[i] = wgs;
+        bt.n = n;
+        bt.members = members;
+        if (members > 1) for (int i = 0; i < n; ++i) if (bt.f[i].on || a[i].kl_rows || a[i].act_mu) return LBBNN_E_FLAGS;
+        hipLaunchKernelGGL(weight_rows_kernel, dim3(wgs, members > 1 ? members : 1), dim3(256),
+                           (size_t)3 * maxld * sizeof(float), s, bt);
+        return (int)hipGetLastError();
+    }
+    if (members > 1) return LBBNN_E_ALIGN;                  // the member dimension exists in the row kernel only
+    if (flows) for (int i = 0; i < n; ++i) if (flows[i].on) return LBBNN_E_ALIGN;    // (callers test in_flow_eligible first)
     WeightPassBatch bt;
     bt.rng = rng; bt.rng_snap = (rng && rng_snap) ? rng_snap : nullptr; bt.advance = advance;
     int rows = 0;

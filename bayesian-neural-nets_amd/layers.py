@@ -1133,17 +1133,21 @@ class _NetworkBase(nn.Module):
                     eps_z2 = eps_z2.reshape(-1).contiguous()
                 keep.extend([eps_z, eps_z2])
                 l._chain_flows(rng, eps_z, eps_z2, c[1])
-        # K1 of every layer (+ K3 of the planar ones); its launch also snapshots the Philox state for the rest of this
-        # forward and advances the live offset, so the forward ends with the last GEMM
+        # K1 of every layer, the planar flows computed inside its own workgroups (no K3 launch: weight_pass.hip); the launch
+        # snapshots the Philox state for the rest of this forward.  The live offset is advanced by the extra workgroup of
+        # the first GEMM's launch (lbbnn_lrt_gemm_finalize_adv): every workgroup of THIS launch reads it.
         snap = st.t[2:4] if st is not None else None
         _lib.check(_lib.lib().lbbnn_layers_operands_snap(descs, n, rng.data_ptr() if rng is not None else None,
-                                                         snap.data_ptr() if snap is not None else None, 1, stream),
+                                                         snap.data_ptr() if snap is not None else None, 0, stream),
                    "lbbnn_layers_operands_snap")
         all_kl = want_kl and all(c[1] for c in cfgs)
         for i, (l, c) in enumerate(zip(layers, cfgs)):
             # the KL finalize of all layers (parameters only) rides in the first GEMM's launch as one extra workgroup
-            fin = (descs, n, snap.data_ptr() if snap is not None else None, kls[n:].data_ptr() if all_kl else None) \
-                if (i == 0 and want_kl) else None
+            fin = None
+            if i == 0 and (want_kl or st is not None):
+                fin = (descs if want_kl else None, n if want_kl else 0, snap.data_ptr() if snap is not None else None,
+                       kls[n:].data_ptr() if all_kl else None, rng.data_ptr() if rng is not None else None,
+                       1 if rng is not None else 0)
             x = l._gemm(x, c, snap, log_softmax=(i == n - 1 and l.out_features <= 16), finalize=fin)
         if layers[-1].out_features > 16:
             x = F.log_softmax(x, dim=1)

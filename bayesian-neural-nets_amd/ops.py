@@ -153,8 +153,9 @@ def weight_pass(mu, rho, lambdal, *, z_fwd=None, z_kl=None, r0_c=None, bias_rho=
 
 
 def output_grad(g_out, *, out=None, std=None, eps=None, rng=None, rng_stream: int = 0, row_offset: int = 0,
-                relu: bool = False):
-    """lbbnn_output_grad.  Returns (gm, gv, gmT, gvT, g_sum, gv_sum); the gv* are None for a posterior-mean forward."""
+                relu: bool = False, gv_scale=None):
+    """lbbnn_output_grad.  Returns (gm, gv, gmT, gvT, g_sum, gv_sum); the gv* are None for a posterior-mean forward.
+    gv_scale (O,): per-column factor on G_v (the variational-dropout alpha)."""
     B, O = g_out.shape
     f = dict(dtype=torch.float32, device=g_out.device)
     if g_out.stride(1) != 1:
@@ -183,6 +184,7 @@ def output_grad(g_out, *, out=None, std=None, eps=None, rng=None, rng_stream: in
     if stoch:
         a.gv, a.gvT, a.gv_sum = gv.data_ptr(), gvT.data_ptr(), gv_sum.data_ptr()
     a.row_offset, a.rng_stream = row_offset, rng_stream
+    a.gv_scale = _ptr(gv_scale, "gv_scale") if (stoch and gv_scale is not None) else None
     a.B, a.O, a.ldg, a.ldo, a.relu = B, O, g_out.stride(0), ldo, 1 if relu else 0
     _lib.check(_lib.lib().lbbnn_output_grad(ctypes.byref(a), _stream()), "lbbnn_output_grad")
     return gm, gv, gmT, gvT, g_sum, gv_sum
@@ -275,8 +277,9 @@ def lrt_gemm(x, e_w, var_w, *, I: int, O: int, bias_mean=None, bias_var=None, va
              split: bool = False, out: Optional[torch.Tensor] = None, std_out: Optional[torch.Tensor] = None,
              finalize=None):
     """lbbnn_lrt_gemm: out = x.e_w^T + b [+ sqrt(x^2.var_w^T + bv) * eps] [ReLU].
-    finalize = (layer descriptors, n, rng pointer for K5, kl_total pointer): lbbnn_lrt_gemm_finalize -- the KL finalize of
-    the whole network rides in this launch."""
+    finalize = (layer descriptors, n, rng pointer for K5, kl_total pointer[, live rng pointer, advance]):
+    lbbnn_lrt_gemm_finalize_adv -- the KL finalize of the whole network (n may be 0) and the forward's RNG advance ride in
+    this launch."""
     if x.dim() != 2 or x.shape[1] != I:
         raise RuntimeError("bnn_amd: input must be (B,%d), got %s" % (I, tuple(x.shape)))
     B = x.shape[0]
@@ -294,12 +297,14 @@ def lrt_gemm(x, e_w, var_w, *, I: int, O: int, bias_mean=None, bias_var=None, va
     if ev is not None:
         ev[0].record()
     if finalize is not None:
-        rc = _lib.lib().lbbnn_lrt_gemm_finalize(
+        # (descs, n, fin_rng, kl_total[, rng_live, advance]): with the last two the piggy workgroup also advances the live offset
+        live, adv = (finalize[4], finalize[5]) if len(finalize) > 4 else (None, 0)
+        rc = _lib.lib().lbbnn_lrt_gemm_finalize_adv(
             _ptr_rows(x, "input"), x.stride(0), _ptr(e_w), _ptr(var_w), operand_ld(I),
             _ptr(bias_mean), _ptr(bias_var), _ptr(var_scale), _ptr(eps, "eps"),
             rng.data_ptr() if rng is not None else None, rng_stream, row_offset,
             out.data_ptr(), out.stride(0), _ptr(std_out, "std_out"), B, I, O, flags,
-            finalize[0], finalize[1], finalize[2], finalize[3], _stream())
+            finalize[0], finalize[1], finalize[2], finalize[3], live, adv, _stream())
     elif std_out is None:
         rc = _lib.lib().lbbnn_lrt_gemm(
             _ptr_rows(x, "input"), x.stride(0), _ptr(e_w), _ptr(var_w), operand_ld(I),
@@ -648,6 +653,17 @@ def transpose_operand(src: torch.Tensor, *, square: bool = False, split: bool = 
     rc = _lib.lib().lbbnn_transpose_operand(_ptr_rows(src, "src"), R, C, src.stride(0), out.data_ptr(), ld,
                                             1 if square else 0, F_SPLIT16 if split else 0, _stream())
     _lib.check(rc, "lbbnn_transpose_operand")
+    return out
+
+
+def format_operand(src: torch.Tensor, *, square: bool = False, split: bool = False) -> torch.Tensor:
+    """lbbnn_format_operand: (R,C) fp32 -> GEMM operand [R][operand_ld(C)] holding src (squared if asked), no transpose."""
+    R, C = src.shape
+    ld = operand_ld(C)
+    out = torch.empty((R, ld), dtype=torch.float32, device=src.device)
+    rc = _lib.lib().lbbnn_format_operand(_ptr_rows(src, "src"), R, C, src.stride(0), out.data_ptr(), ld,
+                                         1 if square else 0, F_SPLIT16 if split else 0, _stream())
+    _lib.check(rc, "lbbnn_format_operand")
     return out
 
 

@@ -153,6 +153,71 @@ class DataParallelELBO:
     def bucket_numel(self) -> int:
         return self.bucket.numel
 
+    def make_graphed_step(self, optimizer, example_x, example_y, num_batches, warmup: int = 3):
+        """The data-parallel training step as TWO HIP graphs around ONE collective:
+
+            graph A   zero_grad -> forward -> nll + kl / (num_batches * world) -> backward (HIP kernels, vector chains
+                      deferred and batched) -> all gradients packed into the flat bucket (one launch)
+            eager     all-reduce of the bucket over RCCL (world > 1; nothing at world 1)
+            graph B   bnn_amd.optim.Adam on the reduced bucket (one launch)
+
+        Three host calls per step instead of ~90 launches: the eager step of the headline net is host-bound at ~2 ms, the
+        graphs run at GPU speed.  The collective stays OUTSIDE the graphs on purpose: capturing RCCL inside a graph works
+        in principle, but a capture that misbehaves would hang all N ranks, and an N-GPU node is not available to the
+        build to test it on -- between two graphs the collective is the plain, well-trodden ``dist.all_reduce``.
+        ``optimizer`` must be capture-safe (``bnn_amd.optim.Adam``).  Returns step(x, y) -> loss (a static tensor).
+        Call it before any eager training step of the same network whose autograd graph is still alive: the parameters'
+        AccumulateGrad nodes remember the stream they were created on, and a node created on the default stream makes
+        autograd synchronise the capture stream with the default stream -- which a HIP stream capture does not survive
+        (measured: a segmentation fault in capture_end)."""
+        import contextlib
+        from . import layers
+        net, dev = self.net, example_x.device
+        ov = layers.vector_backward_overlap
+        static_x, static_y = example_x.clone(), example_y.clone()
+
+        def fwd_bwd():
+            optimizer.zero_grad(set_to_none=True)
+            loss = self.loss(net(static_x, sample=True), static_y, num_batches)
+            with ov():
+                loss.backward()
+            self.bucket.pack()
+            return loss
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                fwd_bwd()
+                if self.world > 1:
+                    dist.all_reduce(self.bucket._store, op=dist.ReduceOp.SUM, group=self.group)
+                optimizer.step(grads=self.reduced_grads())
+        torch.cuda.current_stream(dev).wait_stream(side)
+        _quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+        if _quiet is not None:
+            _quiet(False)
+        g_a, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(g_a):
+            static_loss = fwd_bwd()
+        with torch.cuda.graph(g_b, pool=g_a.pool()):
+            optimizer.step(grads=self.reduced_grads())
+        if _quiet is not None:
+            _quiet(True)
+        self.bucket.last = ("all_reduce (%d B) between two HIP graphs" % (self.bucket._store.numel() * 4)) if self.world > 1 else None
+
+        def step(x, y):
+            static_x.copy_(x)
+            static_y.copy_(y)
+            g_a.replay()
+            if self.world > 1:
+                dist.all_reduce(self.bucket._store, op=dist.ReduceOp.SUM, group=self.group)
+            g_b.replay()
+            return static_loss
+
+        step.graphs = (g_a, g_b)
+        return step
+
     def describe_collective(self) -> str:
         backend = dist.get_backend(self.group) if (dist.is_available() and dist.is_initialized()) else "none"
         return "%s over %d rank(s), backend %s" % (self.bucket.last or ("no exchange (world 1)" if self.world == 1

@@ -8,31 +8,63 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import _grad, _lib, ops
+from . import _lib, ops
 
 _ids = itertools.count(48)
 
 
 class _VDFn(torch.autograd.Function):
+    """Forward: lbbnn_vd_operands + the dual-moment GEMM.  Backward, all on the HIP kernels (round 2; round 1 recomputed the
+    layer with torch ops):  with G = dL/dout, G_v = G zeta alpha / (2 sqrt(delta))  (lbbnn_output_grad, gv_scale = alpha)
+        dX     = G . theta^T + 2 x (.) (G_v . (theta^2)^T)          operands theta, theta^2 as they lie (lbbnn_format_operand)
+        dtheta = x^T . G + 2 theta (.) ((x^2)^T . G_v)              x^T | (x^2)^T from one pass over x (lbbnn_vd_operands),
+                                                                    G^T, G_v^T operands (lbbnn_transpose_operand)
+    both "+ 2 a (.) (second product)" combinations run in the second GEMM's epilogue (lbbnn_lrt_gemm_combine)."""
+
     @staticmethod
     def forward(ctx, layer, x, theta, alpha):
-        out, zeta_src = layer._forward_hip(x, save_rng=True)
+        std = torch.empty((x.shape[0], layer.m), dtype=torch.float32, device=x.device)
+        out, zeta_src = layer._forward_hip(x, save_rng=True, std_out=std)
         ctx.layer, ctx.zeta_src = layer, zeta_src
-        ctx.save_for_backward(x, theta, alpha)
+        ctx.save_for_backward(x, theta, alpha, std)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, theta, alpha = ctx.saved_tensors
+        x, theta, alpha, std = ctx.saved_tensors
         layer = ctx.layer
+        n, m, B = layer.n, layer.m, x.shape[0]
         kind, val = ctx.zeta_src
-        zeta = val if kind == "explicit" else ops.philox_normal(val, ops.STREAM_EPS_OUT * 64 + layer._layer_id,
-                                                                  x.shape[0], layer.m, layer.row_offset)
-        with torch.enable_grad():
-            xs = x.detach().requires_grad_(True)
-            th = theta.detach().requires_grad_(True)
-            out = _grad.vd_torch(xs, th, alpha.detach(), zeta)
-            gx, gt = torch.autograd.grad(out, [xs, th], g)
+        gm, gv, _, _, _, _ = ops.output_grad(
+            g, std=std, eps=val if kind == "explicit" else None, rng=val if kind != "explicit" else None,
+            rng_stream=ops.STREAM_EPS_OUT * 64 + layer._layer_id, row_offset=layer.row_offset, relu=False, gv_scale=alpha)
+        split = ops.get_precision() == "bf16x3"
+        gx = gt = None
+        if ctx.needs_input_grad[1]:
+            sp = split and ops.split_eligible(m, n) and gm.stride(0) % 4 == 0
+            op_t = ops.format_operand(theta, square=False, split=sp)            # [n][ld(m)]: theta rows, K = m
+            op_t2 = ops.format_operand(theta, square=True, split=sp)
+            gx = ops.lrt_gemm(gm, op_t, None, I=m, O=n, mean_only=True, split=sp)
+            if n > 16 and x.stride(1) == 1:
+                gx = ops.lrt_gemm_combine(gv, op_t2, K=m, N=n, comb_x=x, comb_add=gx, split=sp)
+            else:
+                gx = ops.dx_combine(gx, ops.lrt_gemm(gv, op_t2, None, I=m, O=n, mean_only=True, split=sp), x)
+        if ctx.needs_input_grad[2]:
+            # x^T and (x^2)^T as plain fp32 matrices [n][ld(B)] (the GEMM's A side is fp32; it splits it in registers)
+            ld = ops.operand_ld(B)
+            xc = x if x.is_contiguous() else x.contiguous()
+            xt = torch.empty((n, ld), dtype=torch.float32, device=x.device)
+            x2t = torch.empty((n, ld), dtype=torch.float32, device=x.device)
+            _lib.check(_lib.lib().lbbnn_vd_operands(xc.data_ptr(), xt.data_ptr(), x2t.data_ptr(), ld, B, n, 0, ops._stream()),
+                       "lbbnn_vd_operands")
+            sp = split and ops.split_eligible(B, m)
+            gmT_op = ops.transpose_operand(gm, split=sp)                        # [m][ld(B)]: K = B
+            gvT_op = ops.transpose_operand(gv, split=sp)
+            gt = ops.lrt_gemm(xt[:, :B], gmT_op, None, I=B, O=m, mean_only=True, split=sp)
+            if m > 16:
+                gt = ops.lrt_gemm_combine(x2t[:, :B], gvT_op, K=B, N=m, comb_x=theta, comb_add=gt, split=sp)
+            else:
+                gt = ops.dx_combine(gt, ops.lrt_gemm(x2t[:, :B], gvT_op, None, I=B, O=m, mean_only=True, split=sp), theta)
         return None, gx, gt, None
 
 
@@ -50,7 +82,7 @@ class BayesianLayer(nn.Module):
         self._layer_id = next(_ids) % 64
         self._ws = None
 
-    def _forward_hip(self, x, relu=False, save_rng=False):
+    def _forward_hip(self, x, relu=False, save_rng=False, std_out=None):
         dev = x.device
         ld = ops.operand_ld(self.n)
         if self._ws is None or self._ws[0].device != dev:
@@ -70,7 +102,7 @@ class BayesianLayer(nn.Module):
         src = ("explicit", zeta) if zeta is not None else ("rng", rng.clone() if save_rng else None)
         out = ops.lrt_gemm(x, e_w, var_w, I=self.n, O=self.m, var_scale=self.alpha, eps=zeta, rng=rng,
                            rng_stream=ops.STREAM_EPS_OUT * 64 + self._layer_id, row_offset=self.row_offset,
-                           relu=relu, split=split)
+                           relu=relu, split=split, std_out=std_out)
         if st is not None:
             st.advance(1)
         return out, src

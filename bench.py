@@ -333,7 +333,7 @@ def train_leg(args, bnn_amd, net, x, sync, world, rank):
     opt = optim.Adam(net.parameters(), lr=1e-3)
     y = torch.randint(0, DIMS[-1], (x.shape[0],), device=dev, generator=torch.Generator(device=dev).manual_seed(7 + rank))
 
-    def step():
+    def eager_step():
         opt.zero_grad(set_to_none=True)
         loss = dp.loss(net(x, sample=True), y, 600)
         loss.backward()
@@ -341,6 +341,15 @@ def train_leg(args, bnn_amd, net, x, sync, world, rank):
         opt.step(grads=dp.reduced_grads())
         return loss
 
+    # two HIP graphs around the eager collective (parallel.DataParallelELBO.make_graphed_step); the plain eager step if
+    # the capture fails for any reason (recorded in the JSON)
+    mode, why = "two HIP graphs around the collective", None
+    try:
+        gstep = dp.make_graphed_step(opt, x, y, 600)
+        step = lambda: gstep(x, y)
+    except Exception as e:                                   # noqa: BLE001 -- report, fall back, keep the bench alive
+        mode, why = "eager", "%s: %s" % (type(e).__name__, str(e)[:200])
+        step = eager_step
     for _ in range(max(3, min(args.warmup, 10))):
         step()
     sync()
@@ -356,8 +365,9 @@ def train_leg(args, bnn_amd, net, x, sync, world, rank):
         import torch.distributed as dist
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    res = {"what": "data-parallel training step (eager): ELBO forward, HIP backward, one flat fp32 gradient bucket "
-                   "all-reduced over RCCL (%d elements), bnn_amd.optim.Adam" % dp.bucket_numel(),
+    res = {"what": "data-parallel training step (%s): ELBO forward, HIP backward, one flat fp32 gradient bucket "
+                   "all-reduced over RCCL (%d elements), bnn_amd.optim.Adam" % (mode, dp.bucket_numel()),
+           "graph_fallback_reason": why,
            "value": x.shape[0] * world * steps / elapsed, "unit": "samples/s", "steps": steps,
            "ms_per_step": elapsed / steps * 1e3, "settle": st, "timed_attempts": attempts,
            "bucket_bytes": dp.bucket_numel() * 4, "collective": dp.describe_collective()}

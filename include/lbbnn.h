@@ -295,6 +295,41 @@ int lbbnn_lrt_gemm_finalize(const float* x, int ldx, const void* e_w, const void
                             const lbbnn_layer_desc_t* layers, int n, const uint64_t* fin_rng, float* kl_total,
                             void* stream);
 
+/* lbbnn_lrt_gemm_finalize_adv = lbbnn_lrt_gemm_finalize + `rng_live[1] += advance`, done by the same extra workgroup
+ * (n == 0 allowed: nothing to finalize, the advance is then a tiny launch after the GEMM).  This is what lets
+ * lbbnn_layers_operands_snap run with advance = 0 -- and only then do its workgroups compute the planar flows of the
+ * layers THEMSELVES from the live {seed, offset} (no K3 launch ahead of the weight pass; weight_pass.hip): the advance
+ * has to come from a later launch of the same forward, none of whose kernels reads the live offset (they are given
+ * rng_snap). */
+int lbbnn_lrt_gemm_finalize_adv(const float* x, int ldx, const void* e_w, const void* var_w, int ld,
+                                const float* bias_mean, const float* bias_var, const float* var_scale,
+                                const float* eps, const uint64_t* rng, uint32_t rng_stream, int64_t row_offset,
+                                float* out, int ldo, float* std_out, int B, int I, int O, int flags,
+                                const lbbnn_layer_desc_t* layers, int n, const uint64_t* fin_rng, float* kl_total,
+                                uint64_t* rng_live, uint64_t advance, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Ensemble evaluation (test_ensemble, LBBNN-GP-MF-MNF.py:286-294 / ...LRT.py:241-247: TEST_SAMPLES stochastic forwards of
+ * the same batch): `members` forwards of a layer in ONE launch per kernel kind, member m bit-identical to the m-th of
+ * `members` consecutive single forwards (whose shared Philox offset advances by member_advance each).
+ *
+ * lbbnn_ensemble_operands: K3 + K1 for all n layers and all members (2 launches): per layer, z_fwd points to
+ *   [members][lbbnn_operand_ld(I)] floats (member m's z_k; MNF layers with planar flows of <= 4 transforms; ignored for
+ *   LRT layers) and e_w to [members][O][ld] operands (member m's e_w = mu alpha z_m); var_w, bias_var are shared (one copy).
+ *   Every layer must have stochastic = 1, want_kl = 0 (evaluation draws no KL, ...MNF.py:208), flows_done = 0, no explicit
+ *   eps_z.  Member m draws from Philox offset rng[1] + m * member_advance.
+ * lbbnn_lrt_gemm_members: the dual-moment GEMM of lbbnn_lrt_gemm for every member, gridDim.z = members:
+ *   x + m * x_mstride (floats; 0 = the same input for every member, the first layer), e_w + m * w_mstride (floats),
+ *   var_w shared, out + m * o_mstride; in-kernel noise only, at offset rng[1] + m * member_advance.
+ * The caller advances rng by members * member_advance afterwards (lbbnn_rng_advance). */
+int lbbnn_ensemble_operands(const lbbnn_layer_desc_t* layers, int n, int members, const uint64_t* rng,
+                            uint64_t member_advance, void* stream);
+int lbbnn_lrt_gemm_members(const float* x, int ldx, int64_t x_mstride, const void* e_w, int64_t w_mstride,
+                           const void* var_w, int ld, const float* bias_mean, const float* bias_var,
+                           const uint64_t* rng, uint32_t rng_stream, int64_t row_offset, uint64_t member_advance,
+                           float* out, int ldo, int64_t o_mstride, int B, int I, int O, int flags, int members,
+                           void* stream);
+
 /* End of a network forward: *kl_total = sum_l *kl_layers[l] (fixed order; BayesianNetwork.kl(),
  * …LRT.py:213-214) and rng[1] += advance, one tiny launch.  kl_total may be NULL (n ignored). */
 int lbbnn_forward_finish(uint64_t* rng, uint64_t advance, const float* const* kl_layers, int n,
@@ -371,6 +406,10 @@ int lbbnn_lrt_gemm_train(const float* x, int ldx, const void* e_w, const void* v
                          const float* eps, const uint64_t* rng, uint32_t rng_stream, int64_t row_offset,
                          float* out, int ldo, float* std_out, int B, int I, int O, int flags, void* stream);
 
+/* lbbnn_format_operand: dst[r][c] = src[r][c] (squared when `square`) as a GEMM operand [R][ld] (ld = lbbnn_operand_ld(C),
+ * zero tail, fp32 or LBBNN_F_SPLIT16) -- no transpose: the matrix already has the contraction index contiguous.  Used by
+ * the variational-dropout backward: theta (n,m) and theta^2 are the operands of dX = G . theta^T + 2 x (.) (G_v . (theta^2)^T). */
+int lbbnn_format_operand(const float* src, int R, int C, int lds_src, void* dst, int ld, int square, int flags, void* stream);
 int lbbnn_transpose_operand(const float* src, int R, int C, int lds_src, void* dst, int ld,
                             int square, int flags, void* stream);
 
@@ -518,6 +557,8 @@ typedef struct lbbnn_outgrad_args {
     int64_t row_offset;
     uint32_t rng_stream;
     int B, O, ldg, ldo, relu;
+    const float* gv_scale;                    /* NULL, or (O): G_v[b,o] *= gv_scale[o] -- the variational-dropout alpha
+                                                 (d delta / d(x^2 theta^2) = alpha, variational_dropout.py:65)          */
 } lbbnn_outgrad_args_t;
 
 int64_t lbbnn_output_grad_workspace(int B, int O);

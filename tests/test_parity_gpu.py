@@ -788,6 +788,48 @@ def test_vd_layer_vs_golden(bnn, dev, golden, case):
     assert rel_err(loss, c["loss"]) < 1e-5
 
 
+@pytest.mark.parametrize("B,n,m", [(37, 50, 24), (64, 96, 10), (128, 256, 160), (33, 16, 7)])
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_vd_backward_all_hip_vs_oracle_autograd(bnn, dev, B, n, m, prec):
+    """variational_dropout.py:170 ``loss.backward()`` through BayesianLayer: dX and dtheta from the HIP kernels
+    (lbbnn_output_grad with gv_scale = alpha, lbbnn_format_operand, lbbnn_vd_operands, lbbnn_transpose_operand, the GEMM
+    with the combine epilogue) against fp64 autograd of the oracle; injected zeta and the in-kernel draw."""
+    torch.manual_seed(14)
+    layer = bnn.vd.BayesianLayer(n, m).to(dev)
+    g = torch.Generator().manual_seed(15)
+    x = torch.randn(B, n, generator=g)
+    zeta = torch.randn(B, m, generator=g)
+    c = torch.randn(B, m, generator=g)
+    layer.noise = {"zeta": zeta.to(dev)}
+    xd = x.to(dev).requires_grad_(True)
+    bnn.set_precision(prec)
+    try:
+        out = layer(xd)
+        (out * c.to(dev)).sum().backward()
+    finally:
+        bnn.set_precision("fp32")
+    x64 = x.double().requires_grad_(True)
+    th64 = layer.theta.detach().cpu().double().requires_grad_(True)
+    ref = orc.vd_forward(x64, th64, layer.alpha.cpu().double(), zeta.double())
+    (ref * c.double()).sum().backward()
+    tol = 2e-4
+    assert rel_err(out, ref) < (TIGHT if prec == "fp32" else 2e-5)
+    assert rel_err(xd.grad, x64.grad) < tol and rel_err(layer.theta.grad, th64.grad) < tol
+    # in-kernel zeta: the backward re-creates the forward's draw from the saved Philox state
+    layer.noise = None
+    layer.theta.grad = None
+    bnn.manual_seed(3, 0)
+    st = bnn.ops.RngState.get(dev)
+    z_used = bnn.ops.philox_normal(st.t, bnn.ops.STREAM_EPS_OUT * 64 + layer._layer_id, B, m, 0)
+    xd2 = x.to(dev).requires_grad_(True)
+    out2 = layer(xd2)
+    (out2 * c.to(dev)).sum().backward()
+    x64b = x.double().requires_grad_(True)
+    th64b = layer.theta.detach().cpu().double().requires_grad_(True)
+    (orc.vd_forward(x64b, th64b, layer.alpha.cpu().double(), z_used.cpu().double()) * c.double()).sum().backward()
+    assert rel_err(xd2.grad, x64b.grad) < tol and rel_err(layer.theta.grad, th64b.grad) < tol
+
+
 def test_vd_network_full_size_and_training(bnn, dev):
     """BASELINE configs[4] shape (3072-4096-4096-10 'CIFAR-flat') forward vs fp64, in both precisions; then
     the reference's BNN (784-1200-1200-1200-10) takes optimizer steps."""
@@ -846,6 +888,61 @@ print("GRAPH_OK", vals[0], vals[-1])
 """ % root
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "GRAPH_OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_graphed_data_parallel_step_equals_eager_subprocess():
+    """parallel.DataParallelELBO.make_graphed_step (graph A: forward + backward + bucket pack | eager all-reduce | graph B:
+    Adam) at world size 1: after the same number of steps from the same state and the same Philox offsets the parameters
+    are bitwise those of the eager bucket step.  Own process (capture wants a clean autograd state)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, copy, torch
+sys.path.insert(0, %r)
+import bnn_amd
+from bnn_amd.parallel import DataParallelELBO
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+net = bnn_amd.mnf.BayesianNetwork((784, 128, 64, 10), 2, z_flow_type="Planar", r_flow_type="Planar").to(dev).train()
+init = copy.deepcopy(net.state_dict())
+x = torch.rand(256, 1, 28, 28, device=dev); y = torch.randint(0, 10, (256,), device=dev)
+res = []
+for mode in ("graph", "eager"):       # graph first: an eager autograd graph alive on the default stream breaks a later capture
+    net.load_state_dict(init)
+    opt = bnn_amd.optim.Adam(net.parameters(), lr=1e-3)
+    dp = DataParallelELBO(net)
+    if mode == "graph":
+        step = dp.make_graphed_step(opt, x, y, 100, warmup=2)
+        net.load_state_dict(init)                         # the warm-up steps moved the parameters: start over
+        opt2 = None
+        for st in opt.state.values():
+            st["exp_avg"].zero_(); st["exp_avg_sq"].zero_()
+        for g in opt.param_groups:
+            g["step_dev"].zero_()
+    losses = []
+    for it in range(4):
+        bnn_amd.manual_seed(50 + it)
+        if mode == "eager":
+            opt.zero_grad(set_to_none=True)
+            loss = dp.loss(net(x, sample=True), y, 100)
+            from bnn_amd import layers
+            with layers.vector_backward_overlap():
+                loss.backward()
+            dp.all_reduce_grads(unpack=False)
+            opt.step(grads=dp.reduced_grads())
+        else:
+            loss = step(x, y)
+        losses.append(float(loss.detach()))
+    torch.cuda.synchronize()
+    res.append(({k: v.detach().clone() for k, v in net.named_parameters()}, losses))
+assert res[0][1] == res[1][1], (res[0][1], res[1][1])
+for k in res[0][0]:
+    assert torch.equal(res[0][0][k], res[1][0][k]), k
+assert res[0][1][-1] < res[0][1][0]
+print("DPGRAPH_OK", res[0][1])
+""" % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "DPGRAPH_OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-2500:])
 
 
 # --------------------------------------------------------------------------- BASELINE.json configs as parity cases
@@ -1067,6 +1164,42 @@ def test_ensemble_eval_helper(bnn, dev):
     P = [{k: v.detach().cpu() for k, v in l.state_dict().items()} for l in (net.l1, net.l2, net.l3)]
     ref, _ = orc.lrt_network_forward(data.cpu(), P, [None] * 3, stochastic=False, compute_kl=False)
     assert torch.equal(ref.argmax(1), r["pred_posterior_mean"].cpu()) or rel_err(net(data).cpu(), ref) < TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family,dims,B,S", [("lrt", (784, 400, 600, 10), 1000, 10), ("mnf", (784, 1200, 1200, 10), 1000, 10),
+                                             ("mnf", (784, 96, 64, 10), 37, 3), ("lrt", (64, 48, 40, 24), 130, 4)])
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_ensemble_batched_equals_loop_bitwise(bnn, dev, family, dims, B, S, prec):
+    """test_ensemble's TEST_SAMPLES x net(data, sample=True) on one test batch (LBBNN-GP-MF-MNF.py:286-294, ...LRT.py:241-247;
+    reference sizes: 10 members x 1000 rows): the batched form -- ONE K3, ONE K1 and ONE GEMM launch per layer for all
+    members (lbbnn_ensemble_operands, lbbnn_lrt_gemm_members) -- equals the loop of fused single forwards BIT FOR BIT under
+    the same Philox {seed, offset}, and leaves the offset where the loop leaves it."""
+    torch.manual_seed(17)
+    if family == "lrt":
+        net = bnn.lrt.BayesianNetwork(dims).to(dev)
+    else:
+        net = bnn.mnf.BayesianNetwork(dims, 2, z_flow_type="Planar", r_flow_type="Planar").to(dev)
+    net.eval()
+    data = torch.rand(B, dims[0], device=dev)
+    st = bnn.ops.RngState.get(dev)
+    bnn.set_precision(prec)
+    try:
+        with torch.no_grad():
+            bnn.manual_seed(3, 5)
+            loop = torch.stack([net(data, sample=True) for _ in range(S)])
+            off_loop = int(st.t[1])
+            bnn.manual_seed(3, 5)
+            bat = bnn.evaluate.ensemble_forward(net, data, S)
+            off_bat = int(st.t[1])
+            assert bnn.evaluate._batched_ok(net, data)
+    finally:
+        bnn.set_precision("fp32")
+    assert bat.shape == (S, B, dims[-1]) and off_loop == off_bat == 5 + S
+    assert torch.equal(bat, loop)
+    assert not torch.equal(bat[0], bat[1])
+    r = bnn.evaluate.ensemble_eval(net, data, torch.randint(0, dims[-1], (B,), device=dev), samples=S)
+    assert r["outputs"].shape == (S, B, dims[-1])
 
 
 @pytest.mark.gpu
