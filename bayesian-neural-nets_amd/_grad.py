@@ -4,7 +4,6 @@ What still enters here from ``autograd.Function.backward`` (never from a forward
   * layers whose flows are 1-D chains (Radial / Householder / Sylvester / mixed): ``mnf_vector_graph`` over (I,) / (O,)
     vectors, with the noise the forward kernels drew re-created by ``lbbnn_philox_normal``;
   * the LRT layer's two bias terms (``lrt_vector_graph``);
-  * the baseline LBBNN layer (``base_torch``) -- the variational-dropout layer's backward is all HIP since round 2;
   * RNVP / MNF-type layers only when ``LBBNN_DENSE_TORCH_BWD=1`` asks for it (A/B timing, second opinion in tests).
 Everything (O,I)- or (B,O)-sized -- and, for planar and dense-flow MNF layers, every vector-sized gradient too -- is
 computed by the HIP kernels (``layers._BayesLinearFn.backward``).
@@ -271,42 +270,3 @@ def mnf_vector_graph(P, zf, rf, noise, act_mu, act_var, *, stochastic, want_kl, 
         g["z2"] = z2
         g["kl"] = _kl_bias(P["bias_mu"], P["bias_rho"], priors) + (-log_det_q + log_q0) - (log_det_r + log_rb)
     return g
-
-
-def base_torch(x, cgamma, tau_w, tau_b, P, noise, *, mode, want_lp, exact, alpha_attr, gamma_alpha):
-    """Baseline LBBNN layer (LBBNN-GP-MF.py:228-255) as differentiable torch ops; returns (out, log_prior, log_q)."""
-    def rnd(g, flag):
-        return torch.round(g.detach()) if flag else g
-    if mode == 0:
-        ws = P["weight_mu"] + _sigma(P["weight_rho"]) * noise["eps_w"]
-        weight = cgamma * ws
-        bias = P["bias_mu"] + _sigma(P["bias_rho"]) * noise["eps_b"]
-    elif mode == 1:
-        weight, bias = cgamma * P["weight_mu"], P["bias_mu"]
-    else:
-        weight, bias = alpha_attr * P["weight_mu"], P["bias_mu"]
-    out = x @ weight.T + bias
-    lp = lq = None
-    if want_lp:
-        half_log_2pi = 0.5 * math.log(2 * math.pi)
-
-        def gg(xv, g, a, b, tau, flag):
-            g1 = rnd(g, flag)
-            return (g1 * (a * torch.log(b) + (a - 0.5) * tau - b * tau - torch.lgamma(a) - half_log_2pi)
-                    - tau * xv ** 2 + (1 - g1) + 1e-8).sum()
-        pa, pb = P["pa"], P["pb"]
-        gbb = rnd(cgamma, exact & 4)
-        one = torch.ones_like(cgamma)
-        bb = (torch.lgamma(one) + torch.lgamma(gbb + one * pa) + torch.lgamma(one * (1 + pb) - gbb)
-              + torch.lgamma(one * (pa + pb)) - torch.lgamma(one * pa + gbb) - torch.lgamma(one * 2 - gbb)
-              - torch.lgamma(one * (1 + pa + pb)) - torch.lgamma(one * pa) - torch.lgamma(one * pb)).sum()
-        lp = (gg(weight, cgamma, P["weight_a"], P["weight_b"], tau_w, exact & 1)
-              + gg(bias, torch.ones_like(bias), P["bias_a"], P["bias_b"], tau_b, exact & 2) + bb)
-        sw, sb = _sigma(P["weight_rho"]), _sigma(P["bias_rho"])
-        lpdf = -math.log(math.sqrt(2 * math.pi)) - torch.log(sw) - (weight - P["weight_mu"]) ** 2 / (2 * sw ** 2)
-        full = torch.log(cgamma * torch.exp(lpdf) + (1 - cgamma) + 1e-8).sum()
-        gbe = rnd(cgamma, exact & 8)
-        bern = (gbe * torch.log(gamma_alpha + 1e-8) + (1 - gbe) * torch.log(1 - gamma_alpha + 1e-8)).sum()
-        qb = (-math.log(math.sqrt(2 * math.pi)) - torch.log(sb) - (bias - P["bias_mu"]) ** 2 / (2 * sb ** 2)).sum()
-        lq = full + bern + qb
-    return out, lp, lq

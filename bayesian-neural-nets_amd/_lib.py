@@ -104,6 +104,15 @@ class DenseGrad(ctypes.Structure):
 MAX_DENSE_T = 8
 
 
+class GateBwdArgs(ctypes.Structure):
+    """lbbnn_gate_bwd_args_t"""
+    _fields_ = [(n, c_p) for n in ("mu", "rho", "gamma_alpha", "cgamma", "eps_w", "bias_mu", "bias_rho", "eps_b", "bias_a",
+                                   "bias_b", "tau_b", "weight_a", "weight_b", "tau_w", "pa", "pb", "dW", "g_sum", "g_lp", "g_lq",
+                                   "d_mu", "d_rho", "d_cgamma", "d_alpha", "w_out", "d_bias_mu", "d_bias_rho", "d_bias_a",
+                                   "d_bias_b", "d_tau_b", "d_scalars", "rows")] + \
+               [("O", c_i), ("I", c_i), ("exact", c_i), ("layer_id", c_u32)]
+
+
 class OutGradArgs(ctypes.Structure):
     """lbbnn_outgrad_args_t"""
     _fields_ = [(n, c_p) for n in ("g_out", "out", "std", "eps", "rng", "gm", "gv", "gmT", "gvT", "g_sum", "gv_sum", "work")] + \
@@ -173,6 +182,7 @@ SIGNATURES = {
     "lbbnn_flow_dense_rows_max_dim": (c_i, []),
     "lbbnn_flow_dense_rows": (c_i, [ctypes.POINTER(DenseTransform), c_i, c_p, c_p, c_p, c_u32, c_u64, c_p, c_i, c_i, c_i,
                                     c_p, c_i, c_p, c_p]),
+    "lbbnn_gate_backward": (c_i, [ctypes.POINTER(GateBwdArgs), c_p, c_p]),
     "lbbnn_format_operand": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p]),
     "lbbnn_multi_copy": (c_i, [ctypes.POINTER(CopyList), c_p]),
     "lbbnn_adam_step": (c_i, [ctypes.POINTER(AdamList), ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,

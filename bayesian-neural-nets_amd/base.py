@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import _grad, _lib, ops
+from . import _lib, ops
 from .distributions import Bernoulli, Gaussian, TEMPER_PRIOR  # noqa: F401  (TEMPER_PRIOR re-exported: the reference scripts read it here)
 
 _ids = itertools.count(32)
@@ -46,32 +46,67 @@ class BetaBinomial(object):
 
 
 class _BaseFn(torch.autograd.Function):
+    """Forward: lbbnn_gate_sample + the mean-only GEMM.  Backward (round 2: all on the HIP kernels; round 1 recomputed the
+    layer with torch ops): lbbnn_output_grad (G^T, column sums) -> dW = G^T x on the GEMM kernel -> lbbnn_gate_backward
+    (K6b: every (O,I)-, (O)- and scalar-sized gradient in one pass + tail, and the sampled W as a dense matrix) ->
+    dX = G W on the GEMM kernel.  ``galpha`` is ``layer.gamma.alpha`` as an autograd input: Bernoulli.log_prob
+    differentiates through it (LBBNN-GP-MF.py:125-127, alpha = sigmoid(lambdal) set by sample_elbo :292-297)."""
+
     @staticmethod
-    def forward(ctx, layer, x, cgamma, tau_w, tau_b, cfg, *params):
+    def forward(ctx, layer, x, cgamma, tau_w, tau_b, galpha, cfg, *params):
         out, lp, lq, saved = layer._forward_hip(x, cgamma, tau_w, tau_b, cfg, save_rng=True)
         ctx.layer, ctx.cfg, ctx.saved = layer, cfg, saved
-        ctx.save_for_backward(x, cgamma, tau_w, tau_b, *params)
+        ctx.save_for_backward(x, tau_w, tau_b, *params)
         z = out.new_zeros(())
         return out, (lp if lp is not None else z), (lq if lq is not None else z)
 
     @staticmethod
     def backward(ctx, g_out, g_lp, g_lq):
-        layer, cfg = ctx.layer, ctx.cfg
-        x, cgamma, tau_w, tau_b, *params = ctx.saved_tensors
-        noise = layer._noise_for_backward(ctx.saved)
-        with torch.enable_grad():
-            leaves = [t.detach().requires_grad_(True) for t in (x, cgamma, tau_w, tau_b)] + \
-                     [p.detach().requires_grad_(True) for p in params]
-            P = dict(zip(layer._names, leaves[4:]))
-            out_t, lp_t, lq_t = _grad.base_torch(leaves[0], leaves[1], leaves[2], leaves[3], P, noise,
-                                                 mode=cfg[0], want_lp=cfg[1], exact=cfg[2],
-                                                 alpha_attr=ctx.saved["alpha_attr"], gamma_alpha=ctx.saved["gamma_alpha"])
-            outs, gs = [out_t], [g_out]
-            if lp_t is not None:
-                outs += [lp_t, lq_t]
-                gs += [g_lp, g_lq]
-            grads = torch.autograd.grad(outs, leaves, gs, allow_unused=True)
-        return (None, grads[0], grads[1], grads[2], grads[3], None, *grads[4:])
+        from .layers import _hip_matmul_nt
+        layer, cfg, saved = ctx.layer, ctx.cfg, ctx.saved
+        x, tau_w, tau_b, *params = ctx.saved_tensors
+        P = dict(zip(layer._names, params))
+        O, I, dev = layer.out_features, layer.in_features, x.device
+        f = dict(dtype=torch.float32, device=dev)
+        noise = saved.get("noise") or {}
+        gm, _, gmT, _, g_sum, _ = ops.output_grad(g_out.contiguous())
+        dW = _hip_matmul_nt(gmT, ops.transpose_operand, x)                       # (O,I) = G^T x
+        a = _lib.GateBwdArgs()
+        keep = []
+
+        def dptr(t):
+            if t is None:
+                return None
+            u = t.detach()
+            if u.dtype != torch.float32 or not u.is_contiguous():
+                u = u.float().contiguous()
+            keep.append(u)
+            return ops._ptr(u, "tensor")
+        a.mu, a.rho = dptr(P["weight_mu"]), dptr(P["weight_rho"])
+        a.gamma_alpha, a.cgamma = dptr(saved["gamma_alpha"]), dptr(saved["cg"])
+        a.eps_w, a.eps_b = dptr(noise.get("eps_w")), dptr(noise.get("eps_b"))
+        a.bias_mu, a.bias_rho, a.bias_a, a.bias_b = dptr(P["bias_mu"]), dptr(P["bias_rho"]), dptr(P["bias_a"]), dptr(P["bias_b"])
+        a.tau_b, a.tau_w = dptr(tau_b), dptr(tau_w)
+        a.weight_a, a.weight_b, a.pa, a.pb = dptr(P["weight_a"]), dptr(P["weight_b"]), dptr(P["pa"]), dptr(P["pb"])
+        a.dW, a.g_sum = dW.data_ptr(), g_sum.data_ptr()
+        a.g_lp, a.g_lq = dptr(g_lp.reshape(1)), dptr(g_lq.reshape(1))
+        outs = {n: torch.empty((O, I), **f) for n in ("d_mu", "d_rho", "d_cgamma", "d_alpha", "w_out")}
+        vecs = {n: torch.empty(O, **f) for n in ("d_bias_mu", "d_bias_rho", "d_bias_a", "d_bias_b", "d_tau_b")}
+        scal, rows = torch.empty(5, **f), torch.empty(3 * O, **f)
+        for n, t in list(outs.items()) + list(vecs.items()):
+            setattr(a, n, t.data_ptr())
+        a.d_scalars, a.rows = scal.data_ptr(), rows.data_ptr()
+        a.O, a.I, a.exact, a.layer_id = O, I, cfg[2], layer._layer_id
+        rng = saved.get("rng")
+        _lib.check(_lib.lib().lbbnn_gate_backward(ctypes.byref(a), rng.data_ptr() if rng is not None else None, ops._stream()),
+                   "lbbnn_gate_backward")
+        del keep
+        gx = _hip_matmul_nt(gm, ops.transpose_operand, outs["w_out"]) if ctx.needs_input_grad[1] else None   # G W
+        grads = {"weight_mu": outs["d_mu"], "weight_rho": outs["d_rho"], "weight_a": scal[0:1], "weight_b": scal[1:2],
+                 "lambdal": None, "pa": scal[3:4], "pb": scal[4:5], "bias_mu": vecs["d_bias_mu"],
+                 "bias_rho": vecs["d_bias_rho"], "bias_a": vecs["d_bias_a"], "bias_b": vecs["d_bias_b"]}
+        return (None, gx, outs["d_cgamma"], scal[2:3].reshape(tau_w.shape), vecs["d_tau_b"].reshape(tau_b.shape),
+                outs["d_alpha"], None, *[grads[n] for n in layer._names])
 
 
 class BayesianLinear(nn.Module):
@@ -192,9 +227,14 @@ class BayesianLinear(nn.Module):
         x = input.float()
         params = [getattr(self, n) for n in self._names]
         needs = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
-        if needs and want_lp:
-            out, lp, lq = _BaseFn.apply(self, x, cgamma.to(dev), tau_w, tau_b, cfg, *params)
+        if needs and want_lp and mode == 0:
+            galpha = self.gamma.alpha if torch.is_tensor(self.gamma.alpha) else torch.as_tensor(self.gamma.alpha)
+            out, lp, lq = _BaseFn.apply(self, x, cgamma.to(dev), tau_w, tau_b, galpha.to(dev), cfg, *params)
         else:
+            if needs and want_lp:
+                raise NotImplementedError("bnn_amd: gradients through the medimean / mean branches with calculate_log_probs "
+                                          "are not implemented (the reference differentiates the sampled branch only, "
+                                          "LBBNN-GP-MF.py:331-337); wrap evaluation in torch.no_grad()")
             out, lp, lq, _ = self._forward_hip(x, cgamma, tau_w, tau_b, cfg)
         if want_lp:
             self.alpha = 1 / (1 + torch.exp(-self.lambdal))           # :246

@@ -125,6 +125,104 @@ __global__ __launch_bounds__(256) void gate_finalize_kernel(const lbbnn_gate_arg
     }
 }
 
+// ------------------------------------------------------------------------------------------------ K6b
+// Backward of the sampled baseline layer (LBBNN-GP-MF.py:228-255 under loss.backward(), :331-337): one pass over (O,I)
+// turns the upstream gradients -- dW = G^T x of F.linear (:255), and the scalars g_lp = dL/dlog_prior, g_lq = dL/dlog_q --
+// into d weight_mu, d weight_rho, d cgamma, d gamma.alpha and the row sums the scalar parameters need; a single-workgroup
+// tail adds those up (weight_a, weight_b, tau_w, pa, pb) and does the (O)-sized bias chain.  Also rewrites the sampled
+// weight W as a dense fp32 (O,I) matrix for the dX product.  eps_w / eps_b are re-created from the forward's Philox state.
+// psi = digamma by upward recurrence to x >= 6 and the asymptotic series (|error| < 1e-6 for x >= 0.5).
+__device__ __forceinline__ float digammaf_pos(float x) {
+    float r = 0.f;
+#pragma unroll 1
+    while (x < 6.f) { r -= 1.f / x; x += 1.f; }
+    const float i = 1.f / x, i2 = i * i;
+    return r + logf(x) - 0.5f * i - i2 * (0.083333333f - i2 * (0.0083333333f - i2 * 0.003968254f));
+}
+
+struct GateScal { float C, tau, pa, pb, glp, glq; };
+
+__global__ __launch_bounds__(256) void gate_backward_kernel(const lbbnn_gate_bwd_args_t a, const uint64_t* rng) {
+    __shared__ double red[3][4];
+    const int o = blockIdx.x, tid = threadIdx.x;
+    const size_t ro = (size_t)o * a.I;
+    uint64_t seed = 0, offs = 0;
+    if (!a.eps_w) { seed = rng[0]; offs = rng[1]; }
+    const float wa = a.weight_a[0], wb = a.weight_b[0], tau = a.tau_w[0], pb = a.pb[0];
+    const float C = wa * logf(wb) + (wa - 0.5f) * tau - wb * tau - lgammaf(wa) - 0.5f * 1.8378770664093453f;
+    const float glp = a.g_lp ? a.g_lp[0] : 0.f, glq = a.g_lq ? a.g_lq[0] : 0.f;
+    double s_c = 0.0, s_w2 = 0.0, s_psi = 0.0;
+    for (int i = tid; i < a.I; i += 256) {
+        const float mu = a.mu[ro + i], g = a.cgamma[ro + i];
+        float e;
+        if (a.eps_w) e = a.eps_w[ro + i];
+        else { float n[4]; philox_normal4(seed, offs, LBBNN_STREAM_EPS_W * 64u + a.layer_id, (uint64_t)o, (uint32_t)(i >> 2), n); e = n[i & 3]; }
+        const float rho = a.rho[ro + i];
+        const float sigma = softplus_ref(rho);
+        const float ws = mu + sigma * e, w = g * ws;
+        if (a.w_out) a.w_out[ro + i] = w;
+        const float d = w - mu, is2 = 1.f / (sigma * sigma);
+        const float lp = -0.9189385332046727f - logf(sigma) - (d * d) * 0.5f * is2;
+        const float E = expf(lp), D = g * E + (1.f - g) + 1e-8f;
+        const float q = glq * (g * E / D);                         // g_lq * d full_log_prob / d lp
+        const float A = (a.dW ? a.dW[ro + i] : 0.f) + glp * (-2.f * tau * w) + q * (-d * is2);       // dL/dW
+        const float g_wp = (a.exact & 1) ? rintf(g) : g, g_bb = (a.exact & 4) ? rintf(g) : g, g_be = (a.exact & 8) ? rintf(g) : g;
+        const float al = a.gamma_alpha[ro + i];
+        float dg = A * ws + glq * ((E - 1.f) / D);
+        if (!(a.exact & 1)) dg += glp * (C - 1.f);
+        const float psi1 = digammaf_pos(1.f + pb - g_bb);
+        if (!(a.exact & 4)) dg += glp * (-psi1 + digammaf_pos(2.f - g_bb));
+        if (!(a.exact & 8)) dg += glq * (logf(al + 1e-8f) - logf(1.f - al + 1e-8f));
+        const float dws = A * g;
+        a.d_mu[ro + i] = dws + q * (d * is2);
+        const float dsig = dws * e + q * (-1.f / sigma + (d * d) * is2 / sigma);
+        a.d_rho[ro + i] = dsig / (1.f + expf(-rho));
+        a.d_cgamma[ro + i] = dg;
+        a.d_alpha[ro + i] = glq * (g_be / (al + 1e-8f) - (1.f - g_be) / (1.f - al + 1e-8f));
+        s_c += (double)g_wp; s_w2 += (double)(w * w); s_psi += (double)psi1;
+    }
+    s_c = wave_sum(s_c); s_w2 = wave_sum(s_w2); s_psi = wave_sum(s_psi);
+    const int lane = tid & 63, wv = tid >> 6;
+    if (lane == 0) { red[0][wv] = s_c; red[1][wv] = s_w2; red[2][wv] = s_psi; }
+    __syncthreads();
+    if (tid < 3) a.rows[(size_t)tid * a.O + o] = (float)((red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]));
+}
+
+__global__ __launch_bounds__(256) void gate_backward_tail_kernel(const lbbnn_gate_bwd_args_t a, const uint64_t* rng) {
+    __shared__ double scratch[4];
+    const int tid = threadIdx.x;
+    uint64_t seed = 0, offs = 0;
+    if (!a.eps_b) { seed = rng[0]; offs = rng[1]; }
+    const float glp = a.g_lp ? a.g_lp[0] : 0.f, glq = a.g_lq ? a.g_lq[0] : 0.f;
+    double r0 = 0, r1 = 0, r2 = 0;
+    for (int o = tid; o < a.O; o += 256) {
+        r0 += (double)a.rows[o]; r1 += (double)a.rows[(size_t)a.O + o]; r2 += (double)a.rows[2 * (size_t)a.O + o];
+        const float rho = a.bias_rho[o], sb = softplus_ref(rho), bm = a.bias_mu[o];
+        float e;
+        if (a.eps_b) e = a.eps_b[o];
+        else { float n[4]; philox_normal4(seed, offs, LBBNN_STREAM_EPS_B * 64u + a.layer_id, (uint64_t)(o >> 2), 0u, n); e = n[o & 3]; }
+        const float b = bm + sb * e, d = b - bm, is2 = 1.f / (sb * sb);
+        const float ba = a.bias_a[o], bb = a.bias_b[o], tb = a.tau_b[o];
+        const float db = (a.g_sum ? a.g_sum[o] : 0.f) + glp * (-2.f * tb * b) + glq * (-d * is2);      // dL/db
+        a.d_bias_mu[o] = db + glq * (d * is2);
+        a.d_bias_rho[o] = (db * e + glq * (-1.f / sb + (d * d) * is2 / sb)) / (1.f + expf(-rho));
+        a.d_bias_a[o] = glp * (logf(bb) + tb - digammaf_pos(ba));
+        a.d_bias_b[o] = glp * (ba / bb - tb);
+        a.d_tau_b[o] = glp * ((ba - 0.5f) - bb - b * b);
+    }
+    r0 = block_sum<double, 4>(r0, scratch); r1 = block_sum<double, 4>(r1, scratch); r2 = block_sum<double, 4>(r2, scratch);
+    if (tid == 0) {
+        const float wa = a.weight_a[0], wb = a.weight_b[0], tau = a.tau_w[0], pa = a.pa[0], pb = a.pb[0];
+        const double N = (double)a.O * (double)a.I;
+        a.d_scalars[0] = glp * (float)(r0 * (double)(logf(wb) + tau - digammaf_pos(wa)));             // d weight_a
+        a.d_scalars[1] = glp * (float)(r0 * (double)(wa / wb - tau));                                 // d weight_b
+        a.d_scalars[2] = glp * (float)(r0 * (double)((wa - 0.5f) - wb) - r1);                         // d tau_w
+        const float common = digammaf_pos(pa + pb) - digammaf_pos(1.f + pa + pb);
+        a.d_scalars[3] = glp * (float)(N * (double)(common - digammaf_pos(pa)));                      // d pa
+        a.d_scalars[4] = glp * (float)(r2 + N * (double)(common - digammaf_pos(pb)));                 // d pb
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ K7
 // 32x32 tiles of theta (I,O) through LDS: coalesced reads along O, coalesced writes along I.
 __global__ __launch_bounds__(256) void vd_operands_kernel(const float* __restrict__ theta, void* e_w, void* var_w,
@@ -267,6 +365,21 @@ extern "C" int lbbnn_gate_sample(const lbbnn_gate_args_t* p, const uint64_t* rng
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(gate_sample_kernel, dim3(a.O), dim3(256), 0, s, a, rng);
     hipLaunchKernelGGL(gate_finalize_kernel, dim3(1), dim3(256), 0, s, a, rng);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lbbnn_gate_backward(const lbbnn_gate_bwd_args_t* p, const uint64_t* rng, void* stream) {
+    if (!p) return LBBNN_E_NULL;
+    const lbbnn_gate_bwd_args_t& a = *p;
+    if (!a.mu || !a.rho || !a.gamma_alpha || !a.cgamma || !a.bias_mu || !a.bias_rho || !a.bias_a || !a.bias_b || !a.tau_b ||
+        !a.weight_a || !a.weight_b || !a.tau_w || !a.pa || !a.pb) return LBBNN_E_NULL;
+    if (!a.d_mu || !a.d_rho || !a.d_cgamma || !a.d_alpha || !a.d_bias_mu || !a.d_bias_rho || !a.d_bias_a || !a.d_bias_b ||
+        !a.d_tau_b || !a.d_scalars || !a.rows) return LBBNN_E_NULL;
+    if ((!a.eps_w || !a.eps_b) && !rng) return LBBNN_E_NOISE;
+    if (a.O <= 0 || a.I <= 0) return LBBNN_E_SHAPE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(gate_backward_kernel, dim3(a.O), dim3(256), 0, s, a, rng);
+    hipLaunchKernelGGL(gate_backward_tail_kernel, dim3(1), dim3(256), 0, s, a, rng);
     return (int)hipGetLastError();
 }
 

@@ -371,6 +371,27 @@ typedef struct lbbnn_gate_args {
 
 int lbbnn_gate_sample(const lbbnn_gate_args_t* args, const uint64_t* rng, void* stream);
 
+/* K6b  lbbnn_gate_backward -- backward of the SAMPLED baseline layer (mode LBBNN_MODE_SAMPLE with log-probabilities: what
+ * net.sample_elbo(...)[0].backward() differentiates, LBBNN-GP-MF.py:331-337).  Inputs: the forward's arguments (eps_w /
+ * eps_b explicit, or NULL + the forward's rng state: same Philox streams), dW (O,I) = G^T x of F.linear (NULL = 0),
+ * g_sum (O) = column sums of G (NULL = 0), and the device scalars g_lp = dL/dlog_prior, g_lq = dL/dlog_q (NULL = 0).
+ * Outputs: d_mu, d_rho, d_cgamma, d_alpha (O,I) [d_alpha: through Bernoulli.log_prob's alpha, :125-127]; d_bias_mu,
+ * d_bias_rho, d_bias_a, d_bias_b, d_tau_b (O); d_scalars[5] = d weight_a, d weight_b, d tau_w, d pa, d pb; w_out (O,I,
+ * nullable): the sampled weight as a dense fp32 matrix (the operand of dX = G W).  rows: 3*O floats of workspace.
+ * `exact` bits as in the forward (a rounded, detached gate passes no gradient).  Two launches. */
+typedef struct lbbnn_gate_bwd_args {
+    const float *mu, *rho, *gamma_alpha, *cgamma, *eps_w;                    /* (O,I) */
+    const float *bias_mu, *bias_rho, *eps_b, *bias_a, *bias_b, *tau_b;       /* (O)   */
+    const float *weight_a, *weight_b, *tau_w, *pa, *pb;                      /* (1)   */
+    const float *dW, *g_sum, *g_lp, *g_lq;
+    float *d_mu, *d_rho, *d_cgamma, *d_alpha, *w_out;
+    float *d_bias_mu, *d_bias_rho, *d_bias_a, *d_bias_b, *d_tau_b, *d_scalars, *rows;
+    int O, I, exact;
+    uint32_t layer_id;
+} lbbnn_gate_bwd_args_t;
+
+int lbbnn_gate_backward(const lbbnn_gate_bwd_args_t* args, const uint64_t* rng, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K7  lbbnn_vd_operands -- Gaussian variational-dropout layer (variational_dropout.py:55-68).
  *   phi = x.theta ; delta = (x^2).(theta^2) * alpha ; out = phi + sqrt(delta)*zeta        :64-67

@@ -743,6 +743,61 @@ def test_base_backward_and_sample_elbo(bnn, dev, golden):
     assert all(math.isfinite(v) for v in vals)
 
 
+@pytest.mark.parametrize("case", ["c0", "c1", "c2"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_base_backward_all_hip_full_graph_vs_oracle_autograd(bnn, dev, golden, case, prec):
+    """loss.backward() of the baseline layer as sample_elbo builds the graph (LBBNN-GP-MF.py:292-318): alpha = sigmoid(lambdal)
+    feeds BOTH the relaxed gate draw and Bernoulli.log_prob, taus are Gamma rsamples of (a, b).  Every gradient --
+    x, weight_mu/rho, lambdal (through the gate AND through alpha), weight_a/b, pa, pb, bias_mu/rho/a/b -- from the HIP
+    backward (lbbnn_output_grad, GEMMs, lbbnn_gate_backward) against fp64 autograd of the oracle on the same draws.  The
+    gate uses temperature 0.5 instead of the reference's 0.001 so that it is not saturated and its gradient is informative."""
+    c = golden("base.npz").case(case)
+    B, I, O = [int(v) for v in c["shape"]]
+    p = sub(c, "p.")
+    layer = _load_layer(bnn.base.BayesianLinear(I, O, 1), p, dev).train()
+    g = torch.Generator().manual_seed(77)
+    logistic = torch.log(torch.rand(O, I, generator=g).clamp(1e-6, 1 - 1e-6))
+    logistic = logistic - torch.log1p(-torch.exp(logistic))
+    noise = {k: c[k] for k in ("eps_w", "eps_b")}
+    gam_w = torch.rand(1, generator=g) + 0.5          # stand-ins for the Gamma draws' dependence on (a, b): tau = u * a / b
+    gam_b = torch.rand(O, generator=g) + 0.5
+
+    def build(P, x, lib):
+        alpha = 1 / (1 + torch.exp(-P["lambdal"]))
+        cg = torch.sigmoid((torch.log(alpha) - torch.log1p(-alpha) + lib(logistic)) / 0.5)
+        tau_w = lib(gam_w) * P["weight_a"] / P["weight_b"]
+        tau_b = lib(gam_b) * P["bias_a"] / P["bias_b"]
+        return alpha, cg, tau_w, tau_b
+
+    # HIP path
+    P = dict(layer.named_parameters())
+    x = c["x"].to(dev).requires_grad_(True)
+    alpha, cg, tau_w, tau_b = build(P, x, lambda t: t.to(dev))
+    layer.gamma.alpha = alpha
+    layer.noise = {"eps_w": noise["eps_w"].to(dev), "eps_b": noise["eps_b"].to(dev), "tau_w": tau_w, "tau_b": tau_b}
+    bnn.set_precision(prec)
+    try:
+        out = layer(x, cg, sample=True)
+        loss = (out ** 2).sum() + (layer.log_variational_posterior - layer.log_prior) / 600
+        loss.backward()
+    finally:
+        bnn.set_precision("fp32")
+    # oracle, fp64
+    P64 = {k: v.double().clone().requires_grad_(True) for k, v in p.items()}
+    x64 = c["x"].double().requires_grad_(True)
+    a64, cg64, tw64, tb64 = build(P64, x64, lambda t: t.double())
+    n64 = {"eps_w": noise["eps_w"].double(), "eps_b": noise["eps_b"].double(), "tau_w": tw64, "tau_b": tb64}
+    o, lp, lq = orc.base_forward(x64, P64, cg64, n64, mode="sample", gamma_alpha=a64)
+    ((o ** 2).sum() + (lq - lp) / 600).backward()
+    assert rel_err(out, o) < (TIGHT if prec == "fp32" else 2e-5)
+    assert rel_err(layer.log_prior, lp) < 2e-5 and rel_err(layer.log_variational_posterior, lq) < 2e-5
+    tol = 2e-4 if prec == "fp32" else 5e-4
+    assert rel_err(x.grad, x64.grad) < tol
+    for name, prm in layer.named_parameters():
+        assert P64[name].grad is not None, name
+        assert rel_err(prm.grad, P64[name].grad) < tol, name
+
+
 def test_base_network_sample_elbo_vs_reference_anchor(bnn, dev, golden):
     """net.sample_elbo(input, target) -- the reference's call, LBBNN-GP-MF.py:331 -- on the HIP path against the
     reference's own numbers at SURVEY.md 8c's anchor (tests/golden/base_elbo.npz: seed 0, 784-400-600-10, B = 100;
