@@ -14,8 +14,9 @@ in-kernel (Philox).  Data parallel: every rank holds the (replicated) parameters
 
 How the number is taken (round 2; the round-1 line did not reproduce under the driver's command):
   1. W untimed warm-up steps (--warmup, honoured and reported), then warm-up CONTINUES to steady
-     state: chunks of 5 steps are timed with HIP events until the last 3 chunk times agree within
-     5 % or 0.5 s has passed ("settle" in the JSON).
+     state: blocks of 25 steps run back to back (no synchronisation between them) until the last
+     4 block times agree within 2 % or 0.5 s has passed ("settle" in the JSON) -- a fresh GPU needs
+     tens of milliseconds to reach its clocks, far longer than 5 warm-up steps.
   2. the timed region: barrier + synchronize, EXACTLY K steps, barrier + synchronize; MAX over
      ranks; ms_per_step = elapsed / K.  One pre-created, pre-recorded HIP event marks each step
      boundary inside the region (ms_per_step_median/min/max: an outlier step is visible).  A region
@@ -52,8 +53,9 @@ BATCH = 4096
 FP32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md, dense BF16 MFMA
 HBM_PEAK_GBS = 8000.0
-SETTLE_CHUNK = 5
-SETTLE_TOL = 0.05
+SETTLE_BLOCK = 25        # steps per block of the steady-state warm-up
+SETTLE_WINDOW = 4        # ... whose last this-many block times must agree
+SETTLE_TOL = 0.02        # ... within this
 SETTLE_MAX_S = 0.5
 
 
@@ -161,22 +163,41 @@ def _recorded_events(n):
     return evs
 
 
-def settle(run_step):
-    """Warm-up to steady state: chunks of SETTLE_CHUNK steps until the last three chunk times agree within SETTLE_TOL
-    or SETTLE_MAX_S has passed.  Returns the report for the JSON line."""
-    evs = _recorded_events(2)
+def settle(run_step, world=1):
+    """Warm-up to steady state.  Blocks of SETTLE_BLOCK steps are enqueued back to back with one event between blocks;
+    the host only ever waits for the block BEFORE the one it has just enqueued, so the GPU queue never drains (a
+    synchronisation between blocks would put the ~0.1 ms pipeline refill into every measurement -- the first settle
+    logic of this round did, and called a GPU that was still ramping its clocks converged).  Done when the last
+    SETTLE_WINDOW block times agree within SETTLE_TOL, or after SETTLE_MAX_S.  Returns the report for the JSON line."""
+    max_blocks = 256
+    evs = _recorded_events(max_blocks + 2)
     times, t_start = [], time.perf_counter()
+    evs[0].record()
+    for _ in range(SETTLE_BLOCK):
+        run_step()
+    evs[1].record()
+    k, ok = 1, False
     while True:
-        evs[0].record()
-        for _ in range(SETTLE_CHUNK):
+        for _ in range(SETTLE_BLOCK):
             run_step()
-        evs[1].record()
-        evs[1].synchronize()
-        times.append(evs[0].elapsed_time(evs[1]) / SETTLE_CHUNK)
-        ok = len(times) >= 3 and max(times[-3:]) <= (1.0 + SETTLE_TOL) * min(times[-3:])
-        if ok or time.perf_counter() - t_start > SETTLE_MAX_S:
-            return {"steps": len(times) * SETTLE_CHUNK, "ms": (time.perf_counter() - t_start) * 1e3, "converged": bool(ok),
-                    "first_chunk_ms_per_step": times[0], "last_chunks_ms_per_step": times[-3:]}
+        evs[k + 1].record()
+        evs[k].synchronize()                                   # block k-1 is done; block k is running
+        times.append(evs[k - 1].elapsed_time(evs[k]) / SETTLE_BLOCK)
+        k += 1
+        w = times[-SETTLE_WINDOW:]
+        ok = len(w) == SETTLE_WINDOW and max(w) <= (1.0 + SETTLE_TOL) * min(w)
+        stop = ok or time.perf_counter() - t_start > SETTLE_MAX_S or k >= max_blocks
+        if world > 1:
+            # every rank must run the same number of steps (the training step contains a collective): stop together,
+            # when the LAST rank is ready
+            import torch.distributed as dist
+            flag = torch.tensor([0.0 if stop else 1.0], device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            stop = bool(flag.item() == 0.0) or k >= max_blocks
+        if stop:
+            break
+    return {"steps": (k + 1) * SETTLE_BLOCK, "ms": (time.perf_counter() - t_start) * 1e3, "converged": bool(ok),
+            "first_block_ms_per_step": times[0], "last_blocks_ms_per_step": times[-SETTLE_WINDOW:]}
 
 
 STALL_FACTOR = 10.0     # a step this many times longer than the region's median step is an external stall
@@ -303,7 +324,7 @@ def forward_leg(args, bnn_amd, ops, net, x, sync, precision, world):
             with torch.cuda.graph(graph):
                 out, kl = step()
             run = graph.replay
-        leg["settle"] = settle(run)
+        leg["settle"] = settle(run, world)
         leg["attempts"] = []
         elapsed, per_step = timed_region(run, args.steps, sync, not args.no_step_events, leg["attempts"], world)
         if not args.graph:
@@ -353,7 +374,7 @@ def train_leg(args, bnn_amd, net, x, sync, world, rank):
     for _ in range(max(3, min(args.warmup, 10))):
         step()
     sync()
-    st = settle(step)
+    st = settle(step, world)
     steps = max(5, min(args.steps, 50))
     attempts = []
     elapsed, per_step = timed_region(step, steps, sync, not args.no_step_events, attempts, world)
