@@ -20,7 +20,11 @@ class Adam(torch.optim.Optimizer):
             raise NotImplementedError("bnn_amd.optim.Adam: amsgrad / maximize are not implemented")
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
             raise ValueError("bnn_amd.optim.Adam: invalid hyper-parameter")
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        # (the extra keys are torch.optim.Adam's own group keys at their defaults: a state_dict of this optimizer then loads
+        # into torch.optim.Adam and back)
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
+                                      foreach=None, capturable=False, differentiable=False, fused=None,
+                                      decoupled_weight_decay=False))
 
     def _group_state(self, group):
         st = self.state
@@ -34,6 +38,40 @@ class Adam(torch.optim.Optimizer):
             ref = group["params"][0]
             group["step_dev"] = torch.zeros(1, dtype=torch.float32, device=ref.device)
         return group["step_dev"]
+
+    # torch.optim.Adam keeps one ``state[p]["step"]`` per parameter; this optimizer keeps ONE device-side counter per
+    # parameter group (``group["step_dev"]``: every parameter of a group is updated in the same launch, so their counts
+    # cannot differ).  state_dict() / load_state_dict() translate between the two, so that checkpoints interchange with
+    # torch.optim.Adam and bias correction continues where it stopped.
+    def state_dict(self):
+        sd = super().state_dict()
+        for gi, group in enumerate(self.param_groups):
+            step = group.get("step_dev")
+            sg = sd["param_groups"][gi]
+            sg.pop("step_dev", None)
+            if step is not None:
+                val = step.detach().clone().reshape(())
+                for idx in sg["params"]:
+                    if idx in sd["state"]:
+                        sd["state"][idx] = dict(sd["state"][idx], step=val)
+        return sd
+
+    def load_state_dict(self, state_dict):
+        steps = {}
+        for gi, sg in enumerate(state_dict["param_groups"]):
+            for idx in sg["params"]:
+                st = state_dict["state"].get(idx)
+                if st is not None and "step" in st:
+                    steps[gi] = float(torch.as_tensor(st["step"]).reshape(-1)[0])
+                    break
+        super().load_state_dict(state_dict)
+        self.__dict__.pop("_lists", None)                       # kernel-argument lists point at the old m / v buffers
+        for gi, group in enumerate(self.param_groups):
+            group.pop("step_dev", None)
+            for p in group["params"]:
+                self.state.get(p, {}).pop("step", None)
+            if gi in steps and group["params"]:
+                group["step_dev"] = torch.full((1,), steps[gi], dtype=torch.float32, device=group["params"][0].device)
 
     @torch.no_grad()
     def step(self, closure=None, grads=None):
@@ -68,7 +106,11 @@ class Adam(torch.optim.Optimizer):
                     gs.append(g)
                 # the kernel-argument list is rebuilt only when a pointer changed (gradients living in a flat bucket, or
                 # accumulated in place, keep their addresses: 5 ctypes stores per tensor saved on every step)
-                key = (tuple(p.data_ptr() for p in chunk), tuple(g.data_ptr() for g in gs))
+                # (the m / v addresses are part of the key: optimizer.state may be replaced or cleared between steps --
+                # load_state_dict, a fresh state after a checkpoint restore -- and a stale list would update freed buffers)
+                key = (tuple(p.data_ptr() for p in chunk), tuple(g.data_ptr() for g in gs),
+                       tuple(self.state[p]["exp_avg"].data_ptr() for p in chunk),
+                       tuple(self.state[p]["exp_avg_sq"].data_ptr() for p in chunk))
                 hit = cache.get(ci)
                 if hit is None or hit[0] != key:
                     lst = _lib.AdamList()

@@ -1342,6 +1342,40 @@ def test_fused_adam_matches_torch_adam(bnn, dev, wd):
 
 
 @pytest.mark.gpu
+def test_fused_adam_checkpoint_interchanges_with_torch_adam(bnn, dev):
+    """state_dict() of bnn_amd.optim.Adam carries torch.optim.Adam's per-parameter ``step`` (bias correction continues after
+    a restore) and loads into torch.optim.Adam and back; replacing the optimizer state invalidates the cached kernel
+    argument lists (a stale list would update freed m / v buffers)."""
+    torch.manual_seed(3)
+    ps = [torch.nn.Parameter(torch.randn(37, 5, device=dev)), torch.nn.Parameter(torch.randn(11, device=dev))]
+    pt = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    ours, ref = bnn.optim.Adam(ps, lr=1e-2), torch.optim.Adam(pt, lr=1e-2)
+    gs = [[torch.randn_like(p) for p in ps] for _ in range(6)]
+
+    def run(opt, params, k0, k1):
+        for k in range(k0, k1):
+            for p, g in zip(params, gs[k]):
+                p.grad = g.clone()
+            opt.step()
+    run(ours, ps, 0, 3); run(ref, pt, 0, 3)
+    sd = ours.state_dict()
+    assert all(float(st["step"]) == 3.0 for st in sd["state"].values()) and "step_dev" not in sd["param_groups"][0]
+    # restore into a FRESH instance of each kind and continue: all three trajectories must agree
+    import copy                                   # (a state_dict holds the live m / v tensors: every consumer gets its own copy)
+    ours2 = bnn.optim.Adam(ps, lr=1e-2); ours2.load_state_dict(copy.deepcopy(sd))
+    pt2 = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    ref2 = torch.optim.Adam(pt2, lr=1e-2); ref2.load_state_dict(copy.deepcopy(sd))
+    run(ours2, ps, 3, 6); run(ref, pt, 3, 6); run(ref2, pt2, 3, 6)
+    for a, b, c in zip(ps, pt, pt2):
+        assert rel_err(a, b) < 1e-6 and rel_err(c, b) < 1e-6
+    # same instance: replacing its state must not leave the kernel updating the old buffers
+    ours2.load_state_dict(copy.deepcopy(ours2.state_dict()))
+    before = [p.detach().clone() for p in ps]
+    run(ours2, ps, 0, 1)
+    assert all(not torch.equal(a, b) for a, b in zip(before, ps))
+    assert all(torch.isfinite(st["exp_avg"]).all() for st in ours2.state.values())
+
+
 def test_training_with_fused_adam_decreases_loss(bnn, dev):
     torch.manual_seed(0)
     net = bnn.mnf.BayesianNetwork((784, 64, 48, 10), 2, z_flow_type="Planar", r_flow_type="Planar").to(dev).train()
