@@ -163,7 +163,7 @@ class BayesianLinear(nn.Module):
         dev = x.device
         noise = self.noise or {}
         O, I = self.out_features, self.in_features
-        split = (ops.get_precision() == "bf16x3" and ops.split_eligible(I, O)
+        split = (ops.split_precision() and ops.split_eligible(I, O)
                  and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
         a = _lib.GateArgs()
         P = lambda t: None if t is None else ops._ptr(t.detach() if t.requires_grad else t, "tensor")

@@ -56,6 +56,7 @@ struct GemmArgs {
     // lbbnn_lrt_gemm_members: gridDim.z = members; member m = blockIdx.z is the same product on x + m*x_ms, e_w + m*w_ms
     // (var_w shared), out + m*o_ms, its noise drawn at Philox offset rng[1] + m*m_adv -- an ensemble of forwards
     // (test_ensemble, LBBNN-GP-MF-MNF.py:286-294) in one launch, every member bit-identical to its own launch
+    int single16;                // LBBNN_F_SINGLE16 (host-side dispatch only)
     int members;
     long long x_ms, w_ms, o_ms;
     unsigned long long m_adv, m_off;     // m_off: filled in by member_view()
@@ -544,7 +545,11 @@ constexpr int BKS = 32;
 
 __device__ __forceinline__ int swzx(int r) { return (((r >> 1) & 3) << 1) | ((r >> 3) & 1); }
 
-template <int TO, int TB, int WB, bool MEAN_ONLY>
+// NP = 3: the split products above.  NP = 1 (LBBNN_F_SINGLE16): ONE bf16 product per moment -- xh.wh and sh.vh with RNE
+// operands, the lo units of the operand lines unread -- the plain "bf16 MFMA" arithmetic BASELINE configs[1] names: a
+// third of the matrix work and of the conversions, measured error 2e-3 relative on the mean GEMM (outside the 1e-4
+// contract; its own tolerance in the tests), so never the default.
+template <int TO, int TB, int WB, bool MEAN_ONLY, int NP = 3>
 __global__ __launch_bounds__(WB * 64, (TB * TO > 10) ? 1 : (WB == 8 ? 4 : 2)) void lrt_gemm_bf16x3_kernel(const GemmArgs a_in) {
     const GemmArgs a = member_view(a_in);
     constexpr int BN = TO * 16, BM = TB * WB * 16;
@@ -646,10 +651,10 @@ __global__ __launch_bounds__(WB * 64, (TB * TO > 10) ? 1 : (WB == 8 ? 4 : 2)) vo
 #pragma unroll
         for (int i = 0; i < TO; ++i) {
             wh[i] = *reinterpret_cast<const uint4*>(cur + woh + i * 16 * 128);
-            wl[i] = *reinterpret_cast<const uint4*>(cur + wol + i * 16 * 128);
+            if (NP == 3) wl[i] = *reinterpret_cast<const uint4*>(cur + wol + i * 16 * 128);
             if (!MEAN_ONLY) {
                 wvh[i] = *reinterpret_cast<const uint4*>(cur + WRB + woh + i * 16 * 128);
-                wvl[i] = *reinterpret_cast<const uint4*>(cur + WRB + wol + i * 16 * 128);
+                if (NP == 3) wvl[i] = *reinterpret_cast<const uint4*>(cur + WRB + wol + i * 16 * 128);
             }
         }
     };
@@ -661,6 +666,16 @@ __global__ __launch_bounds__(WB * 64, (TB * TO > 10) ? 1 : (WB == 8 ? 4 : 2)) vo
             uint32_t ph[4], pl[4], qh[4], ql[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
+                if (NP == 1) {                                                           // one RNE bf16 per value (unbiased)
+                    const floatx2 hv = {v[2 * t], v[2 * t + 1]};
+                    ph[t] = __builtin_bit_cast(uint32_t, __builtin_convertvector(hv, bf16x2));
+                    pl[t] = 0; qh[t] = 0; ql[t] = 0;
+                    if (!MEAN_ONLY) {
+                        const floatx2 sv = {v[2 * t] * v[2 * t], v[2 * t + 1] * v[2 * t + 1]};
+                        qh[t] = __builtin_bit_cast(uint32_t, __builtin_convertvector(sv, bf16x2));
+                    }
+                    continue;
+                }
                 const uint32_t u0 = __float_as_uint(v[2 * t]), u1 = __float_as_uint(v[2 * t + 1]);
                 ph[t] = __builtin_amdgcn_perm(u1, u0, 0x07060302);                       // {hi16(v1), hi16(v0)}
                 const floatx2 lo = {v[2 * t] - __uint_as_float(u0 & 0xFFFF0000u), v[2 * t + 1] - __uint_as_float(u1 & 0xFFFF0000u)};
@@ -686,15 +701,19 @@ __global__ __launch_bounds__(WB * 64, (TB * TO > 10) ? 1 : (WB == 8 ? 4 : 2)) vo
 #pragma unroll
             for (int i = 0; i < TO; ++i) {
                 const bf16x8 ah = __builtin_bit_cast(bf16x8, wh[i]);
-                const bf16x8 al = __builtin_bit_cast(bf16x8, wl[i]);
+                const bf16x8 al = NP == 3 ? __builtin_bit_cast(bf16x8, wl[i]) : ah;
                 accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh[j], accm[i][j], 0, 0, 0);
-                accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xh[j], accm[i][j], 0, 0, 0);
-                accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xl[j], accm[i][j], 0, 0, 0);
+                if (NP == 3) {
+                    accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xh[j], accm[i][j], 0, 0, 0);
+                    accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xl[j], accm[i][j], 0, 0, 0);
+                }
                 if (!MEAN_ONLY) {
                     const bf16x8 bh = __builtin_bit_cast(bf16x8, wvh[i]);
                     accv[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, sh[j], accv[i][j], 0, 0, 0);
-                    accv[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wvl[i]), sh[j], accv[i][j], 0, 0, 0);
-                    accv[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, sl[j], accv[i][j], 0, 0, 0);
+                    if (NP == 3) {
+                        accv[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wvl[i]), sh[j], accv[i][j], 0, 0, 0);
+                        accv[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, sl[j], accv[i][j], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -919,6 +938,7 @@ int launch_split_cfg(GemmArgs& a, bool mean_only, hipStream_t s, bool* hosted) {
         if (piggy_lds_bytes(a.fin) <= (mean_only ? l_mean : l_full)) { grid.y += 1; *hosted = true; }
         else a.fin.n = 0;
     }
+    if (a.single16 && !mean_only) return launch_one(lrt_gemm_bf16x3_kernel<TO, TB, WB, false, 1>, grid, block, l_full, s, a);
     if (mean_only) return launch_one(lrt_gemm_bf16x3_kernel<TO, TB, WB, true>, grid, block, l_mean, s, a);
     return launch_one(lrt_gemm_bf16x3_kernel<TO, TB, WB, false>, grid, block, l_full, s, a);
 }
@@ -951,8 +971,9 @@ static int lrt_gemm_impl(const float* x, int ldx, const void* e_w, const void* v
     if (B == 0 && I > 0 && O > 0) return 0;        // empty batch (torch.mm of 0 rows, LBBNN-GP-MF-LRT.py:172): nothing to do
     if (!x || !e_w || !out) return LBBNN_E_NULL;
     if (B <= 0 || I <= 0 || O <= 0 || ldx < I || ldo < O) return LBBNN_E_SHAPE;
-    if (flags & ~(LBBNN_F_RELU | LBBNN_F_MEAN_ONLY | LBBNN_F_SPLIT16 | LBBNN_F_LOG_SOFTMAX)) return LBBNN_E_FLAGS;
+    if (flags & ~(LBBNN_F_RELU | LBBNN_F_MEAN_ONLY | LBBNN_F_SPLIT16 | LBBNN_F_LOG_SOFTMAX | LBBNN_F_SINGLE16)) return LBBNN_E_FLAGS;
     if ((flags & LBBNN_F_LOG_SOFTMAX) && (O > 16 || (flags & LBBNN_F_RELU))) return LBBNN_E_FLAGS;
+    if ((flags & LBBNN_F_SINGLE16) && !(flags & LBBNN_F_SPLIT16)) return LBBNN_E_FLAGS;
     const bool split = (flags & LBBNN_F_SPLIT16) != 0;
     const bool mean_only = (flags & LBBNN_F_MEAN_ONLY) != 0;
     if (!mean_only && !var_w) return LBBNN_E_NULL;
@@ -970,6 +991,7 @@ static int lrt_gemm_impl(const float* x, int ldx, const void* e_w, const void* v
     a.kchunk = kchunk; a.split_stride = (long long)B * ldo;
     if (fin) a.fin = *fin; else a.fin = FinalizePiggy{};
     a.comb_x = comb_x; a.comb_add = comb_add; a.ld_cx = ld_cx; a.ld_ca = ld_ca;
+    a.single16 = (flags & LBBNN_F_SINGLE16) ? 1 : 0;
     a.members = members; a.x_ms = x_ms; a.w_ms = w_ms; a.o_ms = o_ms; a.m_adv = m_adv; a.m_off = 0;
     if (members > 1 && (kchunk || fin || eps || std_out || comb_x)) return LBBNN_E_FLAGS;
 

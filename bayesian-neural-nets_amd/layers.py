@@ -341,7 +341,7 @@ class _BayesLinearFn(torch.autograd.Function):
 
 
 def _operand_split_ok(a, K, N):
-    return (ops.get_precision() == "bf16x3" and ops.split_eligible(K, N)
+    return (ops.split_precision() and ops.split_eligible(K, N)
             and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0)
 
 
@@ -441,7 +441,7 @@ class _BayesLinearBase(nn.Module):
 
     def _split(self, x=None):
         """Use the split-precision (bf16x3) operands/kernels for this layer call?"""
-        if ops.get_precision() != "bf16x3" or not ops.split_eligible(self.in_features, self.out_features):
+        if not ops.split_precision() or not ops.split_eligible(self.in_features, self.out_features):
             return False
         if x is not None and (x.stride(0) % 4 != 0 or x.data_ptr() % 16 != 0 or x.stride(1) != 1
                               or x.shape[0] * x.stride(0) * 4 >= 0x7FFFFFF0):      # 32-bit buffer offsets in the split kernel

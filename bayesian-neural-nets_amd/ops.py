@@ -16,6 +16,7 @@ F_RELU = 0x1
 F_MEAN_ONLY = 0x2
 F_SPLIT16 = 0x4
 F_LOG_SOFTMAX = 0x8
+F_SINGLE16 = 0x10
 
 STREAM_EPS_OUT = 0
 STREAM_EPS_Z = 1
@@ -35,13 +36,20 @@ _PRECISION = "fp32"
 
 def set_precision(name: str):
     global _PRECISION
-    if name not in ("fp32", "bf16x3"):
-        raise ValueError("precision must be 'fp32' or 'bf16x3'")
+    if name not in ("fp32", "bf16x3", "bf16"):
+        raise ValueError("precision must be 'fp32', 'bf16x3' or 'bf16'")
     _PRECISION = name
 
 
 def get_precision() -> str:
     return _PRECISION
+
+
+def split_precision() -> bool:
+    """Do the GEMMs take 16-bit operand planes ('bf16x3': three products per moment, inside the 1e-4 contract; 'bf16': ONE
+    product per moment in the forward's dual-moment GEMM -- the plain bf16 MFMA arithmetic BASELINE configs[1] names, 2e-3
+    relative on the mean GEMM, a reduced-precision mode with its own tolerance; backward products stay bf16x3)?"""
+    return _PRECISION in ("bf16x3", "bf16")
 
 
 def split_eligible(I: int, O: int) -> bool:
@@ -288,7 +296,7 @@ def lrt_gemm(x, e_w, var_w, *, I: int, O: int, bias_mean=None, bias_var=None, va
     if eps is not None and tuple(eps.shape) != (B, O):
         raise RuntimeError("bnn_amd: eps must be (%d,%d), got %s" % (B, O, tuple(eps.shape)))
     flags = ((F_RELU if relu else 0) | (F_MEAN_ONLY if mean_only else 0) | (F_LOG_SOFTMAX if log_softmax else 0)
-             | (F_SPLIT16 if split else 0))
+             | (F_SPLIT16 if split else 0) | (F_SINGLE16 if (split and not mean_only and _PRECISION == "bf16") else 0))
     if B == 0 and finalize is None:    # empty batch: (0,O) activations, as torch.mm gives; the KL side is unaffected
         return out
     if x.stride(1) != 1 or (x.stride(0) < I):

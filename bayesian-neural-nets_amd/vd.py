@@ -38,7 +38,7 @@ class _VDFn(torch.autograd.Function):
         gm, gv, _, _, _, _ = ops.output_grad(
             g, std=std, eps=val if kind == "explicit" else None, rng=val if kind != "explicit" else None,
             rng_stream=ops.STREAM_EPS_OUT * 64 + layer._layer_id, row_offset=layer.row_offset, relu=False, gv_scale=alpha)
-        split = ops.get_precision() == "bf16x3"
+        split = ops.split_precision()
         gx = gt = None
         if ctx.needs_input_grad[1]:
             sp = split and ops.split_eligible(m, n) and gm.stride(0) % 4 == 0
@@ -89,7 +89,7 @@ class BayesianLayer(nn.Module):
             self._ws = (torch.empty((self.m, ld), dtype=torch.float32, device=dev),
                         torch.empty((self.m, ld), dtype=torch.float32, device=dev))
         e_w, var_w = self._ws
-        split = (ops.get_precision() == "bf16x3" and ops.split_eligible(self.n, self.m)
+        split = (ops.split_precision() and ops.split_eligible(self.n, self.m)
                  and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
         _lib.check(_lib.lib().lbbnn_vd_operands(ops._ptr(self.theta.detach(), "theta"), e_w.data_ptr(), var_w.data_ptr(),
                                                 ld, self.n, self.m, ops.F_SPLIT16 if split else 0, ops._stream()),

@@ -70,6 +70,8 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel roofline pass")
     ap.add_argument("--no-step-events", action="store_true", help="no per-step event marks inside the timed region")
     ap.add_argument("--no-secondary", action="store_true", help="skip the fp32 (reference-precision) leg")
+    ap.add_argument("--no-reduced", action="store_true",
+                    help="skip the reduced-precision leg (one bf16 product per moment: OUTSIDE the 1e-4 contract)")
     ap.add_argument("--train", dest="train", action="store_true", default=None,
                     help="also time the data-parallel training step (default: only when N > 1)")
     ap.add_argument("--no-train", dest="train", action="store_false")
@@ -289,12 +291,13 @@ def roofline_object(events, precision, ms_per_step, sampled_in):
     if share > 1.0:
         return None, "bracketed GEMM time per step is %.2f x the timed region's step time" % share
     split = precision == "bf16x3"
-    peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
+    single = precision == "bf16"
+    peak = BF16_MFMA_PEAK_TFLOPS if (split or single) else FP32_MFMA_PEAK_TFLOPS
     ach = flops / (avg_ms * 1e-3) / 1e12
     traffic, traffic_src = pmc_traffic(precision)
     return {"bound": "mfma",
-            "kernel": ("lrt_gemm_bf16x3_kernel<5,2,4>" if split else "lrt_gemm_f32_dma_kernel<5,2,4>")
-                      + " (dual-moment GEMM, 80x128 tile)",
+            "kernel": ("lrt_gemm_bf16x3_kernel<5,2,4>" if split else "lrt_gemm_bf16x3_kernel<5,2,4,NP=1>" if single
+                       else "lrt_gemm_f32_dma_kernel<5,2,4>") + " (dual-moment GEMM, 80x128 tile)",
             "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
             "traffic": traffic, "traffic_unit": "HBM-side bytes per launch", "traffic_source": traffic_src,
             "executed_mfma_tflops": ach * (3.0 if split else 1.0),
@@ -443,6 +446,8 @@ def main():
     legs = {args.precision: forward_leg(args, bnn_amd, ops, net, x, sync, args.precision, world)}
     if args.precision == "bf16x3" and not args.no_secondary:
         legs["fp32"] = forward_leg(args, bnn_amd, ops, net, x, sync, "fp32", world)
+    if args.precision == "bf16x3" and not args.no_reduced and world == 1:
+        legs["bf16"] = forward_leg(args, bnn_amd, ops, net, x, sync, "bf16", world)
     train = None
     if want_train:
         train = train_leg(args, bnn_amd, net, x, sync, world, rank)
@@ -487,6 +492,25 @@ def main():
                 else:
                     sec["roofline_invalid"] = why
             res["secondary"] = sec
+        if "bf16" in legs:
+            leg = legs["bf16"]
+            red = {"dtype": "bf16 (ONE product per moment)",
+                   "what": "REDUCED PRECISION, outside the 1e-4 contract (2e-3 relative on the mean GEMM): the plain bf16 MFMA "
+                           "arithmetic BASELINE configs[1] names, same step, same process; not comparable with `value`",
+                   "value": total / leg["elapsed"], "unit": "samples/s", "steps": args.steps,
+                   "ms_per_step": leg["elapsed"] / args.steps * 1e3, "settle": leg["settle"],
+                   "timed_attempts": leg["attempts"]}
+            step_stats(red, leg["per_step"])
+            if leg["events"]:
+                roof, why = roofline_object(leg["events"], "bf16", red["ms_per_step"], sampled_in)
+                if roof is not None:
+                    roof["executed_mfma_tflops"] = roof["achieved"]
+                    roof["note"] = "achieved = ALGORITHMIC 4*B*I*O flop per launch / HIP-event time; one bf16 product per algorithmic product"
+                    roof["traffic"], roof["traffic_source"] = None, None
+                    red["roofline"] = roof
+                else:
+                    red["roofline_invalid"] = why
+            res["secondary_reduced_bf16"] = red
         if train is not None:
             if world > 1 and backend == "nccl":
                 train["rccl"] = rccl_log_summary(os.environ.get("NCCL_DEBUG_FILE"))

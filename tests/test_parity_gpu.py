@@ -1000,6 +1000,36 @@ print("DPGRAPH_OK", res[0][1])
     assert r.returncode == 0 and "DPGRAPH_OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-2500:])
 
 
+def test_reduced_precision_bf16_single_product_mode(bnn, dev):
+    """set_precision('bf16'): ONE bf16 product per moment in the forward's dual-moment GEMM -- the arithmetic BASELINE
+    configs[1] names ("LRT 784-400-400-10, batch 1024 bf16").  It is a REDUCED-precision mode with its own, measured
+    tolerance (2.2e-3 relative L2 on the mean GEMM): outputs within 1e-2 of the fp64 oracle under the
+    max norm, and demonstrably NOT within the 1e-4 contract -- which is why it is never the default."""
+    dims, B = (784, 400, 400, 10), 1024
+    torch.manual_seed(8)
+    net = bnn.lrt.BayesianNetwork(dims)
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(B, 784, generator=g)
+    eps = [torch.randn(B, d, generator=g) for d in dims[1:]]
+    P = [{k: v.detach().double() for k, v in l.state_dict().items()} for l in (net.l1, net.l2, net.l3)]
+    ref, _ = orc.lrt_network_forward(x.double(), P, [e.double() for e in eps])
+    net = net.to(dev).train()
+    for l, e in zip((net.l1, net.l2, net.l3), eps):
+        l.noise = {"eps_out": e.to(dev)}
+    errs = {}
+    for prec in ("bf16x3", "bf16"):
+        bnn.set_precision(prec)
+        try:
+            with torch.no_grad():
+                out = net(x.to(dev), sample=True)
+                assert net.l1._split_now and net.l2._split_now
+        finally:
+            bnn.set_precision("fp32")
+        errs[prec] = rel_err(out, ref)
+    assert errs["bf16x3"] < 2e-5
+    assert 1e-4 < errs["bf16"] < 1e-2, errs
+
+
 # --------------------------------------------------------------------------- BASELINE.json configs as parity cases
 def test_baseline_config1_lrt_400_b1024_split(bnn, dev):
     """configs[1]: LBBNN-GP-MF-LRT 784-400-400-10, batch 1024, reduced-precision matrix-core path (bf16x3 here),
