@@ -14,10 +14,19 @@ __device__ __forceinline__ uint32_t bf16_rne_bits(float f) {
     return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
 // store one operand value at [o][i] either as fp32 or in the split bf16 hi|lo layout
+// split: 0 = fp32, 1 = bf16 hi|lo (LBBNN_F_SPLIT16), 2 = fp16 in the hi unit, zero lo (LBBNN_F_HALF16: the single-product
+// fp16 form of the variational-dropout operands)
 __device__ __forceinline__ void store_operand(void* base, int split, size_t O, int ld, int o, int i, float v) {
     if (!split) { static_cast<float*>(base)[(size_t)o * ld + i] = v; return; }
     uint16_t* const w = static_cast<uint16_t*>(base);           // split hi|lo layout (lbbnn_device.h)
     const size_t at = split_hi_index((size_t)o, i, ld);
+    if (split == 2) {
+        const _Float16 h16 = (_Float16)v;                       // RNE; subnormals kept (the f16 MFMA honours them)
+        w[at] = __builtin_bit_cast(uint16_t, h16);
+        w[at + kSplitLoOffset] = 0;
+        (void)O;
+        return;
+    }
     const uint32_t h = bf16_rne_bits(v);
     w[at] = (uint16_t)h;
     w[at + kSplitLoOffset] = (uint16_t)bf16_rne_bits(v - __uint_as_float(h << 16));
@@ -387,8 +396,10 @@ extern "C" int lbbnn_vd_operands(const float* theta, void* e_w, void* var_w, int
     if (!theta || !e_w || !var_w) return LBBNN_E_NULL;
     if (I <= 0 || O <= 0) return LBBNN_E_SHAPE;
     if (ld < I || (ld & 31)) return LBBNN_E_ALIGN;
-    if (flags & ~LBBNN_F_SPLIT16) return LBBNN_E_FLAGS;
+    if (flags & ~(LBBNN_F_SPLIT16 | LBBNN_F_HALF16)) return LBBNN_E_FLAGS;
+    if ((flags & LBBNN_F_HALF16) && !(flags & LBBNN_F_SPLIT16)) return LBBNN_E_FLAGS;
     hipLaunchKernelGGL(vd_operands_kernel, dim3((ld + 31) / 32, (O + 31) / 32), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), theta, e_w, var_w, ld, I, O, (flags & LBBNN_F_SPLIT16) ? 1 : 0);
+                       static_cast<hipStream_t>(stream), theta, e_w, var_w, ld, I, O,
+                       (flags & LBBNN_F_HALF16) ? 2 : ((flags & LBBNN_F_SPLIT16) ? 1 : 0));
     return (int)hipGetLastError();
 }

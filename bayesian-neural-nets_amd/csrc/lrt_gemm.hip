@@ -549,8 +549,11 @@ __device__ __forceinline__ int swzx(int r) { return (((r >> 1) & 3) << 1) | ((r 
 // operands, the lo units of the operand lines unread -- the plain "bf16 MFMA" arithmetic BASELINE configs[1] names: a
 // third of the matrix work and of the conversions, measured error 2e-3 relative on the mean GEMM (outside the 1e-4
 // contract; its own tolerance in the tests), so never the default.
-template <int TO, int TB, int WB, bool MEAN_ONLY, int NP = 3>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+template <int TO, int TB, int WB, bool MEAN_ONLY, int NP = 3, bool F16 = false>
 __global__ __launch_bounds__(WB * 64, (TB * TO > 10) ? 1 : (WB == 8 ? 4 : 2)) void lrt_gemm_bf16x3_kernel(const GemmArgs a_in) {
+    static_assert(!F16 || NP == 1, "fp16 operands exist in the single-product form only");
     const GemmArgs a = member_view(a_in);
     constexpr int BN = TO * 16, BM = TB * WB * 16;
     constexpr int NWR = MEAN_ONLY ? 1 : 2;               // weight regions: e_w (, var_w); a row = [hi 64 B | lo 64 B]
@@ -666,13 +669,15 @@ __global__ __launch_bounds__(WB * 64, (TB * TO > 10) ? 1 : (WB == 8 ? 4 : 2)) vo
             uint32_t ph[4], pl[4], qh[4], ql[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                if (NP == 1) {                                                           // one RNE bf16 per value (unbiased)
+                if (NP == 1) {                                                           // one RNE 16-bit value per element (unbiased)
                     const floatx2 hv = {v[2 * t], v[2 * t + 1]};
-                    ph[t] = __builtin_bit_cast(uint32_t, __builtin_convertvector(hv, bf16x2));
+                    ph[t] = F16 ? __builtin_bit_cast(uint32_t, __builtin_convertvector(hv, f16x2))
+                                : __builtin_bit_cast(uint32_t, __builtin_convertvector(hv, bf16x2));
                     pl[t] = 0; qh[t] = 0; ql[t] = 0;
                     if (!MEAN_ONLY) {
                         const floatx2 sv = {v[2 * t] * v[2 * t], v[2 * t + 1] * v[2 * t + 1]};
-                        qh[t] = __builtin_bit_cast(uint32_t, __builtin_convertvector(sv, bf16x2));
+                        qh[t] = F16 ? __builtin_bit_cast(uint32_t, __builtin_convertvector(sv, f16x2))
+                                    : __builtin_bit_cast(uint32_t, __builtin_convertvector(sv, bf16x2));
                     }
                     continue;
                 }
@@ -700,6 +705,14 @@ __global__ __launch_bounds__(WB * 64, (TB * TO > 10) ? 1 : (WB == 8 ? 4 : 2)) vo
         for (int j = 0; j < TB; ++j) {
 #pragma unroll
             for (int i = 0; i < TO; ++i) {
+                if (F16) {
+                    accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh[i]), __builtin_bit_cast(f16x8, xh[j]),
+                                                                        accm[i][j], 0, 0, 0);
+                    if (!MEAN_ONLY)
+                        accv[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wvh[i]), __builtin_bit_cast(f16x8, sh[j]),
+                                                                            accv[i][j], 0, 0, 0);
+                    continue;
+                }
                 const bf16x8 ah = __builtin_bit_cast(bf16x8, wh[i]);
                 const bf16x8 al = NP == 3 ? __builtin_bit_cast(bf16x8, wl[i]) : ah;
                 accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh[j], accm[i][j], 0, 0, 0);
@@ -938,6 +951,7 @@ int launch_split_cfg(GemmArgs& a, bool mean_only, hipStream_t s, bool* hosted) {
         if (piggy_lds_bytes(a.fin) <= (mean_only ? l_mean : l_full)) { grid.y += 1; *hosted = true; }
         else a.fin.n = 0;
     }
+    if (a.single16 == 2 && !mean_only) return launch_one(lrt_gemm_bf16x3_kernel<TO, TB, WB, false, 1, true>, grid, block, l_full, s, a);
     if (a.single16 && !mean_only) return launch_one(lrt_gemm_bf16x3_kernel<TO, TB, WB, false, 1>, grid, block, l_full, s, a);
     if (mean_only) return launch_one(lrt_gemm_bf16x3_kernel<TO, TB, WB, true>, grid, block, l_mean, s, a);
     return launch_one(lrt_gemm_bf16x3_kernel<TO, TB, WB, false>, grid, block, l_full, s, a);
@@ -971,7 +985,9 @@ static int lrt_gemm_impl(const float* x, int ldx, const void* e_w, const void* v
     if (B == 0 && I > 0 && O > 0) return 0;        // empty batch (torch.mm of 0 rows, LBBNN-GP-MF-LRT.py:172): nothing to do
     if (!x || !e_w || !out) return LBBNN_E_NULL;
     if (B <= 0 || I <= 0 || O <= 0 || ldx < I || ldo < O) return LBBNN_E_SHAPE;
-    if (flags & ~(LBBNN_F_RELU | LBBNN_F_MEAN_ONLY | LBBNN_F_SPLIT16 | LBBNN_F_LOG_SOFTMAX | LBBNN_F_SINGLE16)) return LBBNN_E_FLAGS;
+    if (flags & ~(LBBNN_F_RELU | LBBNN_F_MEAN_ONLY | LBBNN_F_SPLIT16 | LBBNN_F_LOG_SOFTMAX | LBBNN_F_SINGLE16 | LBBNN_F_HALF16))
+        return LBBNN_E_FLAGS;
+    if ((flags & LBBNN_F_HALF16) && (!(flags & LBBNN_F_SINGLE16) || (flags & LBBNN_F_MEAN_ONLY))) return LBBNN_E_FLAGS;
     if ((flags & LBBNN_F_LOG_SOFTMAX) && (O > 16 || (flags & LBBNN_F_RELU))) return LBBNN_E_FLAGS;
     if ((flags & LBBNN_F_SINGLE16) && !(flags & LBBNN_F_SPLIT16)) return LBBNN_E_FLAGS;
     const bool split = (flags & LBBNN_F_SPLIT16) != 0;
@@ -991,7 +1007,7 @@ static int lrt_gemm_impl(const float* x, int ldx, const void* e_w, const void* v
     a.kchunk = kchunk; a.split_stride = (long long)B * ldo;
     if (fin) a.fin = *fin; else a.fin = FinalizePiggy{};
     a.comb_x = comb_x; a.comb_add = comb_add; a.ld_cx = ld_cx; a.ld_ca = ld_ca;
-    a.single16 = (flags & LBBNN_F_SINGLE16) ? 1 : 0;
+    a.single16 = (flags & LBBNN_F_HALF16) ? 2 : ((flags & LBBNN_F_SINGLE16) ? 1 : 0);
     a.members = members; a.x_ms = x_ms; a.w_ms = w_ms; a.o_ms = o_ms; a.m_adv = m_adv; a.m_off = 0;
     if (members > 1 && (kchunk || fin || eps || std_out || comb_x)) return LBBNN_E_FLAGS;
 

@@ -17,6 +17,7 @@ F_MEAN_ONLY = 0x2
 F_SPLIT16 = 0x4
 F_LOG_SOFTMAX = 0x8
 F_SINGLE16 = 0x10
+F_HALF16 = 0x20
 
 STREAM_EPS_OUT = 0
 STREAM_EPS_Z = 1
@@ -36,8 +37,8 @@ _PRECISION = "fp32"
 
 def set_precision(name: str):
     global _PRECISION
-    if name not in ("fp32", "bf16x3", "bf16"):
-        raise ValueError("precision must be 'fp32', 'bf16x3' or 'bf16'")
+    if name not in ("fp32", "bf16x3", "bf16", "fp16"):
+        raise ValueError("precision must be 'fp32', 'bf16x3', 'bf16' or 'fp16'")
     _PRECISION = name
 
 
@@ -48,8 +49,10 @@ def get_precision() -> str:
 def split_precision() -> bool:
     """Do the GEMMs take 16-bit operand planes ('bf16x3': three products per moment, inside the 1e-4 contract; 'bf16': ONE
     product per moment in the forward's dual-moment GEMM -- the plain bf16 MFMA arithmetic BASELINE configs[1] names, 2e-3
-    relative on the mean GEMM, a reduced-precision mode with its own tolerance; backward products stay bf16x3)?"""
-    return _PRECISION in ("bf16x3", "bf16")
+    relative on the mean GEMM, a reduced-precision mode with its own tolerance; backward products stay bf16x3; 'fp16': the
+    same with ONE FP16 product per moment in the variational-dropout layer -- BASELINE configs[4]'s "fp16 MFMA", 3e-4 relative
+    -- and the bf16 form everywhere else: the LRT / MNF variance operands (~1e-5) sit in fp16's subnormal range unscaled)?"""
+    return _PRECISION in ("bf16x3", "bf16", "fp16")
 
 
 def split_eligible(I: int, O: int) -> bool:
@@ -283,7 +286,7 @@ def lrt_gemm(x, e_w, var_w, *, I: int, O: int, bias_mean=None, bias_var=None, va
              eps=None, rng: Optional[torch.Tensor] = None, rng_stream: int = 0, row_offset: int = 0,
              relu: bool = False, mean_only: bool = False, log_softmax: bool = False,
              split: bool = False, out: Optional[torch.Tensor] = None, std_out: Optional[torch.Tensor] = None,
-             finalize=None):
+             finalize=None, half: bool = False):
     """lbbnn_lrt_gemm: out = x.e_w^T + b [+ sqrt(x^2.var_w^T + bv) * eps] [ReLU].
     finalize = (layer descriptors, n, rng pointer for K5, kl_total pointer[, live rng pointer, advance]):
     lbbnn_lrt_gemm_finalize_adv -- the KL finalize of the whole network (n may be 0) and the forward's RNG advance ride in
@@ -296,7 +299,9 @@ def lrt_gemm(x, e_w, var_w, *, I: int, O: int, bias_mean=None, bias_var=None, va
     if eps is not None and tuple(eps.shape) != (B, O):
         raise RuntimeError("bnn_amd: eps must be (%d,%d), got %s" % (B, O, tuple(eps.shape)))
     flags = ((F_RELU if relu else 0) | (F_MEAN_ONLY if mean_only else 0) | (F_LOG_SOFTMAX if log_softmax else 0)
-             | (F_SPLIT16 if split else 0) | (F_SINGLE16 if (split and not mean_only and _PRECISION == "bf16") else 0))
+             | (F_SPLIT16 if split else 0)
+             | (F_SINGLE16 if (split and not mean_only and _PRECISION in ("bf16", "fp16")) else 0)
+             | (F_HALF16 if (half and split and not mean_only) else 0))
     if B == 0 and finalize is None:    # empty batch: (0,O) activations, as torch.mm gives; the KL side is unaffected
         return out
     if x.stride(1) != 1 or (x.stride(0) < I):

@@ -91,8 +91,10 @@ class BayesianLayer(nn.Module):
         e_w, var_w = self._ws
         split = (ops.split_precision() and ops.split_eligible(self.n, self.m)
                  and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
+        half = split and ops.get_precision() == "fp16"          # one fp16 product per moment (BASELINE configs[4]: "fp16 MFMA")
         _lib.check(_lib.lib().lbbnn_vd_operands(ops._ptr(self.theta.detach(), "theta"), e_w.data_ptr(), var_w.data_ptr(),
-                                                ld, self.n, self.m, ops.F_SPLIT16 if split else 0, ops._stream()),
+                                                ld, self.n, self.m,
+                                                (ops.F_SPLIT16 if split else 0) | (ops.F_HALF16 if half else 0), ops._stream()),
                    "lbbnn_vd_operands")
         zeta = (self.noise or {}).get("zeta")
         rng, st = None, None
@@ -102,7 +104,7 @@ class BayesianLayer(nn.Module):
         src = ("explicit", zeta) if zeta is not None else ("rng", rng.clone() if save_rng else None)
         out = ops.lrt_gemm(x, e_w, var_w, I=self.n, O=self.m, var_scale=self.alpha, eps=zeta, rng=rng,
                            rng_stream=ops.STREAM_EPS_OUT * 64 + self._layer_id, row_offset=self.row_offset,
-                           relu=relu, split=split, std_out=std_out)
+                           relu=relu, split=split, std_out=std_out, half=half)
         if st is not None:
             st.advance(1)
         return out, src

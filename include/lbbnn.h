@@ -46,6 +46,9 @@ extern "C" {
 #define LBBNN_F_MEAN_ONLY 0x2  /* posterior-mean branch: out = x.e_w^T + b (…LRT.py:178-180)  */
 #define LBBNN_F_SPLIT16 0x4    /* split-precision MFMA path: bf16x3 products, operands hi + lo  */
 #define LBBNN_F_LOG_SOFTMAX 0x8 /* fuse F.log_softmax(dim=1) on the output; O <= 16 only (…LRT.py:210) */
+#define LBBNN_F_HALF16 0x20    /* with LBBNN_F_SPLIT16 | LBBNN_F_SINGLE16: the single product in FP16 (v_mfma_f32_16x16x32_f16; operands
+                                  from lbbnn_vd_operands(LBBNN_F_HALF16): fp16 in the hi units) -- the "fp16 MFMA" of BASELINE
+                                  configs[4]; unscaled, so only for operands inside fp16's range (the variational-dropout theta) */
 #define LBBNN_F_SINGLE16 0x10  /* with LBBNN_F_SPLIT16, lbbnn_lrt_gemm only: ONE bf16 product per moment (the hi parts of the
                                   same operands, x rounded to bf16 in registers) -- the plain "bf16 MFMA" arithmetic that
                                   BASELINE configs[1] names; 2e-3 relative on the mean GEMM, outside the 1e-4 contract */

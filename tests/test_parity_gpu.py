@@ -1585,6 +1585,50 @@ def test_reference_default_flow_headline_network_vs_oracle_full_size(bnn, dev, k
 
 
 @pytest.mark.gpu
+def test_vd_config4_reduced_precision_fp16_and_bf16(bnn, dev):
+    """BASELINE configs[4] "fp16 MFMA": the variational-dropout net 3072-4096-4096-10 at B = 1024 with ONE fp16 product per
+    moment (set_precision('fp16'): lbbnn_vd_operands(LBBNN_F_HALF16) + v_mfma_f32_16x16x32_f16), and with one bf16 product
+    ('bf16').  Reduced-precision modes with their own, measured bars against the fp64 oracle (max norm on the layer-1
+    activations and on the log-probabilities): fp16 < 2e-3, bf16 < 2e-2, both demonstrably outside the 1e-4 contract."""
+    dims, B = (3072, 4096, 4096, 10), 1024
+    torch.manual_seed(6)
+    layers = [bnn.vd.BayesianLayer(dims[i], dims[i + 1]).to(dev) for i in range(3)]
+    g = torch.Generator(device=dev).manual_seed(7)
+    x = torch.rand(B, dims[0], device=dev, generator=g)
+    zetas = [torch.randn(B, dims[i + 1], device=dev, generator=g) for i in range(3)]
+    h = x.double()
+    ref1 = None
+    for i, l in enumerate(layers):
+        h = orc.vd_forward(h, l.theta.detach().double(), l.alpha.double(), zetas[i].double())
+        if i == 0:
+            ref1 = h.clone()
+        if i < 2:
+            h = torch.relu(h)
+    ref = torch.log_softmax(h, dim=1)
+    errs = {}
+    for prec in ("bf16x3", "fp16", "bf16"):
+        bnn.set_precision(prec)
+        try:
+            with torch.no_grad():
+                h = x
+                for i, l in enumerate(layers):
+                    l.noise = {"zeta": zetas[i]}
+                    h = l(h)
+                    if i == 0:
+                        e1 = rel_err(h, ref1)
+                    if i < 2:
+                        h = torch.relu(h)
+                out = torch.log_softmax(h, dim=1)
+        finally:
+            bnn.set_precision("fp32")
+        errs[prec] = (e1, rel_err(out, ref))
+    assert errs["bf16x3"][0] < 2e-5 and errs["bf16x3"][1] < 2e-5, errs
+    assert 2e-5 < errs["fp16"][0] < 2e-3 and errs["fp16"][1] < 2e-3, errs
+    assert 1e-4 < errs["bf16"][0] < 2e-2 and errs["bf16"][1] < 2e-2, errs
+    assert errs["fp16"][0] < errs["bf16"][0]
+
+
+@pytest.mark.gpu
 def test_vd_config4_whole_network_full_size_vs_fp64(bnn, dev):
     """BASELINE configs[4] as a whole: variational-dropout layers 3072-4096-4096-10 with ReLU between them
     (variational_dropout.py:63-68,80-86) at B = 4096, injected zeta, against the oracle run in fp64 (on the GPU: three

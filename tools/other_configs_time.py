@@ -26,7 +26,7 @@ def graphed(fn):
     return g.replay
 
 
-for prec in ("bf16x3", "fp32"):
+for prec in ("bf16x3", "fp32", "bf16", "fp16"):
     bnn_amd.set_precision(prec)
     torch.manual_seed(0)
     with torch.no_grad():
