@@ -132,19 +132,17 @@ __device__ __forceinline__ OConst load_oconst(const GemmArgs& a, int o) {
 }
 
 // Local-reparameterisation epilogue for out[b][o..o+3] (LBBNN-GP-MF-LRT.py:172-175): bias, variance
-// scale/bias, eps (explicit or Philox with counter (row_offset + b, o/4)), sqrt, optional ReLU.
+// scale/bias, eps (explicit -- already loaded by the caller into e_in -- or Philox with counter (row_offset + b, o/4)),
+// sqrt, optional ReLU; cx_in / ca_in: the preloaded operands of the mean-only combine form (dX = ca + 2 cx * product).
 template <bool MEAN_ONLY>
 __device__ __forceinline__ void epilogue4(const GemmArgs& a, const EpiCtx& c, const OConst& oc, int b, int o,
-                                          const floatx4& am, const floatx4& av, float res[4]) {
+                                          const floatx4& am, const floatx4& av, const float* e_in, const float* cx_in,
+                                          const float* ca_in, float res[4], float sd[4]) {
     float e[4] = {0.f, 0.f, 0.f, 0.f};
     if (!MEAN_ONLY) {
         if (a.eps) {
-            const float* ep = a.eps + (size_t)b * a.O + o;
-            if (c.ovec) { const float4 t = *reinterpret_cast<const float4*>(ep); e[0] = t.x; e[1] = t.y; e[2] = t.z; e[3] = t.w; }
-            else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (o + r < a.O) e[r] = ep[r];
-            }
+            for (int r = 0; r < 4; ++r) e[r] = e_in[r];
         } else {
 #ifdef LAB_NO_PHILOX         // tools/lab ablation only: cost of the in-kernel draws in the epilogue
             e[0] = 0.3f; e[1] = -0.7f; e[2] = 1.1f; e[3] = -0.2f;
@@ -153,41 +151,87 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& a, const EpiCtx& c, co
 #endif
         }
     }
-    float sd[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         float mean = am[r] + oc.bm[r];
+        sd[r] = 0.f;
         if (!MEAN_ONLY) { sd[r] = sqrtf(av[r] * oc.vs[r] + oc.bv[r]); mean += sd[r] * e[r]; }
         res[r] = a.relu ? fmaxf(mean, 0.f) : mean;
     }
     if (MEAN_ONLY && a.comb_x) {
-        const float* cx = a.comb_x + (size_t)b * a.ld_cx + o;
-        const float* ca = a.comb_add + (size_t)b * a.ld_ca + o;
-        if (c.ovec && ((a.ld_cx | a.ld_ca) & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.comb_x) | reinterpret_cast<uintptr_t>(a.comb_add)) & 15u) == 0) {
-            const float4 vx = *reinterpret_cast<const float4*>(cx), va = *reinterpret_cast<const float4*>(ca);
-            res[0] = va.x + 2.f * vx.x * res[0]; res[1] = va.y + 2.f * vx.y * res[1];
-            res[2] = va.z + 2.f * vx.z * res[2]; res[3] = va.w + 2.f * vx.w * res[3];
-        } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) if (o + r < a.O) res[r] = ca[r] + 2.f * cx[r] * res[r];
-        }
-    }
-    if (!MEAN_ONLY && a.std_out) {
-        float* sp = a.std_out + (size_t)b * a.O + o;
-        if (c.ovec) *reinterpret_cast<float4*>(sp) = make_float4(sd[0], sd[1], sd[2], sd[3]);
-        else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) if (o + r < a.O) sp[r] = sd[r];
-        }
+        for (int r = 0; r < 4; ++r) res[r] = ca_in[r] + 2.f * cx_in[r] * res[r];
     }
 }
 
-__device__ __forceinline__ void store4(const GemmArgs& a, const EpiCtx& c, int b, int o, const float res[4]) {
-    float* op = a.out + (size_t)b * a.ldo + o;
-    if (c.ovec) *reinterpret_cast<float4*>(op) = make_float4(res[0], res[1], res[2], res[3]);
+__device__ __forceinline__ void load4_rows(const float* p, bool vec, int o, int O, float out[4]) {
+    if (vec) { const float4 t = *reinterpret_cast<const float4*>(p); out[0] = t.x; out[1] = t.y; out[2] = t.z; out[3] = t.w; }
     else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) if (o + r < a.O) op[r] = res[r];
+        for (int r = 0; r < 4; ++r) out[r] = (o + r < O) ? p[r] : 0.f;
+    }
+}
+
+__device__ __forceinline__ void store4_rows(float* p, bool vec, int o, int O, const float v[4]) {
+    if (vec) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (o + r < O) p[r] = v[r];
+    }
+}
+
+// Epilogue of a wave's TO x TB accumulator tiles (lane: out[b][o .. o+3] of tile (i, j), o = o0 + 16 i + 4 q,
+// b = brow0 + 16 j).  Two phases.  (1) EVERY load the epilogue needs -- the per-feature constants of the TO o-tiles, the
+// explicit eps or the combine operands where the call has them -- is issued back to back, before the first store.  (2)
+// noise, arithmetic and stores per tile, no load in between.  The former loop loaded each o-tile's constants inside the
+// loop: `s_waitcnt vmcnt(0)` before their use also waited for the previous o-tile's STORES (vmcnt counts stores), five
+// dependent round trips per workgroup at the point of the launch where nothing else is left to overlap them
+// (tools/gemm_ksweep.py: 16.4 us of a launch did not depend on K).
+template <int TO, int TB, bool MEAN_ONLY>
+__device__ __forceinline__ void epilogue_tile(const GemmArgs& a, int o0, int q, int brow0,
+                                              const floatx4 (&accm)[TO][TB], const floatx4 (&accv)[TO][TB]) {
+    const EpiCtx ec = make_epi_ctx<MEAN_ONLY>(a);
+    OConst oc[TO];
+#pragma unroll
+    for (int i = 0; i < TO; ++i) {
+        const int o = o0 + i * 16 + 4 * q;
+        if (o < a.O) oc[i] = load_oconst(a, o);
+    }
+    const bool pre_eps = !MEAN_ONLY && a.eps != nullptr;
+    const bool pre_comb = MEAN_ONLY && a.comb_x != nullptr;
+    const bool comb_vec = pre_comb && ec.ovec && ((a.ld_cx | a.ld_ca) & 3) == 0 &&
+                          ((reinterpret_cast<uintptr_t>(a.comb_x) | reinterpret_cast<uintptr_t>(a.comb_add)) & 15u) == 0;
+    float pa[TO][TB][4], pb[TO][TB][4];       // explicit eps (pa) or the combine operands (pa = comb_x, pb = comb_add)
+    if (pre_eps || pre_comb) {
+#pragma unroll
+        for (int i = 0; i < TO; ++i) {
+            const int o = o0 + i * 16 + 4 * q;
+#pragma unroll
+            for (int j = 0; j < TB; ++j) {
+                const int b = brow0 + j * 16;
+                if (o >= a.O || b >= a.B) continue;
+                if (pre_eps) load4_rows(a.eps + (size_t)b * a.O + o, ec.ovec, o, a.O, pa[i][j]);
+                else {
+                    load4_rows(a.comb_x + (size_t)b * a.ld_cx + o, comb_vec, o, a.O, pa[i][j]);
+                    load4_rows(a.comb_add + (size_t)b * a.ld_ca + o, comb_vec, o, a.O, pb[i][j]);
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < TO; ++i) {
+        const int o = o0 + i * 16 + 4 * q;
+        if (o >= a.O) continue;
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            const int b = brow0 + j * 16;
+            if (b >= a.B) continue;
+            float res[4], sd[4];
+            epilogue4<MEAN_ONLY>(a, ec, oc[i], b, o, accm[i][j], accv[i][j], pa[i][j], pa[i][j], pb[i][j], res, sd);
+            store4_rows(a.out + (size_t)b * a.ldo + o, ec.ovec, o, a.O, res);
+            if (!MEAN_ONLY && a.std_out) store4_rows(a.std_out + (size_t)b * a.O + o, ec.ovec, o, a.O, sd);
+        }
     }
 }
 
@@ -347,21 +391,7 @@ __global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_f32_kernel(const GemmArgs
     }
 
     // ---- epilogue: lane holds out[b][o .. o+3] for each (i, j) tile
-    const EpiCtx ec = make_epi_ctx<MEAN_ONLY>(a);
-#pragma unroll
-    for (int i = 0; i < TO; ++i) {
-        const int o = o0 + i * 16 + 4 * q;
-        if (o >= a.O) continue;
-        const OConst oc = load_oconst(a, o);
-#pragma unroll
-        for (int j = 0; j < TB; ++j) {
-            const int b = b0 + (wv * TB + j) * 16 + lr;
-            if (b >= a.B) continue;
-            float res[4];
-            epilogue4<MEAN_ONLY>(a, ec, oc, b, o, accm[i][j], accv[i][j], res);
-            store4(a, ec, b, o, res);
-        }
-    }
+    epilogue_tile<TO, TB, MEAN_ONLY>(a, o0, q, b0 + wv * TB * 16 + lr, accm, accv);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -499,21 +529,7 @@ __global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_f32_dma_kernel(const Gemm
     }
 
     // ---- epilogue (identical to the register-staged kernel)
-    const EpiCtx ec = make_epi_ctx<MEAN_ONLY>(a);
-#pragma unroll
-    for (int i = 0; i < TO; ++i) {
-        const int o = o0 + i * 16 + 4 * q;
-        if (o >= a.O) continue;
-        const OConst oc = load_oconst(a, o);
-#pragma unroll
-        for (int j = 0; j < TB; ++j) {
-            const int b = b0 + (wv * TB + j) * 16 + lr;
-            if (b >= a.B) continue;
-            float res[4];
-            epilogue4<MEAN_ONLY>(a, ec, oc, b, o, accm[i][j], accv[i][j], res);
-            store4(a, ec, b, o, res);
-        }
-    }
+    epilogue_tile<TO, TB, MEAN_ONLY>(a, o0, q, b0 + wv * TB * 16 + lr, accm, accv);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -551,6 +567,10 @@ __device__ __forceinline__ int swzx(int r) { return (((r >> 1) & 3) << 1) | ((r 
 // contract; its own tolerance in the tests), so never the default.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#ifdef LAB_GEMM_STAMPS          // tools/lab diagnostic build only (tools/gemm_stamps.py): per-step phase stamps of a few waves
+constexpr int LAB_ST_SLOTS = 64, LAB_ST_STEPS = 48, LAB_ST_PH = 8;
+__device__ uint32_t lab_gemm_stamps[LAB_ST_SLOTS * LAB_ST_STEPS * LAB_ST_PH];
+#endif
 template <int TO, int TB, int WB, bool MEAN_ONLY, int NP = 3, bool F16 = false>
 __global__ __launch_bounds__(WB * 64, (TB * TO > 10) ? 1 : (WB == 8 ? 4 : 2)) void lrt_gemm_bf16x3_kernel(const GemmArgs a_in) {
     static_assert(!F16 || NP == 1, "fp16 operands exist in the single-product form only");
@@ -732,40 +752,66 @@ __global__ __launch_bounds__(WB * 64, (TB * TO > 10) ? 1 : (WB == 8 ? 4 : 2)) vo
         }
     };
 
+#ifdef LAB_GEMM_STAMPS
+    const int lab_lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const bool lab_on = (lab_lin % 32) == 0 && lab_lin / 32 < LAB_ST_SLOTS / 4 && WB == 4 && !MEAN_ONLY;
+    uint32_t* const lab_w = lab_gemm_stamps + (size_t)((lab_lin / 32) * 4 + wv) * LAB_ST_STEPS * LAB_ST_PH;
+    const uint32_t lab_k0 = (uint32_t)__builtin_readcyclecounter();
+#define LAB_T(v) const uint32_t v = (uint32_t)__builtin_readcyclecounter()
+#else
+#define LAB_T(v)
+#endif
     dma_step(0, smc);
     __syncthreads();
     for (int c = 0; c < nsteps; ++c) {
+        LAB_T(lab_t0);
         read_frags(smc + (c & 1) * BUFB);
         __builtin_amdgcn_sched_barrier(0);
+        LAB_T(lab_t1);
 #ifndef LAB_NO_DMA          // tools/lab ablation builds only; never defined in the product library
         if (c + 1 < nsteps) dma_step(c + 1, smc + ((c & 1) ^ 1) * BUFB);
 #endif
         __builtin_amdgcn_sched_barrier(0);
+        LAB_T(lab_t2);
 #ifndef LAB_NO_MFMA
         mfmas();
 #endif
         __builtin_amdgcn_sched_barrier(0);
+        LAB_T(lab_t3);
         __syncthreads();
+#ifdef LAB_GEMM_STAMPS
+        if (lab_on && lane == 0 && c + 1 < LAB_ST_STEPS) {
+            const uint32_t lab_t4 = (uint32_t)__builtin_readcyclecounter();
+            uint32_t* w = lab_w + (c + 1) * LAB_ST_PH;
+            w[0] = lab_t0 - lab_k0; w[1] = lab_t1 - lab_k0; w[2] = lab_t2 - lab_k0; w[3] = lab_t3 - lab_k0; w[4] = lab_t4 - lab_k0;
+        }
+#endif
     }
+#ifdef LAB_GEMM_STAMPS
+    const uint32_t lab_k1 = (uint32_t)__builtin_readcyclecounter();
+#endif
 
     GemmArgs ao = a;                                     // split-K: partial product z goes to its own output slab
     if (a.kchunk) ao.out = a.out + (size_t)blockIdx.z * a.split_stride;
-    const EpiCtx ec = make_epi_ctx<MEAN_ONLY>(ao);
-#pragma unroll
-    for (int i = 0; i < TO; ++i) {
-        const int o = o0 + i * 16 + 4 * q;
-        if (o >= a.O) continue;
-        const OConst oc = load_oconst(ao, o);
-#pragma unroll
-        for (int j = 0; j < TB; ++j) {
-            const int b = b0 + (wv * TB + j) * 16 + lr;
-            if (b >= a.B) continue;
-            float res[4];
-            epilogue4<MEAN_ONLY>(ao, ec, oc, b, o, accm[i][j], accv[i][j], res);
-            store4(ao, ec, b, o, res);
-        }
+    epilogue_tile<TO, TB, MEAN_ONLY>(ao, o0, q, b0 + wv * TB * 16 + lr, accm, accv);
+#ifdef LAB_GEMM_STAMPS
+    if (lab_on && lane == 0) {
+        uint32_t hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        lab_w[0] = hwid; lab_w[1] = xcc; lab_w[2] = lab_k1 - lab_k0; lab_w[3] = (uint32_t)__builtin_readcyclecounter() - lab_k0;
+        lab_w[4] = (uint32_t)nsteps; lab_w[5] = (uint32_t)lab_lin;
+        lab_w[6] = (uint32_t)__builtin_amdgcn_s_memrealtime();
     }
+#endif
 }
+#ifdef LAB_GEMM_STAMPS
+}  // namespace
+extern "C" int lbbnn_lab_gemm_stamps(void* host, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(lab_gemm_stamps), bytes);
+}
+namespace {
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Skinny-output variant (O <= 16: the 10-class head).  One 16(o) x 16(b) accumulator pair per wave;
@@ -793,6 +839,23 @@ __global__ __launch_bounds__(SK_WAVES * 64) void lrt_gemm_skinny_kernel(const Ge
     const int b = b0 + lr;
     const bool brow = b < a.B && lr < SKR, orow = lr < a.O;
     floatx4 accm = {0.f, 0.f, 0.f, 0.f}, accv = {0.f, 0.f, 0.f, 0.f};
+    // wave 0 runs the epilogue: what it loads there (per-feature constants, explicit eps / combine operands, the Philox
+    // state) is requested HERE, ahead of the x stream, instead of as a dependent round trip after the reduction
+    const EpiCtx ec = make_epi_ctx<MEAN_ONLY>(a);
+    const int o = 4 * q;
+    const bool live = brow && o < a.O;
+    OConst oc;
+    float pa[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f};
+    if (wv == 0 && live) {
+        oc = load_oconst(a, o);
+        if (!MEAN_ONLY && a.eps) load4_rows(a.eps + (size_t)b * a.O + o, ec.ovec, o, a.O, pa);
+        if (MEAN_ONLY && a.comb_x) {
+            const bool cvec = ec.ovec && ((a.ld_cx | a.ld_ca) & 3) == 0 &&
+                              ((reinterpret_cast<uintptr_t>(a.comb_x) | reinterpret_cast<uintptr_t>(a.comb_add)) & 15u) == 0;
+            load4_rows(a.comb_x + (size_t)b * a.ld_cx + o, cvec, o, a.O, pa);
+            load4_rows(a.comb_add + (size_t)b * a.ld_ca + o, cvec, o, a.O, pb);
+        }
+    }
     const int nchunks = (a.I + BK - 1) / BK;
     for (int cb = wv; cb < nchunks; cb += SK_WAVES * SK_NCH) {
         float4 xf[SK_NCH], wm[SK_NCH], wvv[SK_NCH];
@@ -845,11 +908,8 @@ __global__ __launch_bounds__(SK_WAVES * 64) void lrt_gemm_skinny_kernel(const Ge
         sm += *reinterpret_cast<const floatx4*>(&red[w][0][lane][0]);
         if (!MEAN_ONLY) sv += *reinterpret_cast<const floatx4*>(&red[w][1][lane][0]);
     }
-    const EpiCtx ec = make_epi_ctx<MEAN_ONLY>(a);
-    const int o = 4 * q;
-    float res[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool live = brow && o < a.O;
-    if (live) { const OConst oc = load_oconst(a, o); epilogue4<MEAN_ONLY>(a, ec, oc, b, o, sm, sv, res); }
+    float res[4] = {0.f, 0.f, 0.f, 0.f}, sd[4] = {0.f, 0.f, 0.f, 0.f};
+    if (live) epilogue4<MEAN_ONLY>(a, ec, oc, b, o, sm, sv, pa, pa, pb, res, sd);
     if (a.log_softmax) {
         // the row's logits live on lanes lr, lr+16, lr+32, lr+48 (q = 0..3), 4 registers each
         float mx = -INFINITY;
@@ -866,7 +926,10 @@ __global__ __launch_bounds__(SK_WAVES * 64) void lrt_gemm_skinny_kernel(const Ge
 #pragma unroll
         for (int r = 0; r < 4; ++r) res[r] -= lse;
     }
-    if (live) store4(a, ec, b, o, res);
+    if (live) {
+        store4_rows(a.out + (size_t)b * a.ldo + o, ec.ovec, o, a.O, res);
+        if (!MEAN_ONLY && a.std_out) store4_rows(a.std_out + (size_t)b * a.O + o, ec.ovec, o, a.O, sd);
+    }
 }
 
 // Workgroup residency matters more than anything else here: the kernel is MFMA-issue bound, so a CU
