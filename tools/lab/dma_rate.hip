@@ -35,7 +35,53 @@ __device__ __forceinline__ void fill_body(const char* src, int rs, int ksteps, i
     }
     const unsigned long long t0 = __builtin_readcyclecounter();
     unsigned acc = 0;
-    if (MODE == 0) {
+    if (MODE == 2 || MODE == 3 || MODE == 4) {
+        // waves with odd SIMD-partner index run back-to-back MFMAs (matrix pipe busy on every SIMD), the others issue the pieces:
+        // MODE 2 per-lane offsets in a VGPR (offen), MODE 3 no address VGPR at all (descriptor ADD_TID_ENABLE, stride 16: lane i
+        // reads 16 B at base + soffset + 16 i -- a contiguous 1-KiB piece), MODE 4 = MODE 2 with the MFMA waves idle (control)
+        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+        typedef float floatx4 __attribute__((ext_vector_type(4)));
+        const bool mf = wv >= WAVES / 2;
+        if (mf) {
+            if (MODE != 4) {
+                floatx4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+                bf16x8 a, b;
+                for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(float)(lane + i); b[i] = (__bf16)(float)(lane ^ i); }
+                const int n = iters * ksteps * 16 * 2;       // 16x16x32 MFMAs, 16 cycles each: about as long as the other waves' loop
+                for (int i = 0; i < n; i += 4) {
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c1, 0, 0, 0);
+                    c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c2, 0, 0, 0);
+                    c3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c3, 0, 0, 0);
+                }
+                acc = __float_as_uint(c0[0] + c1[1] + c2[2] + c3[3]);
+            }
+        } else {
+            constexpr int HW = WAVES / 2 > 0 ? WAVES / 2 : 1; constexpr int NPW2 = (16 + HW - 1) / HW;
+            int off2[NPW2];
+#pragma unroll
+            for (int u = 0; u < NPW2; ++u) {
+                const int g = (wv + HW * u) % 16;
+                off2[u] = (tile * 128 + 8 * g + (lane >> 3)) * rs + 16 * (lane & 7);
+            }
+            // ADD_TID_ENABLE = bit 23 of dword 3, stride (dword 1 bits 29:16) = 16
+            // (with ADD_TID_ENABLE the DATA_FORMAT bits of dword 3 extend the stride: they must be 0 here)
+            const __amdgpu_buffer_rsrc_t rtid = __builtin_amdgcn_make_buffer_rsrc((void*)src, 16, (int)bytes, (1 << 23));
+            int slot = 0;
+            for (int it = 0; it < iters; ++it)
+                for (int c = 0; c < ksteps; ++c) {
+#pragma unroll
+                    for (int u = 0; u < NPW2; ++u) {
+                        auto* dst = (__attribute__((address_space(3))) void*)(smc + (wv * (INFL + 1) + slot) * 1024);
+                        if (MODE == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rtid, dst, 16, 0, (tile * 128 + 8 * u) * rs + c * 1024, 0, 0);
+                        else           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, off2[u], c * 128, 0, 0);
+                        slot = slot == INFL ? 0 : slot + 1;
+                        wait_vmcnt<INFL>();
+                    }
+                }
+            wait_vmcnt<0>();
+        }
+    } else if (MODE == 0) {
         int slot = 0;
         for (int it = 0; it < iters; ++it)
             for (int c = 0; c < ksteps; ++c) {
@@ -64,7 +110,7 @@ __device__ __forceinline__ void fill_body(const char* src, int rs, int ksteps, i
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
     if (acc == 0x12345u) sink[0] = acc;
-    if (tid == 0) cyc[blockIdx.x] = t1 - t0;
+    if (tid == 0) cyc[blockIdx.x] = t1 - t0;     // wave 0 is a DMA wave in every mode
 }
 
 template <int MODE, int WAVES, int INFL>
@@ -76,7 +122,7 @@ __global__ __launch_bounds__(WAVES * 64) void fill_k(const char* src, int rs, in
 template <int MODE, int WAVES, int INFL>
 static void run(const char* name, const char* src, int rs, int ksteps, int iters, int T, int nwg, unsigned* sink,
                 unsigned long long* cyc) {
-    const size_t lds = MODE == 0 ? (size_t)WAVES * (INFL + 1) * 1024 : 0;
+    const size_t lds = MODE != 1 ? (size_t)WAVES * (INFL + 1) * 1024 : 0;
     if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(&fill_k<MODE, WAVES, INFL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
@@ -94,7 +140,7 @@ static void run(const char* name, const char* src, int rs, int ksteps, int iters
     std::vector<unsigned long long> h(nwg);
     hipMemcpy(h.data(), cyc, nwg * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     double cs = 0; for (auto v : h) cs += (double)v; cs /= nwg;
-    constexpr int NPW = (16 + WAVES - 1) / WAVES;
+    constexpr int NPW = MODE >= 2 ? (16 + WAVES / 2 - 1) / (WAVES / 2) / 2 : (16 + WAVES - 1) / WAVES;   // MODE >= 2: half the waves issue
     constexpr int SPB = (INFL / NPW > 0 ? INFL / NPW : 1);       // MODE 1 issues whole batches of SPB K steps
     const int ksi = MODE == 1 ? (ksteps + SPB - 1) / SPB * SPB : ksteps;
     const double pieces_wg = (double)WAVES * NPW * ksi * iters;
@@ -105,6 +151,7 @@ static void run(const char* name, const char* src, int rs, int ksteps, int iters
 }
 
 int main(int argc, char** argv) {
+    setvbuf(stdout, nullptr, _IONBF, 0);
     const int rs = 4800, ksteps = 37, rows = 4096;
     char* src; unsigned* sink; unsigned long long* cyc;
     hipMalloc(&src, (size_t)rows * rs + 4096);
@@ -122,6 +169,9 @@ int main(int argc, char** argv) {
         run<0, 8, 15>("LDS-DMA 8 waves, 16 in flight/wave", src, rs, ksteps, iters, T, 256, sink, cyc);
         run<0, 1, 15>("LDS-DMA 1 wave, 16 in flight", src, rs, ksteps, iters, T, 256, sink, cyc);
         run<0, 2, 15>("LDS-DMA 2 waves, 16 in flight/wave", src, rs, ksteps, iters, T, 256, sink, cyc);
+        run<4, 8, 15>("LDS-DMA 4 of 8 waves, others idle", src, rs, ksteps, iters, T, 256, sink, cyc);
+        run<2, 8, 15>("LDS-DMA 4 of 8 waves, others MFMA", src, rs, ksteps, iters, T, 256, sink, cyc);
+        run<3, 8, 15>("same, ADD_TID (no address VGPR)", src, rs, ksteps, iters, T, 256, sink, cyc);
         run<1, 4, 8>("regs 4 waves, 8 in flight/wave", src, rs, ksteps, iters, T, 256, sink, cyc);
         run<1, 4, 16>("regs 4 waves, 16 in flight/wave", src, rs, ksteps, iters, T, 256, sink, cyc);
         run<1, 8, 16>("regs 8 waves, 16 in flight/wave", src, rs, ksteps, iters, T, 256, sink, cyc);
