@@ -1049,14 +1049,15 @@ __device__ __forceinline__ void lrt_gemm_bf16x3_ring_body(const GemmArgs& a_in) 
             LAB_R(0);
             retire(c);
             LAB_R(1);
-            read_frags(c);
+            if (c + 2 < nsteps) dma_step(c + 2);                    // first: the fill path is free while waves 4-7 issue MFMAs
             LAB_R(2);
-            wait_frags();
+            read_frags(c);
             LAB_R(3);
-            convert();
+            wait_frags();
             LAB_R(4);
-            mfmas(c + 2 < nsteps ? c + 2 : -1);                     // + the pieces of step c+2, into the stage last read in step c-1
+            convert();
             LAB_R(5);
+            mfmas(-1);
             LAB_R(6);
             LAB_FLUSH(c);
         }
@@ -1065,15 +1066,15 @@ __device__ __forceinline__ void lrt_gemm_bf16x3_ring_body(const GemmArgs& a_in) 
             LAB_R(0);
             retire(c);
             LAB_R(1);
-            if (c > 0) mfmas(c + 2 < nsteps ? c + 2 : -1);          // step c-1, operands already in registers
-            else if (c + 2 < nsteps) dma_step(c + 2);
+            if (c > 0) mfmas(-1);                                    // step c-1, operands already in registers
             LAB_R(2);
-            read_frags(c);
+            if (c + 2 < nsteps) dma_step(c + 2);
             LAB_R(3);
-            wait_frags();
+            read_frags(c);
             LAB_R(4);
-            convert();
+            wait_frags();
             LAB_R(5);
+            convert();
             LAB_R(6);
             LAB_FLUSH(c);
         }

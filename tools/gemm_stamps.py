@@ -43,7 +43,7 @@ s = buf.reshape(SLOTS, STEPS, PH).astype(np.int64)
 if os.environ.get("LBBNN_GEMM_RING", "0") != "0":
     # ring kernel: 8 waves per workgroup; phases per role (see the kernel): early = wait+barrier | read issue | dma | wait frags |
     # convert | mfma ; late = wait+barrier | mfma(c-1) | dma | read issue | wait frags | convert
-    names = {False: ["wait+bar", "read_iss", "wait_frag", "convert", "mfma+dma", "-"], True: ["wait+bar", "mfma(c-1)+dma", "read_iss", "wait_frag", "convert", "-"]}
+    names = {False: ["wait+bar", "dma", "read_iss", "wait_frag", "convert", "mfma"], True: ["wait+bar", "mfma(c-1)", "dma", "read_iss", "wait_frag", "convert"]}
     for sl in range(SLOTS):
         ns = int(s[sl, 0, 4])
         if ns == 0:

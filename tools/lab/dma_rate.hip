@@ -35,14 +35,42 @@ __device__ __forceinline__ void fill_body(const char* src, int rs, int ksteps, i
     }
     const unsigned long long t0 = __builtin_readcyclecounter();
     unsigned acc = 0;
-    if (MODE == 2 || MODE == 3 || MODE == 4) {
+    if (MODE == 2 || MODE == 3 || MODE == 4 || MODE == 5 || MODE == 6) {
         // waves with odd SIMD-partner index run back-to-back MFMAs (matrix pipe busy on every SIMD), the others issue the pieces:
         // MODE 2 per-lane offsets in a VGPR (offen), MODE 3 no address VGPR at all (descriptor ADD_TID_ENABLE, stride 16: lane i
         // reads 16 B at base + soffset + 16 i -- a contiguous 1-KiB piece), MODE 4 = MODE 2 with the MFMA waves idle (control)
         typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
         typedef float floatx4 __attribute__((ext_vector_type(4)));
         const bool mf = wv >= WAVES / 2;
-        if (mf) {
+        if (mf && (MODE == 5 || MODE == 6)) {
+            // partner waves stream ds_read_b128 (MODE 5: all the time, 24 reads then a wait -- the GEMM's fragment reads; MODE 6:
+            // plus 60 MFMAs after every 24 reads, the GEMM's ratio)
+            typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+            typedef float floatx4 __attribute__((ext_vector_type(4)));
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smc;
+            const unsigned ra = lds0 + (lane & 15) * 128 + 16 * (lane >> 4);
+            floatx4 c0 = {0, 0, 0, 0}, c1 = c0;
+            bf16x8 a, b;
+            for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(float)(lane + i); b[i] = (__bf16)(float)(lane ^ i); }
+            const int n = iters * ksteps * (MODE == 6 ? 1 : 3);
+            for (int i = 0; i < n; ++i) {
+                u32x4 r[24];
+#pragma unroll
+                for (int k = 0; k < 24; ++k) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r[k]) : "v"(ra), "i"((k % 16) * 2048) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < 24; ++k) asm volatile("" :: "v"(r[k]));
+                if (MODE == 6) {
+#pragma unroll
+                    for (int k = 0; k < 30; ++k) {
+                        c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c0, 0, 0, 0);
+                        c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c1, 0, 0, 0);
+                    }
+                }
+            }
+            acc = __float_as_uint(c0[0] + c1[1]);
+        } else if (mf) {
             if (MODE != 4) {
                 floatx4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
                 bf16x8 a, b;
@@ -122,7 +150,7 @@ __global__ __launch_bounds__(WAVES * 64) void fill_k(const char* src, int rs, in
 template <int MODE, int WAVES, int INFL>
 static void run(const char* name, const char* src, int rs, int ksteps, int iters, int T, int nwg, unsigned* sink,
                 unsigned long long* cyc) {
-    const size_t lds = MODE != 1 ? (size_t)WAVES * (INFL + 1) * 1024 : 0;
+    const size_t lds = MODE != 1 ? ((size_t)WAVES * (INFL + 1) * 1024 < 36864 ? 36864 : (size_t)WAVES * (INFL + 1) * 1024) : 0;
     if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(&fill_k<MODE, WAVES, INFL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
@@ -172,6 +200,8 @@ int main(int argc, char** argv) {
         run<4, 8, 15>("LDS-DMA 4 of 8 waves, others idle", src, rs, ksteps, iters, T, 256, sink, cyc);
         run<2, 8, 15>("LDS-DMA 4 of 8 waves, others MFMA", src, rs, ksteps, iters, T, 256, sink, cyc);
         run<3, 8, 15>("same, ADD_TID (no address VGPR)", src, rs, ksteps, iters, T, 256, sink, cyc);
+        run<5, 8, 15>("LDS-DMA 4 of 8 waves, others ds_read_b128", src, rs, ksteps, iters, T, 256, sink, cyc);
+        run<6, 8, 15>("LDS-DMA 4 of 8, others 24 reads + 60 MFMA", src, rs, ksteps, iters, T, 256, sink, cyc);
         run<1, 4, 8>("regs 4 waves, 8 in flight/wave", src, rs, ksteps, iters, T, 256, sink, cyc);
         run<1, 4, 16>("regs 4 waves, 16 in flight/wave", src, rs, ksteps, iters, T, 256, sink, cyc);
         run<1, 8, 16>("regs 8 waves, 16 in flight/wave", src, rs, ksteps, iters, T, 256, sink, cyc);
