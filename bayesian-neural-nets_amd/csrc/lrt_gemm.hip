@@ -830,269 +830,10 @@ namespace {
 #endif
 
 // ------------------------------------------------------------------------------------------------
-// Ring form of the split-precision kernel: ONE 8-wave workgroup per CU on a 256(b) x 80(o) tile, three LDS stages
-// (3 x 52 KB), the LDS-DMA of K step c+2 issued during step c.
-//
-// Why (round 2, tools/gemm_stamps.py / gemm_ksweep.py / lab/dma_rate.hip / lab/lds_rate.hip): the 128 x 80 kernel costs
-// 1.44 us per K step and CU against 0.95 us of MFMA time, and the K-independent rest of a launch is 16 us.  Per step
-// and CU it moves 72 1-KiB DMA pieces; a CU's fill path serves one piece per ~23 cycles whatever the number of issuing
-// waves (105 GB/s per CU in isolation), i.e. 1 700 of the 2 000 cycles the MFMAs need -- and a wave is stalled ~125
-// cycles per piece while four to eight waves queue for that path, which puts 1 100 cycles of DMA issue into every wave's
-// serial chain of a step next to 1 000-1 200 of conversions + MFMAs.  The two 128-row tiles of a CU share their weight
-// lines here (52 pieces per step and CU instead of 72), the third stage lets a piece land two steps after its issue
-// instead of one, and the two halves of the workgroup run half a step apart (STAGGER: waves 4-7 -- the SIMD partners of
-// waves 0-3 -- issue the MFMAs of step c-1 right after the barrier of step c, from operands kept in registers, while
-// waves 0-3 read and convert step c), so that a SIMD's matrix pipe has work while its other wave reads LDS or queues for
-// the fill path.  Same arithmetic in the same order per accumulator: bit-identical to the 128 x 80 kernel.
-//
-// Synchronisation: a wave retires ITS OWN pieces of step c with a counted s_waitcnt vmcnt(n) that leaves step c+1's in
-// flight, then one raw s_barrier makes every wave's share of stage c visible.  The pieces of step c+2 go into the stage
-// read in step c-1, which every wave finished reading before it arrived at that barrier.  hipcc drains vmcnt(0) before
-// any LDS read it can see behind a pending LDS-DMA, so the fragment reads are inline asm with their own lgkmcnt wait.
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-#define LBBNN_DS_READ128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off) : "memory")
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
-
-template <int TO, bool MEAN_ONLY, bool STAGGER>
-__device__ __forceinline__ void lrt_gemm_bf16x3_ring_body(const GemmArgs& a_in) {
-    const GemmArgs a = member_view(a_in);
-    constexpr int TB = 2, WB = 8, NS = 3;
-    constexpr int BN = TO * 16, BM = TB * WB * 16;
-    constexpr int NWR = MEAN_ONLY ? 1 : 2;
-    constexpr int XB = BM * 128, WRB = BN * 128, BUFB = XB + NWR * WRB;
-    constexpr int NGX = BM / 8, NGW = BN / 8, NG = NGX + NWR * NGW;
-    constexpr int NPW = (NG + WB - 1) / WB, REM = NG % WB;      // waves < REM issue NPW pieces per step, the others NPW - 1
-    extern __shared__ __attribute__((aligned(16))) char smc[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lr = lane & 15, q = lane >> 4;
-    if (a.fin.n > 0 && blockIdx.y == gridDim.y - 1) {                          // the finalize row (uniform per workgroup)
-        if (blockIdx.x == 0) kl_finalize_piggy<WB>(kernarg_as<GemmArgs>()->fin, reinterpret_cast<float*>(smc));
-        return;
-    }
-    int tox, tby;
-    tile_of_block(tox, tby, a.fin.n > 0 ? 1 : 0);
-    const int o0 = tox * BN, b0 = tby * BM;
-    const int kbeg = a.kchunk ? (int)blockIdx.z * a.kchunk : 0;
-    const int Iloc = a.kchunk ? min(a.I - kbeg, a.kchunk) : a.I;
-    const unsigned xbytes = (unsigned)min((size_t)0x7FFFFFF0u, ((size_t)(a.B - 1) * a.ldx + a.I) * 4);
-    const unsigned wbytes = (unsigned)min((size_t)0x7FFFFFF0u, (size_t)a.O * a.ld * 4);
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)xbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc((void*)a.e_w, 0, (int)wbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(MEAN_ONLY ? a.e_w : a.var_w), 0, (int)wbytes, 0x00020000);
-    int gv[NPW], kx[NPW];
-#pragma unroll
-    for (int u = 0; u < NPW; ++u) {
-        const int g = wv + WB * u;
-        if (g < NGX) {
-            const int row = 8 * g + (lane >> 3);
-            const int slot = (lane & 7) ^ swzx(row & 15);
-            gv[u] = (int)(((size_t)min(b0 + row, a.B - 1) * a.ldx + kbeg) * 4) + 16 * slot;
-            kx[u] = 4 * slot;
-        } else {
-            const int gw = min(g, NG - 1) - NGX, row = 8 * (gw % NGW) + (lane >> 3);
-            const int slot = (lane & 7) ^ swzx(row & 15);
-            gv[u] = (int)((size_t)min(o0 + row, a.O - 1) * a.ld * 4) + (kbeg >> 5) * 128 + 16 * slot;
-            kx[u] = -1;
-        }
-    }
-    const int nsteps = (Iloc + BKS - 1) / BKS;
-    const bool has_tail = (Iloc % BKS) != 0;
-    // piece U of this wave for K step C from the address set VA (gv, or gvt on the K-tail step: registers of their own, see
-    // the 128 x 80 kernel).  A macro, not a lambda: nested closures kept the address arrays in scratch.
-    int gvt[NPW];
-#pragma unroll
-    for (int u = 0; u < NPW; ++u)
-        gvt[u] = (kx[u] >= 0 && (nsteps - 1) * BKS + kx[u] >= Iloc) ? 0x7FFFFFF0 : gv[u];
-#define LBBNN_RING_PIECE_VA(C, U, VA)                                                                                   \
-    do {                                                                                                                \
-        const int g_ = wv + WB * (U);                                                                                  \
-        if (g_ < NG) {                                                                                                  \
-            char* buf_ = smc + ((C) % NS) * BUFB;                                                                       \
-            const int loff_ = g_ < NGX ? g_ * 1024 : XB + (g_ - NGX) * 1024;                                            \
-            auto* dst_ = (__attribute__((address_space(3))) void*)(buf_ + loff_);                                      \
-            if (g_ < NGX)                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, dst_, 16, VA[U], (C) * 128, 0, 0); \
-            else if (g_ - NGX < NGW)      __builtin_amdgcn_raw_ptr_buffer_load_lds(re, dst_, 16, VA[U], (C) * 128, 0, 0); \
-            else                          __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, dst_, 16, VA[U], (C) * 128, 0, 0); \
-        }                                                                                                               \
-    } while (0)
-#define LBBNN_RING_PIECE(C, U)                                                                                          \
-    do { if (has_tail && (C) == nsteps - 1) LBBNN_RING_PIECE_VA(C, U, gvt); else LBBNN_RING_PIECE_VA(C, U, gv); } while (0)
-    auto dma_step = [&](int c) {
-#pragma unroll
-        for (int u = 0; u < NPW; ++u) LBBNN_RING_PIECE(c, u);
-    };
-    const bool long_wave = (REM == 0) || (wv < REM);
-    auto retire = [&](int c) {       // my pieces of step c have landed (step c+1's stay in flight); then everyone's
-        if (c + 1 < nsteps) { if (long_wave) wait_vmcnt<NPW>(); else wait_vmcnt<(NPW > 1 ? NPW - 1 : 0)>(); }
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-    };
-
-    floatx4 accm[TO][TB], accv[TO][TB];
-#pragma unroll
-    for (int i = 0; i < TO; ++i)
-#pragma unroll
-        for (int j = 0; j < TB; ++j) { accm[i][j] = floatx4{0.f, 0.f, 0.f, 0.f}; accv[i][j] = floatx4{0.f, 0.f, 0.f, 0.f}; }
-
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smc;
-    const int gx = swzx(lr);
-    const uint32_t xa0 = lds0 + (wv * TB * 16 + lr) * 128 + 16 * ((2 * q) ^ gx);
-    const uint32_t xa1 = lds0 + (wv * TB * 16 + lr) * 128 + 16 * ((2 * q + 1) ^ gx);
-    const uint32_t wah = lds0 + XB + lr * 128 + 16 * ((2 * q) ^ gx);
-    const uint32_t wal = lds0 + XB + lr * 128 + 16 * ((2 * q + 1) ^ gx);
-
-    u32x4 xr[TB][2], wh[TO], wl[TO], wvh[TO], wvl[TO];
-    bf16x8 xh[TB], xl[TB], sh[TB], sl[TB];
-    auto read_frags = [&](int c) {
-        const uint32_t bo = (uint32_t)((c % NS) * BUFB);
-        const uint32_t x0 = xa0 + bo, x1 = xa1 + bo, w0 = wah + bo, w1 = wal + bo;
-        LBBNN_DS_READ128(xr[0][0], x0, 0);
-        LBBNN_DS_READ128(xr[0][1], x1, 0);
-        LBBNN_DS_READ128(xr[1][0], x0, 16 * 128);
-        LBBNN_DS_READ128(xr[1][1], x1, 16 * 128);
-#pragma unroll
-        for (int i = 0; i < TO; ++i) {
-            LBBNN_DS_READ128(wh[i], w0, i * 2048);
-            LBBNN_DS_READ128(wl[i], w1, i * 2048);
-            if (!MEAN_ONLY) {
-                LBBNN_DS_READ128(wvh[i], w0, WRB + i * 2048);
-                LBBNN_DS_READ128(wvl[i], w1, WRB + i * 2048);
-            }
-        }
-    };
-    auto wait_frags = [&]() {        // every destination is named so that no use can be scheduled above the wait
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xr[0][0]), "+v"(xr[0][1]), "+v"(xr[1][0]), "+v"(xr[1][1]) :: "memory");
-#pragma unroll
-        for (int i = 0; i < TO; ++i) {
-            asm volatile("" : "+v"(wh[i]), "+v"(wl[i]) :: "memory");
-            if (!MEAN_ONLY) asm volatile("" : "+v"(wvh[i]), "+v"(wvl[i]) :: "memory");
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto convert = [&]() {           // x and x^2 into bf16 hi (truncated) / lo (RNE of the exact remainder), as the 128 x 80 kernel
-#pragma unroll
-        for (int j = 0; j < TB; ++j) {
-            const float v[8] = {__uint_as_float(xr[j][0][0]), __uint_as_float(xr[j][0][1]), __uint_as_float(xr[j][0][2]),
-                                __uint_as_float(xr[j][0][3]), __uint_as_float(xr[j][1][0]), __uint_as_float(xr[j][1][1]),
-                                __uint_as_float(xr[j][1][2]), __uint_as_float(xr[j][1][3])};
-            uint32_t ph[4], pl[4], qh[4], ql[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const uint32_t u0 = __float_as_uint(v[2 * t]), u1 = __float_as_uint(v[2 * t + 1]);
-                ph[t] = __builtin_amdgcn_perm(u1, u0, 0x07060302);
-                const floatx2 lo = {v[2 * t] - __uint_as_float(u0 & 0xFFFF0000u), v[2 * t + 1] - __uint_as_float(u1 & 0xFFFF0000u)};
-                pl[t] = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2));
-                qh[t] = 0; ql[t] = 0;
-                if (!MEAN_ONLY) {
-                    const float s0 = v[2 * t] * v[2 * t], s1 = v[2 * t + 1] * v[2 * t + 1];
-                    const uint32_t y0 = __float_as_uint(s0), y1 = __float_as_uint(s1);
-                    qh[t] = __builtin_amdgcn_perm(y1, y0, 0x07060302);
-                    const floatx2 slo = {s0 - __uint_as_float(y0 & 0xFFFF0000u), s1 - __uint_as_float(y1 & 0xFFFF0000u)};
-                    ql[t] = __builtin_bit_cast(uint32_t, __builtin_convertvector(slo, bf16x2));
-                }
-            }
-            xh[j] = __builtin_bit_cast(bf16x8, u32x4{ph[0], ph[1], ph[2], ph[3]});
-            xl[j] = __builtin_bit_cast(bf16x8, u32x4{pl[0], pl[1], pl[2], pl[3]});
-            sh[j] = __builtin_bit_cast(bf16x8, u32x4{qh[0], qh[1], qh[2], qh[3]});
-            sl[j] = __builtin_bit_cast(bf16x8, u32x4{ql[0], ql[1], ql[2], ql[3]});
-        }
-    };
-    // cdma >= 0: the pieces of K step cdma are issued BETWEEN the MFMA groups, one per (o-tile, b-tile) group: a piece
-    // issued into a fill path that other waves have just filled stalls its wave for ~150 cycles, one issued every ~100
-    // cycles of matrix work finds it free (tools/gemm_stamps.py, ring build)
-    auto mfmas = [&](int cdma) {     // same products in the same order per accumulator as the 128 x 80 kernel
-#pragma unroll
-        for (int j = 0; j < TB; ++j) {
-#pragma unroll
-            for (int i = 0; i < TO; ++i) {
-                if (j * TO + i < NPW && cdma >= 0) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    LBBNN_RING_PIECE(cdma, j * TO + i);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                const bf16x8 ah = __builtin_bit_cast(bf16x8, wh[i]);
-                const bf16x8 al = __builtin_bit_cast(bf16x8, wl[i]);
-                accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh[j], accm[i][j], 0, 0, 0);
-                accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xh[j], accm[i][j], 0, 0, 0);
-                accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xl[j], accm[i][j], 0, 0, 0);
-                if (!MEAN_ONLY) {
-                    const bf16x8 bh = __builtin_bit_cast(bf16x8, wvh[i]);
-                    accv[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, sh[j], accv[i][j], 0, 0, 0);
-                    accv[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wvl[i]), sh[j], accv[i][j], 0, 0, 0);
-                    accv[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, sl[j], accv[i][j], 0, 0, 0);
-                }
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    const bool late = STAGGER && wv >= WB / 2;
-#ifdef LAB_GEMM_STAMPS          // phase stamps (tools/gemm_stamps.py RING=1): [0] step start (before the counted wait), [1] barrier passed, then per role
-    const int lab_lin = blockIdx.x + gridDim.x * blockIdx.y;
-    const bool lab_on = (lab_lin % 32) == 0 && lab_lin / 32 < LAB_ST_SLOTS / 8 && !MEAN_ONLY && lane == 0;
-    uint32_t* const lab_w = lab_gemm_stamps + (size_t)((lab_lin / 32) * 8 + wv) * LAB_ST_STEPS * LAB_ST_PH;
-    const uint32_t lab_k0 = (uint32_t)__builtin_readcyclecounter();
-    uint32_t lab_t[LAB_ST_PH];
-#define LAB_R(k) do { __builtin_amdgcn_sched_barrier(0); lab_t[k] = (uint32_t)__builtin_readcyclecounter() - lab_k0; __builtin_amdgcn_sched_barrier(0); } while (0)
-#define LAB_FLUSH(c) do { if (lab_on && (c) + 1 < LAB_ST_STEPS) { uint32_t* w_ = lab_w + ((c) + 1) * LAB_ST_PH; for (int k_ = 0; k_ < 7; ++k_) w_[k_] = lab_t[k_]; } } while (0)
-#else
-#define LAB_R(k)
-#define LAB_FLUSH(c)
-#endif
-    dma_step(0);
-    if (nsteps > 1) dma_step(1);
-    if (!late) {
-        for (int c = 0; c < nsteps; ++c) {
-            LAB_R(0);
-            retire(c);
-            LAB_R(1);
-            if (c + 2 < nsteps) dma_step(c + 2);                    // first: the fill path is free while waves 4-7 issue MFMAs
-            LAB_R(2);
-            read_frags(c);
-            LAB_R(3);
-            wait_frags();
-            LAB_R(4);
-            convert();
-            LAB_R(5);
-            mfmas(-1);
-            LAB_R(6);
-            LAB_FLUSH(c);
-        }
-    } else {
-        for (int c = 0; c < nsteps; ++c) {
-            LAB_R(0);
-            retire(c);
-            LAB_R(1);
-            if (c > 0) mfmas(-1);                                    // step c-1, operands already in registers
-            LAB_R(2);
-            if (c + 2 < nsteps) dma_step(c + 2);
-            LAB_R(3);
-            read_frags(c);
-            LAB_R(4);
-            wait_frags();
-            LAB_R(5);
-            convert();
-            LAB_R(6);
-            LAB_FLUSH(c);
-        }
-        mfmas(-1);                                                    // step nsteps-1
-    }
-#ifdef LAB_GEMM_STAMPS
-    if (lab_on) { lab_w[0] = 0; lab_w[1] = 0; lab_w[2] = (uint32_t)__builtin_readcyclecounter() - lab_k0; lab_w[3] = lab_w[2];
-                  lab_w[4] = (uint32_t)nsteps; lab_w[5] = (uint32_t)lab_lin; }
-#endif
-
-    GemmArgs ao = a;
-    if (a.kchunk) ao.out = a.out + (size_t)blockIdx.z * a.split_stride;
-    epilogue_tile<TO, TB, MEAN_ONLY>(ao, o0, q, b0 + wv * TB * 16 + lr, accm, accv);
-}
-template <int TO, bool MEAN_ONLY, bool STAGGER>
-__global__ __launch_bounds__(512, 2) void lrt_gemm_bf16x3_ring_kernel(const GemmArgs a_in) {
-    lrt_gemm_bf16x3_ring_body<TO, MEAN_ONLY, STAGGER>(a_in);
-}
+// (A 256 x 80 three-stage ring form of the kernel above -- one 8-wave workgroup per CU, LDS-DMA two K steps ahead, the two
+// halves of the workgroup half a step apart -- was rebuilt in round 2 on today's piece shapes and measured again: bit-identical,
+// 1.38-1.51 us per K step against 1.40-1.44 for the 128 x 80 kernel in four orderings of DMA / reads / MFMAs.  Source: commits
+// 8e8de53 and its successor; numbers and the reading in DESIGN.md 7.7.)
 
 // ------------------------------------------------------------------------------------------------
 // Skinny-output variant (O <= 16: the 10-class head).  One 16(o) x 16(b) accumulator pair per wave;
@@ -1301,26 +1042,6 @@ int launch_split_cfg(GemmArgs& a, bool mean_only, hipStream_t s, bool* hosted) {
     return launch_one(lrt_gemm_bf16x3_kernel<TO, TB, WB, false>, grid, block, l_full, s, a);
 }
 
-// 256 x 80 ring kernel: one 8-wave workgroup per CU, 3 LDS stages
-int launch_ring(GemmArgs& a, bool mean_only, bool stagger, hipStream_t s, bool* hosted) {
-    dim3 grid((a.O + 79) / 80, (a.B + 255) / 256, a.kchunk ? (a.I + a.kchunk - 1) / a.kchunk : (a.members > 1 ? a.members : 1));
-    dim3 block(512);
-    const size_t l_full = 3u * (256 * 128 + 2 * 80 * 128), l_mean = 3u * (256 * 128 + 80 * 128);
-    const int fin_n = a.fin.n;
-    a.fin.n = 0;
-    if (fin_n > 0 && hosted && !a.kchunk) {
-        a.fin.n = fin_n;
-        if (piggy_lds_bytes(a.fin) <= (mean_only ? l_mean : l_full)) { grid.y += 1; *hosted = true; }
-        else a.fin.n = 0;
-    }
-    if (mean_only) {
-        if (stagger) return launch_one(lrt_gemm_bf16x3_ring_kernel<5, true, true>, grid, block, l_mean, s, a);
-        return launch_one(lrt_gemm_bf16x3_ring_kernel<5, true, false>, grid, block, l_mean, s, a);
-    }
-    if (stagger) return launch_one(lrt_gemm_bf16x3_ring_kernel<5, false, true>, grid, block, l_full, s, a);
-    return launch_one(lrt_gemm_bf16x3_ring_kernel<5, false, false>, grid, block, l_full, s, a);
-}
-
 int launch_split(GemmArgs& a, bool mean_only, hipStream_t s, bool* hosted) {
     // 128x80 tile, 2 workgroups/CU, 2 LDS stages.  Variants measured and dropped: 256x80 3-stage ring
     // (one workgroup/CU), 128x160 with 4 or 8 waves, x split once per tile through LDS, x delivered pre-split.
@@ -1332,10 +1053,6 @@ int launch_split(GemmArgs& a, bool mean_only, hipStream_t s, bool* hosted) {
 #ifdef LAB_GEMM_518         // tools/lab experiment: ... by EIGHT waves of 16 rows each (4 waves per SIMD at 2 workgroups per CU)
     if (blocks_big >= 256 && a.B >= 96) return launch_split_cfg<5, 1, 8>(a, mean_only, s, hosted);
 #endif
-    const char* ring_env = getenv("LBBNN_GEMM_RING");
-    const int ring = ring_env ? atoi(ring_env) : 0;
-    const long blocks_ring = (long)((a.O + 79) / 80) * ((a.B + 255) / 256) * nz;
-    if (ring && blocks_ring >= 128 && !a.single16 && (a.members <= 1 || !a.kchunk)) return launch_ring(a, mean_only, ring >= 2, s, hosted);
     if (blocks_big >= 256 && a.B >= 96) return launch_split_cfg<5, 2, 4>(a, mean_only, s, hosted);
     return launch_split_cfg<5, 1, 2>(a, mean_only, s, hosted);
 }

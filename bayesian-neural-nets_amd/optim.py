@@ -50,10 +50,12 @@ class Adam(torch.optim.Optimizer):
             sg = sd["param_groups"][gi]
             sg.pop("step_dev", None)
             if step is not None:
-                val = step.detach().clone().reshape(())
+                count = float(step.detach().reshape(-1)[0])          # one device -> host read per group (checkpoint time only)
                 for idx in sg["params"]:
                     if idx in sd["state"]:
-                        sd["state"][idx] = dict(sd["state"][idx], step=val)
+                        # a tensor of its OWN per parameter, on the CPU, as torch.optim.Adam keeps it when capturable=False: its
+                        # foreach path adds 1 to every listed step tensor, so a tensor shared by two parameters would count double
+                        sd["state"][idx] = dict(sd["state"][idx], step=torch.tensor(count, dtype=torch.float32))
         return sd
 
     def load_state_dict(self, state_dict):

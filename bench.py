@@ -27,6 +27,9 @@ How the number is taken (round 2; the round-1 line did not reproduce under the d
      launch stream ("roofline", sampled_in = "separate pass after the timed region").  A roofline
      that contradicts the timed region (share of step > 1, launch longer than a step) is not
      printed: "roofline_invalid" carries the reason instead.
+     A step is ONE HIP-graph replay of the forward captured after the warm-up (--eager: the five
+     launches issued from Python each step); the noise is fresh on every replay -- the Philox
+     offset lives on the device and is advanced by the forward's own kernels.
   4. the same three stages again with the exact-fp32 MFMA GEMM ("secondary": reference precision).
   5. with --train (default at N > 1): the full data-parallel training step (forward, backward,
      flat-bucket gradient all-reduce over RCCL, Adam) as "secondary_train".
@@ -75,7 +78,13 @@ def parse():
     ap.add_argument("--train", dest="train", action="store_true", default=None,
                     help="also time the data-parallel training step (default: only when N > 1)")
     ap.add_argument("--no-train", dest="train", action="store_false")
-    ap.add_argument("--graph", action="store_true", help="capture one step in a HIP graph and replay it")
+    ap.add_argument("--graph", dest="graph", action="store_true", default=True,
+                    help="(default) capture one forward in a HIP graph after the warm-up and replay it: one host call per step, "
+                         "so a short timed region is not at the mercy of the host's launch jitter; fresh Philox noise on every "
+                         "replay (the offset lives on the device)")
+    ap.add_argument("--eager", dest="graph", action="store_false",
+                    help="launch every step from Python instead (5 launches per forward, ~100 us of host time against ~165 us "
+                         "of GPU time: 1-3 %% faster than replay in a long run, 0-8 %% slower in a 20-step region)")
     ap.add_argument("--precision", choices=("bf16x3", "fp32"), default="bf16x3",
                     help="GEMM arithmetic of the headline leg: bf16x3 = split-precision products on the bf16 matrix cores "
                          "with fp32 accumulation (measured 3e-6 relative on layer outputs, contract 1e-4); fp32 = exact "

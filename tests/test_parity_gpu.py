@@ -1801,8 +1801,8 @@ def test_propagate_flow_standalone_autograd_1d(bnn, dev, kind):
 def test_bench_contract_json_line():
     """bench.py, run exactly as the driver runs it (--gpus 1 --steps 20 --warmup 5; only the CPU-baseline budget is cut):
     ONE JSON line with the contract keys, a roofline that is consistent with the timed region, an fp32 secondary leg,
-    and a headline within 2x of the committed reference run (profiles/r02_bench_driver_cmd.json) -- a 10x regression
-    such as round 1's driver line (2.05 ms/step against 0.18) fails here."""
+    and a headline within 25 % of the committed reference run of the same command (profiles/r02_bench_driver_cmd.json; three
+    runs on three boxes were 23.70 / 23.77 / 23.88 M samples/s) -- round 1's driver line (2.05 ms/step against 0.18) fails here."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
@@ -1829,10 +1829,11 @@ def test_bench_contract_json_line():
     # the timed region has no outlier step hiding in the mean
     assert d["ms_per_step_max"] < 3.0 * d["ms_per_step_median"], d
     assert abs(d["ms_per_step"] - d["ms_per_step_median"]) < 0.25 * d["ms_per_step_median"], d
-    # within 2x of the committed run of the same command
+    # within 25 % of the committed run of the same command (one HIP-graph replay per step: no host jitter in the region)
+    assert d["hip_graph"] is True
     ref_path = os.path.join(root, "profiles", "r02_bench_driver_cmd.json")
     ref = json.loads(open(ref_path).read().strip().splitlines()[-1])
-    assert 0.5 * ref["value"] < d["value"] < 2.0 * ref["value"], (d["value"], ref["value"], d)
+    assert 0.75 * ref["value"] < d["value"] < 1.33 * ref["value"], (d["value"], ref["value"], d)
     sec = d["secondary"]
     assert sec["dtype"] == "f32" and sec["roofline"]["peak"] == 157.3 and 0.2 < sec["roofline"]["frac"] <= 1.0
     assert 0.5 * ref["secondary"]["value"] < sec["value"] < 2.0 * ref["secondary"]["value"], sec

@@ -40,21 +40,6 @@ lib.lbbnn_lab_gemm_stamps.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 rc = lib.lbbnn_lab_gemm_stamps(buf.ctypes.data, buf.nbytes)
 assert rc == 0, rc
 s = buf.reshape(SLOTS, STEPS, PH).astype(np.int64)
-if os.environ.get("LBBNN_GEMM_RING", "0") != "0":
-    # ring kernel: 8 waves per workgroup; phases per role (see the kernel): early = wait+barrier | read issue | dma | wait frags |
-    # convert | mfma ; late = wait+barrier | mfma(c-1) | dma | read issue | wait frags | convert
-    names = {False: ["wait+bar", "dma", "read_iss", "wait_frag", "convert", "mfma"], True: ["wait+bar", "mfma(c-1)", "dma", "read_iss", "wait_frag", "convert"]}
-    for sl in range(SLOTS):
-        ns = int(s[sl, 0, 4])
-        if ns == 0:
-            continue
-        ns = min(ns, STEPS - 1)
-        t = s[sl, 1:ns + 1, :7]
-        d = np.diff(t, axis=1)[2:-2]
-        step = (t[1:, 0] - t[:-1, 0])[2:-2].mean()
-        late = (sl % 8) >= 4 and os.environ["LBBNN_GEMM_RING"] == "2"
-        print("slot %2d wave %d %s | " % (sl, sl % 8, "late " if late else "early") + "  ".join("%s %5.0f" % (n, v) for n, v in zip(names[late], d.mean(0))) + " | step %5.0f | loop end %d" % (step, s[sl, 0, 2]))
-    sys.exit(0)
 print("slot lin wave | xcc se cu simd | loop_cycles total_cycles nsteps | per-step avg: ds_issue dma_issue conv+mfma barrier gap | step")
 rows = []
 for sl in range(SLOTS):
