@@ -1053,6 +1053,9 @@ int launch_split(GemmArgs& a, bool mean_only, hipStream_t s, bool* hosted) {
 #ifdef LAB_GEMM_518         // tools/lab experiment: ... by EIGHT waves of 16 rows each (4 waves per SIMD at 2 workgroups per CU)
     if (blocks_big >= 256 && a.B >= 96) return launch_split_cfg<5, 1, 8>(a, mean_only, s, hosted);
 #endif
+#ifdef LAB_FORCE_BIG       // tools/lab experiment (tools/two_stream_gemm.py): the 128x80 tile for row shards of the batch too
+    if (a.B >= 96) return launch_split_cfg<5, 2, 4>(a, mean_only, s, hosted);
+#endif
     if (blocks_big >= 256 && a.B >= 96) return launch_split_cfg<5, 2, 4>(a, mean_only, s, hosted);
     return launch_split_cfg<5, 1, 2>(a, mean_only, s, hosted);
 }

@@ -31,6 +31,7 @@ How the number is taken (round 2; the round-1 line did not reproduce under the d
      launches issued from Python each step); the noise is fresh on every replay -- the Philox
      offset lives on the device and is advanced by the forward's own kernels.
   4. the same three stages again with the exact-fp32 MFMA GEMM ("secondary": reference precision).
+  4b. at N > 1: the strong-scaling form (the same 4096 rows split N ways) as "secondary_strong".
   5. with --train (default at N > 1): the full data-parallel training step (forward, backward,
      flat-bucket gradient all-reduce over RCCL, Adam) as "secondary_train".
 
@@ -159,10 +160,23 @@ def cpu_baseline(batch, seconds):
             ts.append(time.perf_counter() - t0)
     ts.sort()
     med = ts[len(ts) // 2]
-    return {"value": batch / med, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": "%d ELBO forwards of the same 784-1200-1200-10 MNF/planar net at batch %d "
-                      "(torch-CPU fp32 oracle, as-written B-row z flow, randn draws included), median %.1f ms"
-                      % (iters, batch, med * 1e3)}
+    res = {"value": batch / med, "unit": "samples/s", "cores": cores, "kind": "port",
+           "sample": "%d ELBO forwards of the same 784-1200-1200-10 MNF/planar net at batch %d "
+                     "(torch-CPU fp32 oracle, as-written B-row z flow, randn draws included), median %.1f ms"
+                     % (iters, batch, med * 1e3)}
+    # the same forward with autograd recording, as train() runs it before .backward() (both); a few iterations
+    for pd in layers + [t for f in zf + rf for t in f.transforms]:
+        for v in pd.values():
+            if isinstance(v, torch.Tensor) and v.is_floating_point():
+                v.requires_grad_(True)
+    tg = []
+    for _ in range(max(3, min(10, iters // 4))):
+        t0 = time.perf_counter()
+        one()
+        tg.append(time.perf_counter() - t0)
+    tg.sort()
+    res["value_grad_enabled"] = batch / tg[len(tg) // 2]
+    return res
 
 
 def _recorded_events(n):
@@ -457,6 +471,14 @@ def main():
         legs["fp32"] = forward_leg(args, bnn_amd, ops, net, x, sync, "fp32", world)
     if args.precision == "bf16x3" and not args.no_reduced and world == 1:
         legs["bf16"] = forward_leg(args, bnn_amd, ops, net, x, sync, "bf16", world)
+    strong = None
+    if world > 1 and B % world == 0 and not args.no_secondary:
+        # SURVEY.md 8(d) asks for both scalings: the SAME 4096 rows split N ways (rank r takes rows [r B/N, (r+1) B/N)), no
+        # collective either -- reported beside the weak-scaling headline, never instead of it
+        Bs = B // world
+        net.set_row_offset(rank * Bs)
+        strong = forward_leg(args, bnn_amd, ops, net, x[:Bs], sync, args.precision, world)
+        net.set_row_offset(rank * B)
     train = None
     if want_train:
         train = train_leg(args, bnn_amd, net, x, sync, world, rank)
@@ -520,6 +542,14 @@ def main():
                 else:
                     red["roofline_invalid"] = why
             res["secondary_reduced_bf16"] = red
+        if strong is not None:
+            st = {"what": "STRONG scaling: the headline's global batch of %d rows split over the %d ranks (%d rows each), same step"
+                          % (B, world, B // world),
+                  "scaling": "strong", "global_batch": B, "value": B * args.steps / strong["elapsed"], "unit": "samples/s",
+                  "steps": args.steps, "ms_per_step": strong["elapsed"] / args.steps * 1e3, "settle": strong["settle"],
+                  "timed_attempts": strong["attempts"]}
+            step_stats(st, strong["per_step"])
+            res["secondary_strong"] = st
         if train is not None:
             if world > 1 and backend == "nccl":
                 train["rccl"] = rccl_log_summary(os.environ.get("NCCL_DEBUG_FILE"))

@@ -454,6 +454,40 @@ def test_hip_graph_capture_replays_with_fresh_noise(bnn, dev):
     assert abs(float(k1) - float(k2)) / abs(float(k1)) < 1e-2 and float(k1) != float(k2)
 
 
+@pytest.mark.parametrize("flow", ["Planar", "RNVP"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_hip_graph_replays_equal_the_eager_sequence_bitwise(bnn, dev, flow, prec):
+    """What bench.py times by default -- ONE replay of the captured forward per step -- is the same computation as the eager
+    launches: from the same Philox {seed, offset}, replay k gives the k-th eager forward's output and KL bit for bit (the
+    offset lives on the device and is advanced by the forward's own kernels, inside the graph too)."""
+    from bnn_amd import ops
+    bnn.set_precision(prec)
+    try:
+        torch.manual_seed(11)
+        net = bnn.mnf.BayesianNetwork((784, 256, 128, 10), 2, z_flow_type=flow, r_flow_type=flow).to(dev).train()
+        x = torch.rand(192, 784, device=dev)
+        st = ops.RngState.get(dev)
+        with torch.no_grad():
+            net(x, sample=True); torch.cuda.synchronize()
+            start = st.t[:2].clone()
+            eager = []
+            for _ in range(3):
+                o = net(x, sample=True)
+                eager.append((o.clone(), net.kl().clone()))
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = net(x, sample=True)
+                kl = net.kl()
+            st.t[:2].copy_(start)
+            for k in range(3):
+                g.replay(); torch.cuda.synchronize()
+                assert torch.equal(out, eager[k][0]) and torch.equal(kl, eager[k][1]), k
+            assert not torch.equal(eager[0][0], eager[1][0])
+    finally:
+        bnn.set_precision("fp32")
+
+
 # --------------------------------------------------------------------------- split-precision (bf16x3) path
 @pytest.mark.parametrize("B,I,O", [(128, 64, 80), (100, 784, 400), (257, 1200, 1200), (1024, 784, 400), (64, 40, 17),
                                    (4000, 784, 1200), (3333, 1200, 1190), (2100, 96, 1200)])
