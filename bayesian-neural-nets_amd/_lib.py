@@ -170,6 +170,7 @@ SIGNATURES = {
     "lbbnn_weight_pass_backward_workspace": (c_i64, [c_i, c_i]),
     "lbbnn_weight_pass_backward": (c_i, [ctypes.POINTER(WpbArgs), c_p]),
     "lbbnn_layers_dense_flows": (c_i, [ctypes.POINTER(DenseLayer), c_i, c_p, c_p]),
+    "lbbnn_layers_dense_flows_phase": (c_i, [ctypes.POINTER(DenseLayer), c_i, c_p, c_i, c_p]),
     "lbbnn_flow_dense_save_size": (c_i64, [c_i, c_i, c_i]),
     "lbbnn_mnf_flow_dense_backward_workspace": (c_i64, [c_i]),
     "lbbnn_mnf_flow_dense_backward": (c_i, [ctypes.POINTER(DenseBwdArgs), c_p]),

@@ -376,7 +376,9 @@ extern "C" int64_t lbbnn_flow_dense_save_size(int I, int Tz, int Tr) {
 }
 
 // K4 of n layers in 2 + 2*(Tz+Tr) launches (blockIdx.z = layer); the layers must agree on Tz, Tr and want_kl
-static int dense_flows_impl(const lbbnn_dense_layer_t* L, int n, const uint64_t* rng, void* stream) {
+// phase 0: everything; 1: the draws + the z flow (what the weight pass needs: z_fwd, z_kl); 2: the r flow + the scalars (what only the
+// KL finalize needs) -- phases 1 and 2 of one forward may run on different streams, 2 after 1 (lbbnn_layers_dense_flows_phase)
+static int dense_flows_impl(const lbbnn_dense_layer_t* L, int n, const uint64_t* rng, void* stream, int phase = 0) {
     if (!L) return LBBNN_E_NULL;
     if (n <= 0 || n > LBBNN_MAX_LAYERS) return LBBNN_E_SHAPE;
     const int Tz = L[0].Tz, Tr = L[0].Tr, want_kl = L[0].want_kl;
@@ -435,10 +437,11 @@ static int dense_flows_impl(const lbbnn_dense_layer_t* L, int n, const uint64_t*
             for (int t = 0; t < ia.Tm[2]; ++t) ia.mk[2][t] = const_cast<float*>(d.rt[t].mask_kl);
         }
     }
-    hipLaunchKernelGGL(dense_init_kernel, dim3(gblk, npaths, n), dim3(NTC), 0, s, ib);
+    if (phase != 2) hipLaunchKernelGGL(dense_init_kernel, dim3(gblk, npaths, n), dim3(NTC), 0, s, ib);
 
     for (int t = 0; t < S; ++t) {
         const bool zphase = t < Tz;
+        if ((phase == 1 && !zphase) || (phase == 2 && zphase)) continue;
         StageBatch sb{};
         for (int k = 0; k < n; ++k) {
             const lbbnn_dense_layer_t& d = L[k];
@@ -486,19 +489,26 @@ static int dense_flows_impl(const lbbnn_dense_layer_t* L, int n, const uint64_t*
     for (int k = 0; k < n; ++k) {
         const lbbnn_dense_layer_t& d = L[k];
         const Bufs& b = B[k];
-        if (want_kl && Tz == 0) (void)hipMemcpyAsync(d.z_kl, d.save ? b.ZK : b.zbuf1, (size_t)d.I * sizeof(float), hipMemcpyDeviceToDevice, s);
-        if (d.save && Tz == 0) (void)hipMemcpyAsync(d.z_fwd, b.ZF, (size_t)d.I * sizeof(float), hipMemcpyDeviceToDevice, s);
+        if (phase != 2) {
+            if (want_kl && Tz == 0) (void)hipMemcpyAsync(d.z_kl, d.save ? b.ZK : b.zbuf1, (size_t)d.I * sizeof(float), hipMemcpyDeviceToDevice, s);
+            if (d.save && Tz == 0) (void)hipMemcpyAsync(d.z_fwd, b.ZF, (size_t)d.I * sizeof(float), hipMemcpyDeviceToDevice, s);
+        }
         FinishArgs& fa = fb.l[k];
         fa.ldz = b.ldz; fa.ldr = b.ldr; fa.lq0 = b.lq0;
         fa.zr = !d.save ? b.zbuf1 : ((want_kl && Tr > 0) ? b.ZR + (size_t)(Tr - 1) * d.I : b.ZK + (size_t)Tz * d.I); fa.ldf = b.ldf; fa.scal = d.scal;
         fa.nblk = b.nblk; fa.nblk_i = b.nblk_i; fa.Tz = Tz; fa.Tr = want_kl ? Tr : 0; fa.I = d.I; fa.want_kl = want_kl;
     }
-    hipLaunchKernelGGL(dense_finish_kernel, dim3(n), dim3(64), 0, s, fb);
+    if (phase != 1) hipLaunchKernelGGL(dense_finish_kernel, dim3(n), dim3(64), 0, s, fb);
     return (int)hipGetLastError();
 }
 
 extern "C" int lbbnn_layers_dense_flows(const lbbnn_dense_layer_t* layers, int n, const uint64_t* rng, void* stream) {
     return dense_flows_impl(layers, n, rng, stream);
+}
+
+extern "C" int lbbnn_layers_dense_flows_phase(const lbbnn_dense_layer_t* layers, int n, const uint64_t* rng, int phase, void* stream) {
+    if (phase < 0 || phase > 2) return LBBNN_E_FLAGS;
+    return dense_flows_impl(layers, n, rng, stream, phase);
 }
 
 extern "C" int lbbnn_mnf_flow_dense(const float* q0_mean, const float* q0_log_var,

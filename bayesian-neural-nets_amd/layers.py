@@ -38,6 +38,21 @@ _DENSE_HIP_BWD = _os.environ.get("LBBNN_DENSE_TORCH_BWD", "0") != "1"
 # LBBNN_TORCH_MASKS=1: draw the Bernoulli masks of the dense flows with torch's generator (one bernoulli_ launch per
 # forward) instead of in the flow kernels from the layer's Philox state
 _MASKS_IN_KERNEL = _os.environ.get("LBBNN_TORCH_MASKS", "0") != "1"
+# LBBNN_DENSE_DEFER=0: keep the r flow and the flows' scalars of the dense flows on the forward's own stream, ahead of the weight
+# pass (default: while a HIP graph is being captured they go on a side stream beside the weight pass and the first GEMM -- only
+# the KL finalize needs them; "always": in eager launches too)
+_DENSE_DEFER = {"0": False, "always": "always"}.get(_os.environ.get("LBBNN_DENSE_DEFER", "1"), True)
+_SIDE = {}
+
+
+def _side_stream(dev):
+    """One side stream per device (the deferred part of the dense flows); created on first use."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _SIDE.get(key)
+    if st is None:
+        st = _SIDE[key] = torch.cuda.Stream(device=dev)
+    return st
+
 
 # Optional deferral of the vector-sized backward chains (V2 / lbbnn_mnf_flow_dense_backward: latency-bound, a handful of
 # workgroups, feeding nothing but the optimizer): each layer's backward only FILES its chain, and when the backward pass
@@ -1113,16 +1128,35 @@ class _NetworkBase(nn.Module):
         # flows that are not planar run first (K4 batched over the layers; 1-D chains per layer), then lbbnn_layers_operands
         # runs K1 only for those layers (flows_done)
         dense = [(l, c) for l, c in zip(layers, cfgs) if l._mnf and l._check_flows() == "dense"]
+        # The r flow and the flows' scalars feed the KL only (LBBNN-GP-MF-MNF.py:208-235); the activations need z_k alone (:190-200).
+        # With KL wanted and a second GEMM to carry the finalize, that part of the dense flows (2 of the 4 stage launches + the
+        # finish for the reference's T = 2: ~42 us) runs on a side stream beside the weight pass and the first GEMM, and the KL
+        # finalize + the RNG advance ride in the SECOND GEMM's launch instead of the first.  Same kernels, same arguments, same
+        # results bit for bit (test_dense_flows_deferred_r_part_bitwise); LBBNN_DENSE_DEFER=0 keeps everything on one stream.
+        # Measured (RNVP, headline sizes, graph replay): 0.237 -> 0.226 ms; the join costs the second GEMM ~11 us of cross-queue
+        # latency and the side branch runs 2.5 x slower beside the first GEMM than alone, or the gain would be the whole 42 us.
+        defer_ev = fork_ev = deferred = None
         if dense:
             self._predraw_masks([l for l, _ in dense])
             same = len({(len(l.z_flow.transforms), len(l.r_flow.transforms), c[1]) for l, c in dense}) == 1
             groups = [dense] if same else [[lc] for lc in dense]
+            # (only while a HIP graph is being captured: launched from Python the two event calls and the stream switch cost the
+            # host more than the overlap returns -- RNVP forward 0.405 -> 0.454 ms eager, 0.237 -> 0.226 ms replayed)
+            defer = (_DENSE_DEFER and (torch.cuda.is_current_stream_capturing() or _DENSE_DEFER == "always") and n >= 2
+                     and all(c[1] for _, c in dense) and layers[1].out_features > 16
+                     and any(len(l.r_flow.transforms) > 0 for l, _ in dense))
+            batches = []
             for grp in groups:
                 dls = (_lib.DenseLayer * len(grp))()
                 for k, (l, c) in enumerate(grp):
                     l._dense_layer_desc(dls[k], c, keep)
-                _lib.check(_lib.lib().lbbnn_layers_dense_flows(dls, len(grp), rng.data_ptr() if rng is not None else None, stream),
-                           "lbbnn_layers_dense_flows")
+                batches.append((dls, len(grp)))
+                _lib.check(_lib.lib().lbbnn_layers_dense_flows_phase(dls, len(grp), rng.data_ptr() if rng is not None else None,
+                                                                    1 if defer else 0, stream), "lbbnn_layers_dense_flows_phase")
+            if defer:
+                fork_ev = torch.cuda.Event()
+                fork_ev.record(torch.cuda.current_stream(dev))
+                deferred = batches
         for l, c in zip(layers, cfgs):
             if l._mnf and l._check_flows() == "chain":
                 noise = l.noise or {}
@@ -1140,11 +1174,25 @@ class _NetworkBase(nn.Module):
         _lib.check(_lib.lib().lbbnn_layers_operands_snap(descs, n, rng.data_ptr() if rng is not None else None,
                                                          snap.data_ptr() if snap is not None else None, 0, stream),
                    "lbbnn_layers_operands_snap")
+        if deferred is not None:
+            # enqueued AFTER the weight pass: a captured graph keeps the first-recorded successor of a fork on the parent's queue,
+            # and a hop to another queue costs ~11 us -- it must be the side branch that pays it, not the weight pass
+            side = _side_stream(dev)
+            side.wait_event(fork_ev)
+            for dls, cnt in deferred:
+                _lib.check(_lib.lib().lbbnn_layers_dense_flows_phase(dls, cnt, rng.data_ptr() if rng is not None else None,
+                                                                    2, side.cuda_stream), "lbbnn_layers_dense_flows_phase")
+            defer_ev = torch.cuda.Event()
+            defer_ev.record(side)
         all_kl = want_kl and all(c[1] for c in cfgs)
+        fin_at = 1 if defer_ev is not None else 0
         for i, (l, c) in enumerate(zip(layers, cfgs)):
-            # the KL finalize of all layers (parameters only) rides in the first GEMM's launch as one extra workgroup
+            # the KL finalize of all layers (parameters only) rides in the first GEMM's launch as one extra workgroup (in the
+            # second's when part of the dense flows was deferred: it waits for the side stream first)
             fin = None
-            if i == 0 and (want_kl or st is not None):
+            if i == fin_at and defer_ev is not None:
+                torch.cuda.current_stream(dev).wait_event(defer_ev)
+            if i == fin_at and (want_kl or st is not None):
                 fin = (descs if want_kl else None, n if want_kl else 0, snap.data_ptr() if snap is not None else None,
                        kls[n:].data_ptr() if all_kl else None, rng.data_ptr() if rng is not None else None,
                        1 if rng is not None else 0)

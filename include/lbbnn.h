@@ -211,6 +211,12 @@ typedef struct lbbnn_dense_layer {
 
 int64_t lbbnn_flow_dense_save_size(int I, int Tz, int Tr);
 int lbbnn_layers_dense_flows(const lbbnn_dense_layer_t* layers, int n, const uint64_t* rng, void* stream);
+/* The same launches in two parts, so that the part only the KL needs can leave the critical path of a forward
+ * (LBBNN-GP-MF-MNF.py:190-200 needs z_k only; :208-235 need the rest): phase 1 = the draws and the z flow on both draws
+ * (outputs z_fwd, z_kl), phase 2 = the r flow on the KL draw and the scalars (scal); phase 0 = both (the call above).
+ * Phase 2 must follow phase 1 of the same call arguments (it continues in `work`); it may be enqueued on another stream
+ * once phase 1 has completed there. */
+int lbbnn_layers_dense_flows_phase(const lbbnn_dense_layer_t* layers, int n, const uint64_t* rng, int phase, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K5  lbbnn_kl_finalize -- the O(O+I) tail of the KL and the final scalar.

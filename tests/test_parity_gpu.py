@@ -454,6 +454,44 @@ def test_hip_graph_capture_replays_with_fresh_noise(bnn, dev):
     assert abs(float(k1) - float(k2)) / abs(float(k1)) < 1e-2 and float(k1) != float(k2)
 
 
+@pytest.mark.parametrize("flow", ["RNVP", "MNF"])
+def test_dense_flows_deferred_r_part_bitwise(bnn, dev, flow, monkeypatch):
+    """The fused no-grad forward of a net with dense flows runs the r flow + the flows' scalars on a side stream beside the weight
+    pass and the first GEMM, and the KL finalize in the second GEMM's launch (layers._DENSE_DEFER): same outputs, same per-layer
+    KL, same total, bit for bit, as with everything on one stream -- eager and under HIP-graph replay."""
+    from bnn_amd import layers, ops
+    torch.manual_seed(5)
+    net = bnn.mnf.BayesianNetwork((784, 320, 256, 10), 2, z_flow_type=flow, r_flow_type=flow).to(dev).train()
+    x = torch.rand(160, 784, device=dev)
+    st = ops.RngState.get(dev)
+    res = {}
+    with torch.no_grad():
+        net(x, sample=True); torch.cuda.synchronize()
+        start = st.t[:2].clone()
+        for defer in (False, "always"):
+            monkeypatch.setattr(layers, "_DENSE_DEFER", defer)
+            st.t[:2].copy_(start)
+            outs = []
+            for _ in range(2):
+                o = net(x, sample=True)
+                outs.append((o.clone(), net.kl().clone(), [l.kl.clone() for l in (net.l1, net.l2, net.l3)]))
+            torch.cuda.synchronize()
+            res[defer] = outs
+        for a, b in zip(res[False], res["always"]):
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+            assert all(torch.equal(u, v) for u, v in zip(a[2], b[2]))
+        # the deferred schedule inside a captured graph
+        monkeypatch.setattr(layers, "_DENSE_DEFER", True)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = net(x, sample=True)
+            kl = net.kl()
+        st.t[:2].copy_(start)
+        for k in range(2):
+            g.replay(); torch.cuda.synchronize()
+            assert torch.equal(out, res[False][k][0]) and torch.equal(kl, res[False][k][1]), k
+
+
 @pytest.mark.parametrize("flow", ["Planar", "RNVP"])
 @pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
 def test_hip_graph_replays_equal_the_eager_sequence_bitwise(bnn, dev, flow, prec):
