@@ -112,3 +112,8 @@ def test_new_entry_points_argument_checks(lib):
     assert lib.lbbnn_flow_dense_save_size(1200, 2, 2) == 1200 * (2 * 3 + 2) + 4 * 2 * 4 * 128
     assert lib.lbbnn_flow_dense_save_size(0, 2, 2) == 0
     assert lib.lbbnn_mnf_flow_dense_backward_workspace(1200) == 2 * 1200 + 2 * 75 * 128 + 2 * 128
+    # round 2: the dense flows in two phases (0 = all, 1 = draws + z flow, 2 = r flow + scalars)
+    assert lib.lbbnn_layers_dense_flows_phase((_lib.DenseLayer * 1)(), 1, None, 3, None) == -4
+    assert lib.lbbnn_layers_dense_flows_phase((_lib.DenseLayer * 1)(), 1, None, -1, None) == -4
+    assert lib.lbbnn_layers_dense_flows_phase(None, 1, None, 1, None) == -1
+    assert lib.lbbnn_layers_dense_flows_phase((_lib.DenseLayer * 1)(), 0, None, 2, None) == -2
