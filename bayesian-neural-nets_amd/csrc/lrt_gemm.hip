@@ -97,14 +97,14 @@ __device__ __forceinline__ void tile_of_block(int& ox, int& by, int extra_rows =
     ox = t % nx; by = t / nx;
 }
 
-struct EpiCtx { bool ovec; uint64_t seed, offs; };
+struct EpiCtx { bool ovec; uint64_t seed, offs; bool lab_const; };
 
 template <bool MEAN_ONLY>
 __device__ __forceinline__ EpiCtx make_epi_ctx(const GemmArgs& a) {
     EpiCtx c;
     c.ovec = ((a.O & 3) == 0) && ((a.ldo & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0) &&
              (!a.eps || (reinterpret_cast<uintptr_t>(a.eps) & 15u) == 0);
-    c.seed = 0; c.offs = 0;
+    c.seed = 0; c.offs = 0; c.lab_const = false;
     if (!MEAN_ONLY && !a.eps) { c.seed = a.rng[0]; c.offs = a.rng[1] + a.m_off; }
     return c;
 }
@@ -147,7 +147,8 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& a, const EpiCtx& c, co
 #ifdef LAB_NO_PHILOX         // tools/lab ablation only: cost of the in-kernel draws in the epilogue
             e[0] = 0.3f; e[1] = -0.7f; e[2] = 1.1f; e[3] = -0.2f;
 #else
-            philox_normal4(c.seed, c.offs, a.rng_stream, (uint64_t)(a.row_offset + b), (uint32_t)(o >> 2), e);
+            if (c.lab_const) { e[0] = 0.3f; e[1] = -0.7f; e[2] = 1.1f; e[3] = -0.2f; }     // LAB_ASYM builds only (never set otherwise)
+            else philox_normal4(c.seed, c.offs, a.rng_stream, (uint64_t)(a.row_offset + b), (uint32_t)(o >> 2), e);
 #endif
         }
     }
@@ -189,8 +190,9 @@ __device__ __forceinline__ void store4_rows(float* p, bool vec, int o, int O, co
 // (tools/gemm_ksweep.py: 16.4 us of a launch did not depend on K).
 template <int TO, int TB, bool MEAN_ONLY>
 __device__ __forceinline__ void epilogue_tile(const GemmArgs& a, int o0, int q, int brow0,
-                                              const floatx4 (&accm)[TO][TB], const floatx4 (&accv)[TO][TB]) {
-    const EpiCtx ec = make_epi_ctx<MEAN_ONLY>(a);
+                                              const floatx4 (&accm)[TO][TB], const floatx4 (&accv)[TO][TB], bool lab_const = false) {
+    EpiCtx ec = make_epi_ctx<MEAN_ONLY>(a);
+    ec.lab_const = lab_const;
     OConst oc[TO];
 #pragma unroll
     for (int i = 0; i < TO; ++i) {
@@ -764,6 +766,21 @@ __device__ __forceinline__ void lrt_gemm_bf16x3_body(const GemmArgs& a_in) {
         }
     };
 
+#ifdef LAB_ASYM          // tools/lab experiment: would it pay to have the second workgroup of a CU draw its noise BEFORE its main loop?
+    // (dispatch is breadth-first: workgroups i and i + 256 share a CU -- tools/gemm_stamps.py).  Role B = linear ids 256..511:
+    // the 10 Philox calls of its tile run here (results folded into one value, kept alive), its epilogue uses constants.
+    const bool lab_role_b = !MEAN_ONLY && a.rng && (((blockIdx.x + gridDim.x * blockIdx.y) >> 8) & 1);
+    float lab_fold = 0.f;
+    if (lab_role_b) {
+        const uint64_t sd = a.rng[0], of = a.rng[1];
+#pragma unroll 1
+        for (int k = 0; k < TO * TB; ++k) {
+            float e4[4];
+            philox_normal4(sd, of, a.rng_stream, (uint64_t)(a.row_offset + b0 + k * 16 + lr), (uint32_t)(o0 + 4 * q + k), e4);
+            lab_fold += e4[0] + e4[1] + e4[2] + e4[3];
+        }
+    }
+#endif
 #ifdef LAB_GEMM_STAMPS
     const int lab_lin = blockIdx.x + gridDim.x * blockIdx.y;
     const bool lab_on = (lab_lin % 32) == 0 && lab_lin / 32 < LAB_ST_SLOTS / 4 && WB == 4 && !MEAN_ONLY;
@@ -805,7 +822,12 @@ __device__ __forceinline__ void lrt_gemm_bf16x3_body(const GemmArgs& a_in) {
 
     GemmArgs ao = a;                                     // split-K: partial product z goes to its own output slab
     if (a.kchunk) ao.out = a.out + (size_t)blockIdx.z * a.split_stride;
+#ifdef LAB_ASYM
+    if (lab_fold == 123.456f) ao.out[0] = lab_fold;
+    epilogue_tile<TO, TB, MEAN_ONLY>(ao, o0, q, b0 + wv * TB * 16 + lr, accm, accv, lab_role_b);
+#else
     epilogue_tile<TO, TB, MEAN_ONLY>(ao, o0, q, b0 + wv * TB * 16 + lr, accm, accv);
+#endif
 #ifdef LAB_GEMM_STAMPS
     if (lab_on && lane == 0) {
         uint32_t hwid, xcc;
