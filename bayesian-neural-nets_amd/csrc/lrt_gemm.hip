@@ -147,8 +147,10 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& a, const EpiCtx& c, co
 #ifdef LAB_NO_PHILOX         // tools/lab ablation only: cost of the in-kernel draws in the epilogue
             e[0] = 0.3f; e[1] = -0.7f; e[2] = 1.1f; e[3] = -0.2f;
 #else
-            if (c.lab_const) { e[0] = 0.3f; e[1] = -0.7f; e[2] = 1.1f; e[3] = -0.2f; }     // LAB_ASYM builds only (never set otherwise)
-            else philox_normal4(c.seed, c.offs, a.rng_stream, (uint64_t)(a.row_offset + b), (uint32_t)(o >> 2), e);
+#ifdef LAB_ASYM
+            if (c.lab_const) { e[0] = 0.3f; e[1] = -0.7f; e[2] = 1.1f; e[3] = -0.2f; } else
+#endif
+            philox_normal4(c.seed, c.offs, a.rng_stream, (uint64_t)(a.row_offset + b), (uint32_t)(o >> 2), e);
 #endif
         }
     }
