@@ -364,15 +364,21 @@ def forward_leg(args, bnn_amd, ops, net, x, sync, precision, world):
             step()
         sync()
         run = step
+        leg["graph"], leg["graph_fallback_reason"] = False, None
         if args.graph:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out, kl = step()
-            run = graph.replay
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    out, kl = step()
+                run = graph.replay
+                leg["graph"] = True
+            except Exception as exc:       # a capture that fails (e.g. a communicator's watchdog touching the device) must not
+                sync()                     # cost the run: the leg is launched from Python instead, and says so
+                leg["graph_fallback_reason"] = "%s: %s" % (type(exc).__name__, str(exc)[:200])
         leg["settle"] = settle(run, world)
         leg["attempts"] = []
         elapsed, per_step = timed_region(run, args.steps, sync, not args.no_step_events, leg["attempts"], world)
-        if not args.graph:
+        if not leg["graph"]:
             out, kl = step()
         sync()
         assert torch.isfinite(out).all() and torch.isfinite(kl)
@@ -514,7 +520,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16x3 split of f32 operands, f32 accumulate" if args.precision == "bf16x3" else "f32",
-            "data": "synthetic", "hip_graph": bool(args.graph),
+            "data": "synthetic", "hip_graph": bool(main_leg["graph"]), "hip_graph_fallback_reason": main_leg["graph_fallback_reason"],
             "config": {"workload": "LBBNN-GP-MF-MNF 784-1200-1200-10, 2 planar flows/layer, batch %d per GPU, "
                                    "training-mode ELBO forward (activations + log_softmax + kl), in-kernel Philox noise" % B,
                        "global_batch": B * world, "parallelism": "dp%d (replicated parameters, no forward collective)" % world},
