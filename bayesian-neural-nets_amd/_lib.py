@@ -246,7 +246,29 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = l
+    if RECORD is not None:
+        return _Recorder(_lib)
     return _lib
+
+
+# graphs.LaunchPlan: while RECORD is a list, every C call made through lib() is appended to it as (function, arguments) -- the
+# arguments are what ctypes was given (ints, None, ctypes arrays / structs: the latter stay alive with the record)
+RECORD = None
+
+
+class _Recorder:
+    def __init__(self, l):
+        self._l = l
+
+    def __getattr__(self, name):
+        fn = getattr(self._l, name)
+
+        def call(*args):
+            # only what ENQUEUES is recorded: every such entry point ends in `void* stream`; the size / version helpers do not
+            if RECORD is not None and fn.argtypes and fn.argtypes[-1] is ctypes.c_void_p:
+                RECORD.append((name, fn, args))
+            return fn(*args)
+        return call
 
 
 def check(rc, what):

@@ -593,7 +593,7 @@ class LRTBayesianLinear(_BayesLinearBase):
         ops.kl_finalize(ws.kl_rows, self.bias_mu, self.bias_rho, priors=self.priors, kl_layer=kl_layer,
                         kl_out=kl_total, accumulate=accumulate)
 
-    def _gemm(self, x, cfg, rng, log_softmax=False, std_out=None, finalize=None):
+    def _gemm(self, x, cfg, rng, log_softmax=False, std_out=None, finalize=None, out=None):
         stochastic, _, relu = cfg
         ws = self._workspace()
         eps = (self.noise or {}).get("eps_out")
@@ -601,7 +601,7 @@ class LRTBayesianLinear(_BayesLinearBase):
                             bias_mean=self.bias_mu, bias_var=ws.bias_var, eps=eps, rng=rng,
                             rng_stream=ops.STREAM_EPS_OUT * 64 + self._layer_id, row_offset=self.row_offset,
                             relu=relu, mean_only=not stochastic, log_softmax=log_softmax, split=self._split_now,
-                            std_out=std_out, finalize=finalize)
+                            std_out=std_out, finalize=finalize, out=out)
 
     def _noise_for_backward(self, saved, B, need_out=True):
         if saved.get("noise") and "eps_out" in saved["noise"]:
@@ -896,14 +896,14 @@ class MNFBayesianLinear(_BayesLinearBase):
                         r0_b1=self.r0_b1, r0_b2=self.r0_b2, scal=ws.scal, rng=rng,
                         layer_id=self._layer_id, kl_layer=kl_layer, kl_out=kl_total, accumulate=accumulate)
 
-    def _gemm(self, x, cfg, rng, log_softmax=False, std_out=None, finalize=None):
+    def _gemm(self, x, cfg, rng, log_softmax=False, std_out=None, finalize=None, out=None):
         stochastic, _, relu = cfg
         ws = self._workspace()
         return ops.lrt_gemm(x, ws.e_w, ws.var_w, I=self.in_features, O=self.out_features,
                             bias_mean=self.bias_mu, bias_var=ws.bias_var, eps=(self.noise or {}).get("eps_out"),
                             rng=rng, rng_stream=ops.STREAM_EPS_OUT * 64 + self._layer_id,
                             row_offset=self.row_offset, relu=relu, mean_only=not stochastic,
-                            log_softmax=log_softmax, split=self._split_now, std_out=std_out, finalize=finalize)
+                            log_softmax=log_softmax, split=self._split_now, std_out=std_out, finalize=finalize, out=out)
 
     def _noise_for_backward(self, saved, B, need_out=True):
         masks = saved.get("masks") or {}
@@ -1117,9 +1117,16 @@ class _NetworkBase(nn.Module):
             st = ops.RngState.get(dev)
         rng = st.t if st is not None else None
         want_kl = any(c[1] for c in cfgs)
-        kls = torch.empty(n + 1, dtype=torch.float32, device=dev) if want_kl else None
+        # graphs.LaunchPlan records this forward into buffers of its own (kls, the layers' outputs) and keeps `keep` alive
+        plan = getattr(self, "_plan_rec", None)
+        if plan is not None and want_kl:
+            kls = plan.setdefault("kls", torch.empty(n + 1, dtype=torch.float32, device=dev))
+        else:
+            kls = torch.empty(n + 1, dtype=torch.float32, device=dev) if want_kl else None
         descs = (_lib.LayerDesc * n)()
         keep = []
+        if plan is not None:
+            plan["keep"] = keep
         for i, (l, c) in enumerate(zip(layers, cfgs)):
             # activations produced by our own GEMMs are dense 16-B aligned rows; the network input is checked
             l._split_now = l._split(x if i == 0 else None) and (i == 0 or layers[i - 1].out_features % 4 == 0)
@@ -1196,7 +1203,10 @@ class _NetworkBase(nn.Module):
                 fin = (descs if want_kl else None, n if want_kl else 0, snap.data_ptr() if snap is not None else None,
                        kls[n:].data_ptr() if all_kl else None, rng.data_ptr() if rng is not None else None,
                        1 if rng is not None else 0)
-            x = l._gemm(x, c, snap, log_softmax=(i == n - 1 and l.out_features <= 16), finalize=fin)
+            obuf = None
+            if plan is not None:
+                obuf = plan.setdefault("out%d" % i, torch.empty(x.shape[0], l.out_features, dtype=torch.float32, device=dev))
+            x = l._gemm(x, c, snap, log_softmax=(i == n - 1 and l.out_features <= 16), finalize=fin, out=obuf)
         if layers[-1].out_features > 16:
             x = F.log_softmax(x, dim=1)
         for i, (l, c) in enumerate(zip(layers, cfgs)):

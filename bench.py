@@ -27,9 +27,10 @@ How the number is taken (round 2; the round-1 line did not reproduce under the d
      launch stream ("roofline", sampled_in = "separate pass after the timed region").  A roofline
      that contradicts the timed region (share of step > 1, launch longer than a step) is not
      printed: "roofline_invalid" carries the reason instead.
-     A step is ONE HIP-graph replay of the forward captured after the warm-up (--eager: the five
-     launches issued from Python each step); the noise is fresh on every replay -- the Philox
-     offset lives on the device and is advanced by the forward's own kernels.
+     A step is one call of a RECORDED LAUNCH PLAN (bnn_amd.graphs.LaunchPlan: the forward's C calls
+     -- 4 calls, 5 kernels -- recorded once after the warm-up and made again from a list; --graph:
+     one HIP-graph replay; --eager: the launches issued from Python each step); the noise is fresh
+     on every call -- the Philox offset lives on the device and is advanced by the forward's kernels.
   4. the same three stages again with the exact-fp32 MFMA GEMM ("secondary": reference precision).
   4b. at N > 1: the strong-scaling form (the same 4096 rows split N ways) as "secondary_strong".
   5. with --train (default at N > 1): the full data-parallel training step (forward, backward,
@@ -79,13 +80,16 @@ def parse():
     ap.add_argument("--train", dest="train", action="store_true", default=None,
                     help="also time the data-parallel training step (default: only when N > 1)")
     ap.add_argument("--no-train", dest="train", action="store_false")
-    ap.add_argument("--graph", dest="graph", action="store_true", default=True,
-                    help="(default) capture one forward in a HIP graph after the warm-up and replay it: one host call per step, "
-                         "so a short timed region is not at the mercy of the host's launch jitter; fresh Philox noise on every "
-                         "replay (the offset lives on the device)")
-    ap.add_argument("--eager", dest="graph", action="store_false",
-                    help="launch every step from Python instead (5 launches per forward, ~100 us of host time against ~165 us "
-                         "of GPU time: 1-3 %% faster than replay in a long run, 0-8 %% slower in a 20-step region)")
+    ap.add_argument("--plan", dest="launch", action="store_const", const="plan", default="plan",
+                    help="(default) a step = bnn_amd.graphs.LaunchPlan: the forward's 4 C calls (5 kernels) recorded once after "
+                         "the warm-up and replayed from a list -- the eager launches without the Python between them (~30 us of "
+                         "host time per step instead of ~100), fresh Philox noise on every call (the offset lives on the device)")
+    ap.add_argument("--graph", dest="launch", action="store_const", const="graph",
+                    help="a step = one replay of the forward captured in a HIP graph (~6 us per replay slower than the plan on "
+                         "this stack: the gap between two graph launches)")
+    ap.add_argument("--eager", dest="launch", action="store_const", const="eager",
+                    help="launch every step from Python (~100 us of host time against ~165 us of GPU time: as fast as the plan in "
+                         "a long run, 0-8 %% slower in a 20-step region that starts from an idle queue)")
     ap.add_argument("--precision", choices=("bf16x3", "fp32"), default="bf16x3",
                     help="GEMM arithmetic of the headline leg: bf16x3 = split-precision products on the bf16 matrix cores "
                          "with fp32 accumulation (measured 3e-6 relative on layer outputs, contract 1e-4); fp32 = exact "
@@ -364,21 +368,28 @@ def forward_leg(args, bnn_amd, ops, net, x, sync, precision, world):
             step()
         sync()
         run = step
-        leg["graph"], leg["graph_fallback_reason"] = False, None
-        if args.graph:
-            try:
+        leg["launch"], leg["launch_fallback_reason"] = "eager", None
+        try:
+            if args.launch == "plan":
+                from bnn_amd import graphs
+                plan = graphs.LaunchPlan(net, x, sample=True)
+                out, kl = plan.out, plan.kl
+                run = plan
+                leg["launch"] = "plan"
+            elif args.launch == "graph":
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     out, kl = step()
                 run = graph.replay
-                leg["graph"] = True
-            except Exception as exc:       # a capture that fails (e.g. a communicator's watchdog touching the device) must not
-                sync()                     # cost the run: the leg is launched from Python instead, and says so
-                leg["graph_fallback_reason"] = "%s: %s" % (type(exc).__name__, str(exc)[:200])
+                leg["launch"] = "graph"
+        except Exception as exc:           # a recording / capture that fails (e.g. a communicator's watchdog touching the device
+            sync()                         # during a capture) must not cost the run: the leg is launched from Python, and says so
+            run = step
+            leg["launch_fallback_reason"] = "%s: %s" % (type(exc).__name__, str(exc)[:200])
         leg["settle"] = settle(run, world)
         leg["attempts"] = []
         elapsed, per_step = timed_region(run, args.steps, sync, not args.no_step_events, leg["attempts"], world)
-        if not leg["graph"]:
+        if leg["launch"] == "eager":
             out, kl = step()
         sync()
         assert torch.isfinite(out).all() and torch.isfinite(kl)
@@ -520,7 +531,10 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16x3 split of f32 operands, f32 accumulate" if args.precision == "bf16x3" else "f32",
-            "data": "synthetic", "hip_graph": bool(main_leg["graph"]), "hip_graph_fallback_reason": main_leg["graph_fallback_reason"],
+            "data": "synthetic", "hip_graph": main_leg["launch"] == "graph",
+            "launch": {"plan": "recorded launch plan (bnn_amd.graphs.LaunchPlan: the forward's 4 C calls = 5 kernels, replayed from a list)",
+                       "graph": "one HIP-graph replay per step", "eager": "5 launches per step from Python"}[main_leg["launch"]],
+            "launch_fallback_reason": main_leg["launch_fallback_reason"],
             "config": {"workload": "LBBNN-GP-MF-MNF 784-1200-1200-10, 2 planar flows/layer, batch %d per GPU, "
                                    "training-mode ELBO forward (activations + log_softmax + kl), in-kernel Philox noise" % B,
                        "global_batch": B * world, "parallelism": "dp%d (replicated parameters, no forward collective)" % world},
