@@ -176,6 +176,9 @@ __device__ __forceinline__ void load4_rows(const float* p, bool vec, int o, int 
 }
 
 __device__ __forceinline__ void store4_rows(float* p, bool vec, int o, int O, const float v[4]) {
+#ifdef LAB_NO_STORE          // tools/lab ablation only: what the output stores cost a launch (kept alive by an impossible condition)
+    if (v[0] != 123456.789f) return;
+#endif
     if (vec) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
     else {
 #pragma unroll
