@@ -583,6 +583,9 @@ __device__ uint32_t lab_gemm_stamps[LAB_ST_SLOTS * LAB_ST_STEPS * LAB_ST_PH];
 template <int TO, int TB, int WB, bool MEAN_ONLY, int NP, bool F16>
 __device__ __forceinline__ void lrt_gemm_bf16x3_body(const GemmArgs& a_in) {
     static_assert(!F16 || NP == 1, "fp16 operands exist in the single-product form only");
+#ifdef LAB_EMPTY             // tools/lab ablation only: the launch itself (dispatch of the grid with its LDS / register footprint), no work
+    if (a_in.B > 0) return;
+#endif
     const GemmArgs a = member_view(a_in);
     constexpr int BN = TO * 16, BM = TB * WB * 16;
     constexpr int NWR = MEAN_ONLY ? 1 : 2;               // weight regions: e_w (, var_w); a row = [hi 64 B | lo 64 B]
