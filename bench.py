@@ -342,6 +342,9 @@ def roofline_object(events, precision, ms_per_step, sampled_in):
                        else "lrt_gemm_f32_dma_kernel<5,2,4>") + " (dual-moment GEMM, 80x128 tile)",
             "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
             "traffic": traffic, "traffic_unit": "HBM-side bytes per launch", "traffic_source": traffic_src,
+            "traffic_note": "FETCH_SIZE x2 + WRITE_SIZE = what the 8 private L2s request from the fabric (Infinity-Cache hits included); "
+                            "the structural minimum for 8 L2s is 85.4 MB fetched + 19.7 MB written at the 1200x1200 layer "
+                            "(4 x 2 XCD ownership of the tile grid, DESIGN.md 7.4), the algorithmic 45.5 MB would need one shared L2",
             "executed_mfma_tflops": ach * (3.0 if split else 1.0),
             "note": ("achieved = ALGORITHMIC 4*B*I*O flop per launch / HIP-event time; the bf16x3 path executes 3 bf16 "
                      "products per algorithmic product") if split else
