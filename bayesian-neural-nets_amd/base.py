@@ -56,6 +56,8 @@ class _BaseFn(torch.autograd.Function):
     def forward(ctx, layer, x, cgamma, tau_w, tau_b, galpha, cfg, *params):
         out, lp, lq, saved = layer._forward_hip(x, cgamma, tau_w, tau_b, cfg, save_rng=True)
         ctx.layer, ctx.cfg, ctx.saved = layer, cfg, saved
+        from . import graphs
+        graphs.mark_autograd_node(ctx, layer)          # capture guard: graphs.assert_no_live_graph
         ctx.save_for_backward(x, tau_w, tau_b, *params)
         z = out.new_zeros(())
         return out, (lp if lp is not None else z), (lq if lq is not None else z)

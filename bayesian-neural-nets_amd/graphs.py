@@ -6,7 +6,66 @@ headline net issues ~85 launches and is host-bound at ~2.3 ms; replayed from a g
 DESIGN.md section 9).  Noise stays fresh across replays because the Philox {seed, offset} pair lives in device memory and
 is advanced by a kernel inside the graph.
 """
+import weakref
+
 import torch
+
+
+# ---- capture guard -------------------------------------------------------------------------------------------------
+# Every autograd node this package creates (layers._BayesLinearFn, base._BaseFn, vd._VDFn) carries a _NodeMark; the
+# mark lives exactly as long as the node, i.e. as long as something (a loss, an output) still holds the graph the
+# node is part of -- and with it the AccumulateGrad nodes of the layer's parameters, which remember the stream they
+# were created on.  A stream capture that runs a backward pass through such an old AccumulateGrad node makes autograd
+# synchronise the capture stream with that node's stream; HIP does not survive it (measured in round 2: a segmentation
+# fault inside capture_end, gpurun_out/r02/dpgraph.log).  The factories below therefore refuse to start while a graph
+# through the network is alive, instead of crashing the process.
+_MARKS = weakref.WeakSet()
+
+
+class _NodeMark:
+    __slots__ = ("owner", "stream", "capturing", "__weakref__")
+
+
+def mark_autograd_node(ctx, owner):
+    """Called from the forward of every autograd.Function of this package: ``ctx`` is the graph node being built."""
+    m = _NodeMark()
+    m.owner = weakref.ref(owner)
+    m.capturing = torch.cuda.is_current_stream_capturing()
+    m.stream = torch.cuda.current_stream(owner_device(owner)).cuda_stream
+    ctx._lbbnn_mark = m
+    _MARKS.add(m)
+
+
+def owner_device(mod):
+    p = next(iter(mod.parameters()), None)
+    return p.device if (p is not None and p.is_cuda) else None
+
+
+def live_autograd_nodes(net):
+    """[(module class name, stream handle)] for the autograd nodes through ``net``'s layers that are still alive."""
+    mods = {id(m) for m in net.modules()}
+    out = []
+    for m in list(_MARKS):
+        o = m.owner()
+        if o is not None and id(o) in mods and not m.capturing:
+            out.append((type(o).__name__, m.stream))
+    return out
+
+
+def assert_no_live_graph(net, who):
+    """Raise (instead of letting the capture crash the process) when an autograd graph through ``net`` is still alive."""
+    import gc
+    if live_autograd_nodes(net):
+        gc.collect()                                   # a graph kept alive by a reference cycle only is not the caller's fault
+    live = live_autograd_nodes(net)
+    if live:
+        on_default = sum(1 for _, s in live if s == 0)
+        raise RuntimeError(
+            "bnn_amd.%s: %d autograd node(s) of an earlier forward through this network are still alive (%d created on the "
+            "default stream; layers: %s).  Their AccumulateGrad nodes would be synchronised inside the stream capture, which "
+            "HIP does not survive (segmentation fault in capture_end).  Drop the tensors that hold that graph (`del loss, "
+            "out`) or build the graphed step before the first eager training step."
+            % (who, len(live), on_default, ", ".join(sorted({n for n, _ in live}))))
 
 
 def make_graphed_train_step(net, optimizer, loss_fn, example_x, example_y, warmup: int = 3, overlap_vector_backward=None):
@@ -26,6 +85,7 @@ def make_graphed_train_step(net, optimizer, loss_fn, example_x, example_y, warmu
         env = os.environ.get("LBBNN_BWD_OVERLAP")
         overlap_vector_backward = env != "0"
     ov = layers.vector_backward_overlap if overlap_vector_backward else contextlib.nullcontext
+    assert_no_live_graph(net, "graphs.make_graphed_train_step")
     dev = example_x.device
     static_x, static_y = example_x.clone(), example_y.clone()
     side = torch.cuda.Stream(device=dev)

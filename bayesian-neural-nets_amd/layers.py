@@ -189,6 +189,8 @@ class _BayesLinearFn(torch.autograd.Function):
             if cfg[1]:
                 saved["act_mu"], saved["act_var"], saved["z_kl"], saved["scal"] = ws.act_mu, ws.act_var, ws.z_kl, ws.scal
         ctx.layer, ctx.cfg, ctx.saved = layer, cfg, saved
+        from . import graphs
+        graphs.mark_autograd_node(ctx, layer)          # capture guard: graphs.assert_no_live_graph
         # how many autograd nodes of this layer are alive: the deferral of its vector chain needs exactly one
         live = layer.__dict__.setdefault("_live_nodes", weakref.WeakSet())
         ctx.token = _NodeToken()

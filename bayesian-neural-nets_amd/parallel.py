@@ -41,6 +41,10 @@ class GradBucket:
         self.mode = os.environ.get("LBBNN_DP_COLLECTIVE", "all_reduce")
         if self.mode not in ("all_reduce", "rs_ag"):
             raise ValueError("LBBNN_DP_COLLECTIVE must be 'all_reduce' or 'rs_ag'")
+        # LBBNN_DP_FORCE_COLLECTIVE=1: issue the collective at world size 1 too (a SUM over one rank is the identity).  It
+        # exists so that the RCCL calls of this module run on a 1-GPU box: tests/test_parity_gpu.py holds the forced step
+        # to the unforced one bit for bit
+        self.force = os.environ.get("LBBNN_DP_FORCE_COLLECTIVE", "0") == "1"
         self.last = None
 
     def _slices(self):
@@ -94,11 +98,14 @@ class GradBucket:
             else:
                 p.grad.copy_(g)
 
-    def all_reduce(self, group=None, unpack: bool = True):
-        """pack -> all_reduce(SUM) -> unpack.  ``unpack=False`` leaves the reduced gradients in the flat buffer only
-        (use ``views()`` with ``bnn_amd.optim.Adam.step(grads=...)``)."""
-        self.pack()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    def wants_collective(self, group=None) -> bool:
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return dist.get_world_size(group) > 1 or self.force
+
+    def collective(self, group=None):
+        """The exchange itself, on the flat buffer as it stands (no pack / unpack): SUM over the ranks of `group`."""
+        if self.wants_collective(group):
             world = dist.get_world_size(group)
             if self.mode == "rs_ag" and self.padded % world == 0:
                 # xGMI is a full point-to-point mesh: reduce-scatter + all-gather moves 1/world of the bucket per peer
@@ -111,6 +118,14 @@ class GradBucket:
             else:
                 dist.all_reduce(self._store, op=dist.ReduceOp.SUM, group=group)
                 self.last = "all_reduce (%d B)" % (self._store.numel() * 4)
+            return True
+        return False
+
+    def all_reduce(self, group=None, unpack: bool = True):
+        """pack -> all_reduce(SUM) -> unpack.  ``unpack=False`` leaves the reduced gradients in the flat buffer only
+        (use ``views()`` with ``bnn_amd.optim.Adam.step(grads=...)``)."""
+        self.pack()
+        self.collective(group)
         if unpack:
             self.unpack()
 
@@ -131,7 +146,8 @@ class DataParallelELBO:
         self.world = dist.get_world_size(group) if on else 1
         self.rank = dist.get_rank(group) if on else 0
         self.bucket = GradBucket(net.parameters())
-        if self.world > 1:
+        self._exchange = on and (self.world > 1 or self.bucket.force)
+        if self._exchange:
             # replicas must start identical: broadcast rank 0's parameters once
             for p in net.parameters():
                 dist.broadcast(p.data, src=0, group=group)
@@ -143,7 +159,7 @@ class DataParallelELBO:
         is broadcast here (construction) and may be re-broadcast by the caller after rank-local work that drew noise on
         some ranks only (an evaluation pass on rank 0)."""
         p0 = next(iter(self.net.parameters()), None)
-        if self.world > 1 and p0 is not None and p0.is_cuda:
+        if self._exchange and p0 is not None and p0.is_cuda:
             from . import ops
             st = ops.RngState.get(p0.device)
             live = st.t[:2].clone()
@@ -166,12 +182,13 @@ class DataParallelELBO:
         in principle, but a capture that misbehaves would hang all N ranks, and an N-GPU node is not available to the
         build to test it on -- between two graphs the collective is the plain, well-trodden ``dist.all_reduce``.
         ``optimizer`` must be capture-safe (``bnn_amd.optim.Adam``).  Returns step(x, y) -> loss (a static tensor).
-        Call it before any eager training step of the same network whose autograd graph is still alive: the parameters'
-        AccumulateGrad nodes remember the stream they were created on, and a node created on the default stream makes
-        autograd synchronise the capture stream with the default stream -- which a HIP stream capture does not survive
-        (measured: a segmentation fault in capture_end)."""
-        import contextlib
-        from . import layers
+        Raises RuntimeError while an autograd graph of an earlier forward through the network is still alive (a loss or
+        an output of an eager step that has not been dropped): the parameters' AccumulateGrad nodes remember the stream
+        they were created on, and a node created on the default stream makes autograd synchronise the capture stream
+        with the default stream -- which a HIP stream capture does not survive (round 2: a segmentation fault in
+        capture_end).  ``graphs.assert_no_live_graph`` is the check."""
+        from . import graphs, layers
+        graphs.assert_no_live_graph(self.net, "parallel.DataParallelELBO.make_graphed_step")
         net, dev = self.net, example_x.device
         ov = layers.vector_backward_overlap
         static_x, static_y = example_x.clone(), example_y.clone()
@@ -189,8 +206,7 @@ class DataParallelELBO:
         with torch.cuda.stream(side):
             for _ in range(warmup):
                 fwd_bwd()
-                if self.world > 1:
-                    dist.all_reduce(self.bucket._store, op=dist.ReduceOp.SUM, group=self.group)
+                self.bucket.collective(self.group)
                 optimizer.step(grads=self.reduced_grads())
         torch.cuda.current_stream(dev).wait_stream(side)
         _quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
@@ -204,14 +220,14 @@ class DataParallelELBO:
             optimizer.step(grads=self.reduced_grads())
         if _quiet is not None:
             _quiet(True)
-        self.bucket.last = ("all_reduce (%d B) between two HIP graphs" % (self.bucket._store.numel() * 4)) if self.world > 1 else None
+        if self.bucket.last:
+            self.bucket.last += " between two HIP graphs"
 
         def step(x, y):
             static_x.copy_(x)
             static_y.copy_(y)
             g_a.replay()
-            if self.world > 1:
-                dist.all_reduce(self.bucket._store, op=dist.ReduceOp.SUM, group=self.group)
+            self.bucket.collective(self.group)
             g_b.replay()
             return static_loss
 

@@ -26,6 +26,8 @@ class _VDFn(torch.autograd.Function):
         std = torch.empty((x.shape[0], layer.m), dtype=torch.float32, device=x.device)
         out, zeta_src = layer._forward_hip(x, save_rng=True, std_out=std)
         ctx.layer, ctx.zeta_src = layer, zeta_src
+        from . import graphs
+        graphs.mark_autograd_node(ctx, layer)          # capture guard: graphs.assert_no_live_graph
         ctx.save_for_backward(x, theta, alpha, std)
         return out
 

@@ -461,19 +461,133 @@ def train_leg(args, bnn_amd, net, x, sync, world, rank):
     return res
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def rank_env(base_env, rank, world, port):
+    """Environment of child rank ``rank``: what torch.distributed.run would have set (one rank per GPU of ONE node)."""
+    env = dict(base_env)
+    env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "LBBNN_BENCH_CHILD": "1"})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
+    return env
+
+
+def spawn_ranks(n, argv=None, script=None, env=None, timeout=None, popen=None):
+    """`python bench.py --gpus N` WITHOUT a launcher: this process starts the N ranks itself -- N fresh children of the same
+    script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set -- and never touches a GPU (no HIP call has been made when this
+    runs, and none is made here: a process that has initialised the GPU must not be replaced or forked from on this pool).
+    Rank 0's stdout (the ONE JSON line) is relayed to this process's stdout as it comes; every child's stderr goes to this
+    process's stderr.  Returns the worst child return code (a rank killed by a signal counts as 128 + signal); when one rank
+    fails the others are terminated -- they would otherwise wait in a collective until its timeout."""
+    import subprocess
+    popen = popen or subprocess.Popen
+    script = script or os.path.abspath(__file__)
+    argv = list(sys.argv[1:] if argv is None else argv)
+    port = int(os.environ.get("MASTER_PORT", "0")) or _free_port()
+    base = dict(os.environ if env is None else env)
+    procs = []
+    for r in range(n):
+        procs.append(popen([sys.executable, script] + argv, env=rank_env(base, r, n, port),
+                           stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None))
+    t_end = None if timeout is None else time.monotonic() + timeout
+    worst, done = 0, [False] * n
+    out0 = procs[0].stdout
+
+    def _rc(p):
+        rc = p.returncode
+        return 128 - rc if rc < 0 else rc
+
+    import threading
+    lines = []
+
+    def _relay():
+        for raw in iter(out0.readline, b""):
+            line = raw.decode(errors="replace")
+            lines.append(line)
+            sys.stdout.write(line)
+            sys.stdout.flush()
+
+    th = threading.Thread(target=_relay, daemon=True)
+    if out0 is not None:
+        th.start()
+    failed = False
+    while not all(done):
+        for i, p in enumerate(procs):
+            if not done[i] and p.poll() is not None:
+                done[i] = True
+                worst = max(worst, _rc(p))
+                failed = failed or p.returncode != 0
+        if failed or (t_end is not None and time.monotonic() > t_end):
+            for i, p in enumerate(procs):               # exact PIDs this process started, nothing by pattern
+                if not done[i]:
+                    p.terminate()
+            for i, p in enumerate(procs):
+                if not done[i]:
+                    try:
+                        p.wait(timeout=20)
+                    except Exception:                    # noqa: BLE001
+                        p.kill()
+                        p.wait()
+                    done[i] = True
+                    worst = max(worst, _rc(p) or 1)
+            if not failed:
+                worst = max(worst, 124)
+            break
+        time.sleep(0.05)
+    if out0 is not None:
+        th.join(timeout=10)
+    return worst
+
+
+def ranks_report(world, rank, backend, dev_index):
+    """Who actually ran: world size and backend as torch.distributed reports them, and every rank's device (index, name,
+    gcn arch, PCI bus id, uuid) all-gathered -- N DISTINCT bus ids / uuids are what shows that N GPUs took part."""
+    pr = torch.cuda.get_device_properties(dev_index)
+    mine = {"rank": rank, "pid": os.getpid(), "device_index": dev_index, "name": pr.name,
+            "arch": getattr(pr, "gcnArchName", None),
+            "pci": "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0)),
+            "uuid": str(getattr(pr, "uuid", ""))}
+    if world > 1:
+        import torch.distributed as dist
+        devs = [None] * world
+        dist.all_gather_object(devs, mine)
+        probe = torch.ones(1, device="cuda")
+        dist.all_reduce(probe)                       # one collective on the data-path backend: counts the ranks it reached
+        return {"world": dist.get_world_size(), "backend": dist.get_backend(), "devices": devs,
+                "distinct_devices": len({d["uuid"] or d["pci"] for d in devs}),
+                "all_reduce_of_ones": float(probe.item()), "launcher": os.environ.get("LBBNN_BENCH_CHILD") and "self-spawned" or "external"}
+    return {"world": 1, "backend": None, "devices": [mine], "distinct_devices": 1, "launcher": "single process"}
+
+
+def pick_backend(world, ndev):
+    """nccl (= RCCL) with one rank per GPU is the form the metric is defined on.  LBBNN_BENCH_BACKEND overrides; without
+    it a box with FEWER devices than ranks falls back to gloo with ranks sharing cards (a rehearsal of the N-rank flow --
+    RCCL refuses two ranks on one device); the JSON line says which (`ranks.backend`, `ranks.devices`)."""
+    forced = os.environ.get("LBBNN_BENCH_BACKEND")
+    if forced:
+        return forced
+    return "nccl" if (world <= 1 or ndev >= world) else "gloo"
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: start the ranks ourselves (before anything in this process touches the GPU)
+        raise SystemExit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: one rank per GPU (run it without a launcher and "
+                         "it starts its own ranks)" % (args.gpus, world))
     import torch.distributed as dist
-    # LBBNN_BENCH_BACKEND=gloo + fewer devices than ranks: rehearsal of the N-rank flow on a 1-GPU box (ranks share the
-    # card); the driver's runs use nccl (= RCCL) with one rank per GPU
-    backend = os.environ.get("LBBNN_BENCH_BACKEND", "nccl")
     ndev = torch.cuda.device_count()
+    backend = pick_backend(world, ndev)
     dev_index = local_rank if (backend == "nccl" or local_rank < ndev) else local_rank % max(ndev, 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -489,6 +603,8 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=backend)
+
+    ranks = ranks_report(world, rank, backend, dev_index)
 
     import bnn_amd
     from bnn_amd import ops
@@ -543,6 +659,7 @@ def main():
                        "global_batch": B * world, "parallelism": "dp%d (replicated parameters, no forward collective)" % world},
             "gflop_per_step_algorithmic": 4.0 * B * sum_io / 1e9,
             "settle": main_leg["settle"], "timed_attempts": main_leg["attempts"],
+            "ranks": ranks,
         }
         step_stats(res, main_leg["per_step"])
         if main_leg["events"]:
