@@ -52,9 +52,27 @@ def live_autograd_nodes(net):
     return out
 
 
+def release_module_graph_refs(net):
+    """The modules themselves hold results of the last forward as attributes, as the reference's do (``layer.kl``,
+    ``layer.log_prior`` ...: LBBNN-GP-MF-MNF.py:237, LBBNN-GP-MF.py:246-251) -- tensors with a grad_fn, i.e. references into
+    the last autograd graph.  They are replaced by detached tensors (same values): nothing can call backward through an
+    attribute of a finished step, and they must not keep an eager graph alive under a capture.  Returns how many."""
+    n = 0
+    for mod in net.modules():
+        for name, val in list(vars(mod).items()):
+            if isinstance(val, torch.Tensor) and val.grad_fn is not None:
+                setattr(mod, name, val.detach())
+                n += 1
+    return n
+
+
 def assert_no_live_graph(net, who):
-    """Raise (instead of letting the capture crash the process) when an autograd graph through ``net`` is still alive."""
+    """Raise (instead of letting the capture crash the process) when an autograd graph through ``net`` is still alive.
+    The network's own references into its last graph (``layer.kl`` ...) are detached first; what is left is held by the
+    caller (a loss, an output)."""
     import gc
+    if live_autograd_nodes(net):
+        release_module_graph_refs(net)
     if live_autograd_nodes(net):
         gc.collect()                                   # a graph kept alive by a reference cycle only is not the caller's fault
     live = live_autograd_nodes(net)
@@ -66,6 +84,23 @@ def assert_no_live_graph(net, who):
             "HIP does not survive (segmentation fault in capture_end).  Drop the tensors that hold that graph (`del loss, "
             "out`) or build the graphed step before the first eager training step."
             % (who, len(live), on_default, ", ".join(sorted({n for n, _ in live}))))
+
+
+def capture(graph, **kw):
+    """``torch.cuda.graph(graph, ...)`` with a capture mode that survives a live communicator.  A process that has
+    initialised RCCL runs torch's ProcessGroupNCCL watchdog thread, which polls HIP events of outstanding collectives; under
+    the default GLOBAL capture mode a HIP call from ANY thread that is not legal inside a capture invalidates the capture
+    and raises in that thread -- in the watchdog that is an uncaught exception, the process aborts (seen once in round 3 on
+    a single-rank nccl group: rc -6 before the first replay; a race, most runs pass).  THREAD_LOCAL restricts the check to
+    the capturing thread, which is the only one that issues work into the capture."""
+    if "capture_error_mode" not in kw:
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                kw["capture_error_mode"] = "thread_local"
+        except Exception:                                # noqa: BLE001
+            pass
+    return torch.cuda.graph(graph, **kw)
 
 
 def make_graphed_train_step(net, optimizer, loss_fn, example_x, example_y, warmup: int = 3, overlap_vector_backward=None):
@@ -105,7 +140,7 @@ def make_graphed_train_step(net, optimizer, loss_fn, example_x, example_y, warmu
     _quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
     if _quiet is not None:
         _quiet(False)
-    with torch.cuda.graph(graph):
+    with capture(graph):
         static_loss = loss_fn(net, static_x, static_y)
         with ov():
             static_loss.backward()

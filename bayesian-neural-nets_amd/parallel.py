@@ -214,9 +214,9 @@ class DataParallelELBO:
             _quiet(False)
         g_a, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)
-        with torch.cuda.graph(g_a):
+        with graphs.capture(g_a):
             static_loss = fwd_bwd()
-        with torch.cuda.graph(g_b, pool=g_a.pool()):
+        with graphs.capture(g_b, pool=g_a.pool()):
             optimizer.step(grads=self.reduced_grads())
         if _quiet is not None:
             _quiet(True)

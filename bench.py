@@ -380,8 +380,9 @@ def forward_leg(args, bnn_amd, ops, net, x, sync, precision, world):
                 run = plan
                 leg["launch"] = "plan"
             elif args.launch == "graph":
+                from bnn_amd import graphs
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with graphs.capture(graph):
                     out, kl = step()
                 run = graph.replay
                 leg["launch"] = "graph"
@@ -506,11 +507,14 @@ def spawn_ranks(n, argv=None, script=None, env=None, timeout=None, popen=None):
     lines = []
 
     def _relay():
+        # the JSON line goes to stdout; anything else a library wrote to rank 0's stdout (gloo announces its connections
+        # there) goes to stderr, so that this process's stdout is the ONE line of the contract
         for raw in iter(out0.readline, b""):
             line = raw.decode(errors="replace")
             lines.append(line)
-            sys.stdout.write(line)
-            sys.stdout.flush()
+            dst = sys.stdout if line.lstrip().startswith("{") else sys.stderr
+            dst.write(line)
+            dst.flush()
 
     th = threading.Thread(target=_relay, daemon=True)
     if out0 is not None:
