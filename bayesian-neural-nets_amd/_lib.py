@@ -47,7 +47,18 @@ class LayerDesc(ctypes.Structure):
                 ("eps_z", c_p), ("eps_z2", c_p), ("eps_act", c_p),
                 ("z_fwd", c_p), ("z_kl", c_p), ("scal", c_p), ("e_w", c_p), ("var_w", c_p),
                 ("kl_rows", c_p), ("act_mu", c_p), ("act_var", c_p), ("bias_var", c_p), ("kl_layer", c_p),
-                ("flows_done", c_i)]
+                ("flows_done", c_i), ("e_scale", c_p), ("v_scale", c_p)]
+
+
+class GemmDesc(ctypes.Structure):
+    """lbbnn_gemm_desc_t"""
+    _fields_ = [("x", c_p), ("ldx", c_i), ("e_w", c_p), ("var_w", c_p), ("ld", c_i),
+                ("mean_scale", c_p), ("wvar_scale", c_p), ("bias_mean", c_p), ("bias_var", c_p), ("var_scale", c_p),
+                ("eps", c_p), ("rng", c_p), ("rng_stream", c_u32), ("row_offset", c_i64),
+                ("out", c_p), ("ldo", c_i), ("out_planes", c_p), ("ldp", c_i), ("std_out", c_p),
+                ("B", c_i), ("I", c_i), ("O", c_i), ("flags", c_i),
+                ("layers", ctypes.POINTER(LayerDesc)), ("n_layers", c_i), ("fin_rng", c_p), ("kl_total", c_p),
+                ("rng_live", c_p), ("advance", c_u64)]
 
 
 class DenseTransform(ctypes.Structure):
@@ -162,6 +173,10 @@ SIGNATURES = {
     "lbbnn_operand_ld": (c_i, [c_i]),
     "lbbnn_weight_pass": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.POINTER(Priors),
                                 c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "lbbnn_weight_pass_f16": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.POINTER(Priors),
+                                    c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
+    "lbbnn_lrt_gemm_ex": (c_i, [ctypes.POINTER(GemmDesc), c_p]),
+    "lbbnn_format_x": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_p]),
     "lbbnn_lrt_gemm": (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_u32, c_i64,
                              c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "lbbnn_lrt_gemm_train": (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_u32, c_i64,

@@ -16,7 +16,8 @@ struct WeightPassArgs {
     float* e_w; float* var_w;
     float* kl_rows; float* act_mu; float* act_var; float* bias_var;
     int O, I, ld, vec;
-    int split;      // 1: e_w and var_w are two bf16 planes each, [2][O][ld] (hi, lo); 0: fp32 [O][ld]
+    int split;      // 0: fp32 [O][ld]; 1: bf16 hi | lo units (lbbnn_device.h); 2: fp16 hi | lo units of the row-scaled values
+    float* e_scale; float* v_scale;      // split == 2: (O) inverse row scales written by the row kernel
     float mu_prior, sigma_prior, alpha_prior;
     float log_sp, log_ap, log_1map, inv_2sp2;     // host-precomputed prior constants
 };
@@ -72,7 +73,7 @@ LBBNN_HIDDEN int make_weight_pass_args(WeightPassArgs& a, const float* mu, const
                                        const float* z_fwd, const float* z_kl, const float* r0_c, const float* bias_rho,
                                        const lbbnn_priors_t* priors, void* e_w, void* var_w, int ld,
                                        float* kl_rows, float* act_mu, float* act_var, float* bias_var, int O, int I,
-                                       int split = 0);
+                                       int split = 0, float* e_scale = nullptr, float* v_scale = nullptr);
 LBBNN_HIDDEN int launch_weight_pass(const WeightPassArgs* a, int n, hipStream_t s, uint64_t* rng = nullptr,
                                     uint64_t* rng_snap = nullptr, uint64_t advance = 0, const InFlow* flows = nullptr,
                                     int members = 1);

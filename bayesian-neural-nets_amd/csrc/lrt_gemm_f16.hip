@@ -1,0 +1,468 @@
+// K2'' -- the two activation-moment GEMMs of the local-reparameterisation layer on the FP16 matrix cores of gfx950
+// (v_mfma_f32_16x16x32_f16, fp32 accumulate) with ROW-SCALED hi + lo operands: the LBBNN_F_F16S format of include/lbbnn.h.
+//
+//   mean[b,o] = sum_k x[b,k]   * e_w[o,k]   + bias_mean[o]                   (torch.mm, LBBNN-GP-MF-LRT.py:172; ...MNF.py:197)
+//   var [b,o] = sum_k x[b,k]^2 * var_w[o,k] (*var_scale[o]) + bias_var[o]    (...LRT.py:173; ...MNF.py:198)
+//   out [b,o] = mean + sqrt(var) * eps[b,o]  (+ReLU)                         (...LRT.py:174-175; ...MNF.py:199-200)
+//
+// Why this format (round 3).  The bf16x3 kernel (lrt_gemm.hip) is co-limited by the matrix pipe and by the
+// VALU port: ~112 conversion instructions per wave and K step (x and x^2 split into bf16 hi / lo in registers) beside 60
+// MFMAs that hold the same issue port for 8 of their 16 cycles.  Here
+//   * x arrives ALREADY split -- fp16 hi | lo units in the same 128-B line layout as the weights (LBBNN_F_XPLANES), written
+//     by the previous layer's epilogue or by lbbnn_format_x: no split in the consumer at all; x^2 is formed from the planes by
+//     four packed-fp16 instructions per 2 k (a = xh 2^-4, b = xl 2^-3, s = fma(a, a, a b));
+//   * the variance GEMM takes ONE product (LBBNN_F_VAR1: sh.vh; 4 MFMAs per tile step instead of 6, 15 fragment reads instead
+//     of 20) or the full three (sh.vh + sh.vl + sl.vh);
+//   * fp16 carries 11 significand bits per part against bf16's 8: hi + lo represent an fp32 value to 2^-22, the 3-product
+//     mean to ~3e-8 of max|out| (bf16x3: 2.7e-6), so the 3 + 3 form is tighter than an fp32-accumulate torch.mm and the 3 + 1
+//     form sits at 1.4-1.8e-5 (tools/format_error.py; contract 1e-4).
+// fp16's 5 exponent bits are handled by exact power-of-two scales: one per weight row and operand (mean_scale / wvar_scale,
+// taken out again in the epilogue) and the fixed 2^-8 on x^2.  |x| >= 4096 makes x^2 2^-8 overflow to +inf: the output of
+// such a row is non-finite, never silently saturated (tests/test_f16_gemm.py::test_range_overflow_is_loud).
+//
+// Tile, LDS image, LDS-DMA pieces, swizzle, XCD tile ownership, schedule: those of lrt_gemm_bf16x3_body (lrt_gemm.hip) --
+// 80(o) x 128(b) per 4-wave workgroup, two workgroups per CU, K step 32, one 128-B line per row and step in every region,
+// 1-KiB pieces of 8 rows, slot s of row r stored at s ^ G(r & 15).
+#include <cstdlib>
+#include "lbbnn_device.h"
+#include "lbbnn_internal.h"
+#include "kl_piggy.h"
+#include "gemm_common.h"
+#include "../../include/lbbnn.h"
+
+namespace {
+
+using namespace lbbnn;
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int BKS = 32;
+constexpr float kS2 = 0.00390625f;          // 2^-8: the fixed scale of the x^2 planes
+constexpr float kS2inv = 256.f;
+
+__device__ __forceinline__ int swzx(int r) { return (((r >> 1) & 3) << 1) | ((r >> 3) & 1); }
+
+struct G16Args {
+    const char* x; const char* e_w; const char* var_w;
+    const float* mean_scale; const float* wvar_scale;
+    const float* bias_mean; const float* bias_var; const float* var_scale;
+    const float* eps; const uint64_t* rng;
+    float* out; char* out_planes; float* std_out;
+    long long row_offset;
+    int ldx, ld, ldo, ldp, B, I, O;
+    uint32_t rng_stream;
+    int relu;
+    FinalizePiggy fin;
+};
+
+__device__ __forceinline__ uint32_t cvt_pk_h(float a, float b) {
+    const floatx2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+}
+__device__ __forceinline__ float h_lo(uint32_t p) { return (float)__builtin_bit_cast(f16x2, p)[0]; }
+__device__ __forceinline__ float h_hi(uint32_t p) { return (float)__builtin_bit_cast(f16x2, p)[1]; }
+
+struct OC16 { float bm[4], bv[4], vs[4], ms[4]; };
+
+__device__ __forceinline__ void ld4f(const float* p, int o, int O, float fill, float out[4]) {
+    if (!p) { out[0] = out[1] = out[2] = out[3] = fill; return; }
+    if (o + 3 < O && ((reinterpret_cast<uintptr_t>(p + o) & 15u) == 0)) {
+        const float4 t = *reinterpret_cast<const float4*>(p + o);
+        out[0] = t.x; out[1] = t.y; out[2] = t.z; out[3] = t.w;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[r] = (o + r < O) ? p[o + r] : fill;
+    }
+}
+
+// Epilogue of a wave's TO x TB accumulator tiles (lane: out[b][o .. o+3] of tile (i, j), o = o0 + 16 i + 4 q, b = brow0 + 16 j).
+// Phase 1: every load (per-feature constants, explicit eps) back to back.  Phase 2 per tile: noise, arithmetic, stores --
+//   fp32 `out` (float4 per lane), sqrt(var) for the backward pass, and the fp16 hi | lo PLANES of the next layer's x: the
+//   lane pair (q, q ^ 1) holds the 8 consecutive k of one 16-B unit pair, v_permlane16_swap_b32 moves the halves so that
+//   the even lane stores the hi unit and the odd lane the lo unit (16 B each, 64 B contiguous per row and tile).
+template <int TO, int TB>
+__device__ __forceinline__ void epilogue16(const G16Args& a, int o0, int q, int brow0,
+                                           const floatx4 (&accm)[TO][TB], const floatx4 (&accv)[TO][TB]) {
+    const bool ovec = ((a.O & 3) == 0) && (!a.out || (((a.ldo & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0))) &&
+                      (!a.eps || (reinterpret_cast<uintptr_t>(a.eps) & 15u) == 0) &&
+                      (!a.std_out || (reinterpret_cast<uintptr_t>(a.std_out) & 15u) == 0);
+    uint64_t seed = 0, offs = 0;
+    if (!a.eps) { seed = a.rng[0]; offs = a.rng[1]; }
+    OC16 oc[TO];
+#pragma unroll
+    for (int i = 0; i < TO; ++i) {
+        const int o = o0 + i * 16 + 4 * q;
+        if (o < a.O) {
+            ld4f(a.bias_mean, o, a.O, 0.f, oc[i].bm);
+            ld4f(a.bias_var, o, a.O, 0.f, oc[i].bv);
+            ld4f(a.var_scale, o, a.O, 1.f, oc[i].vs);
+            ld4f(a.mean_scale, o, a.O, 1.f, oc[i].ms);
+            float wv[4];
+            ld4f(a.wvar_scale, o, a.O, 1.f, wv);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) oc[i].vs[r] = (wv[r] * kS2inv) * oc[i].vs[r];      // exact powers of two first
+        }
+    }
+    float pe[TO][TB][4];
+    if (a.eps) {
+#pragma unroll
+        for (int i = 0; i < TO; ++i) {
+            const int o = o0 + i * 16 + 4 * q;
+#pragma unroll
+            for (int j = 0; j < TB; ++j) {
+                const int b = brow0 + j * 16;
+                if (o >= a.O || b >= a.B) continue;
+                const float* p = a.eps + (size_t)b * a.O + o;
+                if (ovec) { const float4 t = *reinterpret_cast<const float4*>(p); pe[i][j][0] = t.x; pe[i][j][1] = t.y; pe[i][j][2] = t.z; pe[i][j][3] = t.w; }
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pe[i][j][r] = (o + r < a.O) ? p[r] : 0.f;
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const bool odd = q & 1;
+#pragma unroll
+    for (int i = 0; i < TO; ++i) {
+        const int o = o0 + i * 16 + 4 * q;
+        const bool oin = o < a.O;
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            const int b = brow0 + j * 16;
+            const bool live = oin && b < a.B;
+            float e[4] = {0.f, 0.f, 0.f, 0.f};
+            if (a.eps) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) e[r] = pe[i][j][r];
+            } else if (live) {
+                philox_normal4(seed, offs, a.rng_stream, (uint64_t)(a.row_offset + b), (uint32_t)(o >> 2), e);
+            }
+            float res[4], sd[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sd[r] = sqrtf(accv[i][j][r] * oc[i].vs[r] + oc[i].bv[r]);
+                const float m = accm[i][j][r] * oc[i].ms[r] + oc[i].bm[r] + sd[r] * e[r];
+                res[r] = a.relu ? fmaxf(m, 0.f) : m;
+            }
+            if (a.out && live) {
+                float* p = a.out + (size_t)b * a.ldo + o;
+                if (ovec) *reinterpret_cast<float4*>(p) = make_float4(res[0], res[1], res[2], res[3]);
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (o + r < a.O) p[r] = res[r];
+                }
+            }
+            if (a.std_out && live) {
+                float* p = a.std_out + (size_t)b * a.O + o;
+                if (ovec) *reinterpret_cast<float4*>(p) = make_float4(sd[0], sd[1], sd[2], sd[3]);
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (o + r < a.O) p[r] = sd[r];
+                }
+            }
+            if (a.out_planes) {                                   // wave-uniform; every lane takes part in the swaps
+                const uint32_t h01 = cvt_pk_h(res[0], res[1]), h23 = cvt_pk_h(res[2], res[3]);
+                const uint32_t l01 = cvt_pk_h(res[0] - h_lo(h01), res[1] - h_hi(h01));
+                const uint32_t l23 = cvt_pk_h(res[2] - h_lo(h23), res[3] - h_hi(h23));
+                // permlane16_swap(A, B): odd rows (of 16 lanes) of A <-> even rows of B.  With A = hi, B = lo the even lane
+                // ends with (own hi, partner's hi) and the odd lane with (partner's lo, own lo): the unit it stores, in k order
+                const auto s0 = __builtin_amdgcn_permlane16_swap(h01, l01, false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(h23, l23, false, false);
+                if (live) {
+                    const int kk = o & ~7;
+                    char* p = a.out_planes + (size_t)b * a.ldp * 4 + (size_t)(kk >> 5) * 128 + ((kk >> 3) & 3) * 32 + (odd ? 16 : 0);
+                    *reinterpret_cast<uint4*>(p) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                }
+            }
+        }
+    }
+}
+
+// NPV: products of the variance GEMM (1 or 3).  XPL: x given as fp16 hi | lo planes (else fp32 rows, split in registers).
+template <int TO, int TB, int WB, int NPV, bool XPL>
+__device__ __forceinline__ void gemm_f16s_body(const G16Args& a) {
+    static_assert(NPV == 1 || NPV == 3, "one or three variance products");
+    constexpr int BN = TO * 16, BM = TB * WB * 16;
+    constexpr int XB = BM * 128, WRB = BN * 128, BUFB = XB + 2 * WRB;
+    constexpr int NGX = BM / 8, NGW = BN / 8, NG = NGX + 2 * NGW, NPW = (NG + WB - 1) / WB;
+    extern __shared__ __attribute__((aligned(16))) char smc[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, q = lane >> 4;
+    if (a.fin.n > 0 && blockIdx.y == gridDim.y - 1) {                          // the finalize row (uniform per workgroup)
+        if (blockIdx.x == 0) kl_finalize_piggy<WB>(kernarg_as<G16Args>()->fin, reinterpret_cast<float*>(smc));
+        return;
+    }
+    int tox, tby;
+    tile_of_block(tox, tby, a.fin.n > 0 ? 1 : 0);
+    const int o0 = tox * BN, b0 = tby * BM;
+
+    // LDS-DMA through buffer descriptors (see lrt_gemm_bf16x3_body): per-lane byte offsets computed once, the K step
+    // advances a scalar offset of 128 B in every region.  fp32 x: lanes past I in the K tail are pointed out of range
+    // (the bounds check returns zeros); planes carry their own zero tail.
+    const size_t xsz = XPL ? (size_t)a.B * a.ldx * 4 : ((size_t)(a.B - 1) * a.ldx + a.I) * 4;
+    const unsigned xbytes = (unsigned)min((size_t)0x7FFFFFF0u, xsz);
+    const unsigned wbytes = (unsigned)min((size_t)0x7FFFFFF0u, (size_t)a.O * a.ld * 4);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc((void*)a.e_w, 0, (int)wbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)a.var_w, 0, (int)wbytes, 0x00020000);
+    int gv[NPW], kx[NPW];
+#pragma unroll
+    for (int u = 0; u < NPW; ++u) {
+        const int g = wv + WB * u;
+        if (g < NGX) {
+            const int row = 8 * g + (lane >> 3);
+            const int slot = (lane & 7) ^ swzx(row & 15);
+            gv[u] = (int)((size_t)min(b0 + row, a.B - 1) * a.ldx * 4) + 16 * slot;
+            kx[u] = XPL ? -1 : 4 * slot;
+        } else {
+            const int gw = g - NGX, row = 8 * (gw % NGW) + (lane >> 3);
+            const int slot = (lane & 7) ^ swzx(row & 15);
+            gv[u] = (int)((size_t)min(o0 + row, a.O - 1) * a.ld * 4) + 16 * slot;
+            kx[u] = -1;
+        }
+    }
+    const int nsteps = (a.I + BKS - 1) / BKS;
+    const bool has_tail = !XPL && (a.I % BKS) != 0;
+    int gvt[NPW];                                         // the K-tail step's offsets in registers of their own (lrt_gemm.hip)
+#pragma unroll
+    for (int u = 0; u < NPW; ++u)
+        gvt[u] = (kx[u] >= 0 && (nsteps - 1) * BKS + kx[u] >= a.I) ? 0x7FFFFFF0 : gv[u];
+    auto dma_pieces = [&](int c, char* buf, const int (&va)[NPW]) {
+#pragma unroll
+        for (int u = 0; u < NPW; ++u) {
+            const int g = wv + WB * u;                   // wave-uniform
+            if (g < NG) {
+                const int loff = g < NGX ? g * 1024 : XB + (g - NGX) * 1024;
+                auto* dst = (__attribute__((address_space(3))) void*)(buf + loff);
+                if (g < NGX)                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, dst, 16, va[u], c * 128, 0, 0);
+                else if (g - NGX < NGW)      __builtin_amdgcn_raw_ptr_buffer_load_lds(re, dst, 16, va[u], c * 128, 0, 0);
+                else                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, dst, 16, va[u], c * 128, 0, 0);
+            }
+        }
+    };
+    auto dma_step = [&](int c, char* buf) {
+        if (has_tail && c == nsteps - 1) dma_pieces(c, buf, gvt);
+        else dma_pieces(c, buf, gv);
+    };
+
+    floatx4 accm[TO][TB], accv[TO][TB];
+#pragma unroll
+    for (int i = 0; i < TO; ++i)
+#pragma unroll
+        for (int j = 0; j < TB; ++j) { accm[i][j] = floatx4{0.f, 0.f, 0.f, 0.f}; accv[i][j] = floatx4{0.f, 0.f, 0.f, 0.f}; }
+
+    const int gx = swzx(lr);
+    const int xo0 = (wv * TB * 16 + lr) * 128 + 16 * ((2 * q) ^ gx);
+    const int xo1 = (wv * TB * 16 + lr) * 128 + 16 * ((2 * q + 1) ^ gx);
+    const int woh = XB + lr * 128 + 16 * ((2 * q) ^ gx);
+    const int wol = XB + lr * 128 + 16 * ((2 * q + 1) ^ gx);
+
+    uint4 xu[TB][2];
+    uint4 eh[TO], el[TO], vh[TO], vl[TO];
+    auto read_frags = [&](const char* cur) {
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            xu[j][0] = *reinterpret_cast<const uint4*>(cur + xo0 + j * 16 * 128);
+            xu[j][1] = *reinterpret_cast<const uint4*>(cur + xo1 + j * 16 * 128);
+        }
+#pragma unroll
+        for (int i = 0; i < TO; ++i) {
+            eh[i] = *reinterpret_cast<const uint4*>(cur + woh + i * 16 * 128);
+            el[i] = *reinterpret_cast<const uint4*>(cur + wol + i * 16 * 128);
+            vh[i] = *reinterpret_cast<const uint4*>(cur + WRB + woh + i * 16 * 128);
+            if (NPV == 3) vl[i] = *reinterpret_cast<const uint4*>(cur + WRB + wol + i * 16 * 128);
+        }
+    };
+    auto mfmas = [&]() {
+        f16x8 xh[TB], xl[TB], sh[TB], sl[TB];
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            if (XPL) {
+                xh[j] = __builtin_bit_cast(f16x8, xu[j][0]);
+                xl[j] = __builtin_bit_cast(f16x8, xu[j][1]);
+                if (NPV == 1) {
+                    // s = (x 2^-4)^2 from the planes: a = xh 2^-4, b = xl 2^-3, s = a a + a b   (x^2 = xh^2 + 2 xh xl + O(2^-24))
+                    const f16x8 pa = xh[j] * (_Float16)0.0625f, pb = xl[j] * (_Float16)0.125f;
+                    const f16x8 t = pa * pb;
+                    sh[j] = pa * pa + t;
+                } else {
+                    uint32_t ph[4], pl[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float h0 = (float)xh[j][2 * t], h1 = (float)xh[j][2 * t + 1];
+                        const float l0 = (float)xl[j][2 * t], l1 = (float)xl[j][2 * t + 1];
+                        const float s0 = (h0 * h0 + 2.f * h0 * l0) * kS2, s1 = (h1 * h1 + 2.f * h1 * l1) * kS2;
+                        ph[t] = cvt_pk_h(s0, s1);
+                        pl[t] = cvt_pk_h(s0 - h_lo(ph[t]), s1 - h_hi(ph[t]));
+                    }
+                    sh[j] = __builtin_bit_cast(f16x8, make_uint4(ph[0], ph[1], ph[2], ph[3]));
+                    sl[j] = __builtin_bit_cast(f16x8, make_uint4(pl[0], pl[1], pl[2], pl[3]));
+                }
+            } else {
+                const float4 f0 = __builtin_bit_cast(float4, xu[j][0]), f1 = __builtin_bit_cast(float4, xu[j][1]);
+                const float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+                uint32_t ph[4], pl[4], qh[4], ql[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float v0 = v[2 * t], v1 = v[2 * t + 1];
+                    ph[t] = cvt_pk_h(v0, v1);
+                    pl[t] = cvt_pk_h(v0 - h_lo(ph[t]), v1 - h_hi(ph[t]));
+                    const float s0 = (v0 * v0) * kS2, s1 = (v1 * v1) * kS2;
+                    qh[t] = cvt_pk_h(s0, s1);
+                    ql[t] = 0;
+                    if (NPV == 3) ql[t] = cvt_pk_h(s0 - h_lo(qh[t]), s1 - h_hi(qh[t]));
+                }
+                xh[j] = __builtin_bit_cast(f16x8, make_uint4(ph[0], ph[1], ph[2], ph[3]));
+                xl[j] = __builtin_bit_cast(f16x8, make_uint4(pl[0], pl[1], pl[2], pl[3]));
+                sh[j] = __builtin_bit_cast(f16x8, make_uint4(qh[0], qh[1], qh[2], qh[3]));
+                sl[j] = __builtin_bit_cast(f16x8, make_uint4(ql[0], ql[1], ql[2], ql[3]));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+#pragma unroll
+            for (int i = 0; i < TO; ++i) {
+                const f16x8 ah = __builtin_bit_cast(f16x8, eh[i]), al = __builtin_bit_cast(f16x8, el[i]);
+                accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xh[j], accm[i][j], 0, 0, 0);
+                accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xh[j], accm[i][j], 0, 0, 0);
+                accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xl[j], accm[i][j], 0, 0, 0);
+                const f16x8 bh = __builtin_bit_cast(f16x8, vh[i]);
+                accv[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, sh[j], accv[i][j], 0, 0, 0);
+                if (NPV == 3) {
+                    accv[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vl[i]), sh[j], accv[i][j], 0, 0, 0);
+                    accv[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, sl[j], accv[i][j], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    dma_step(0, smc);
+    __syncthreads();
+    for (int c = 0; c < nsteps; ++c) {
+        read_frags(smc + (c & 1) * BUFB);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < nsteps) dma_step(c + 1, smc + ((c & 1) ^ 1) * BUFB);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas();
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    }
+    epilogue16<TO, TB>(a, o0, q, b0 + wv * TB * 16 + lr, accm, accv);
+}
+
+template <int TO, int TB, int WB, int NPV, bool XPL>
+__global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_f16s_kernel(const G16Args a) {
+    gemm_f16s_body<TO, TB, WB, NPV, XPL>(a);
+}
+
+template <int TO, int TB, int WB>
+int launch16(G16Args& a, int npv, bool xpl, hipStream_t s, bool* hosted) {
+    constexpr int BN = TO * 16, BM = TB * WB * 16;
+    dim3 grid((a.O + BN - 1) / BN, (a.B + BM - 1) / BM, 1), block(WB * 64);
+    const long nblocks = (long)grid.x * grid.y;
+    const size_t lds = lds_request(2u * (BM * 128 + 2 * BN * 128), nblocks);
+    const int fin_n = a.fin.n;
+    a.fin.n = 0;
+    if (fin_n > 0 && hosted) {
+        a.fin.n = fin_n;
+        if (piggy_lds_bytes(a.fin) <= lds) { grid.y += 1; *hosted = true; }
+        else a.fin.n = 0;
+    }
+    if (npv == 1) {
+        if (xpl) return launch_one(lrt_gemm_f16s_kernel<TO, TB, WB, 1, true>, grid, block, lds, s, a);
+        return launch_one(lrt_gemm_f16s_kernel<TO, TB, WB, 1, false>, grid, block, lds, s, a);
+    }
+    if (xpl) return launch_one(lrt_gemm_f16s_kernel<TO, TB, WB, 3, true>, grid, block, lds, s, a);
+    return launch_one(lrt_gemm_f16s_kernel<TO, TB, WB, 3, false>, grid, block, lds, s, a);
+}
+
+// fp32 rows -> planes: one thread per 8 consecutive k (two float4 in, the hi unit and the lo unit out)
+__global__ __launch_bounds__(256) void format_x_kernel(const float* x, int ldx, char* planes, int ldp, int B, int I) {
+    const int groups = ldp >> 3;                                      // 8-k groups per row, zero tail included
+    const size_t n = (size_t)B * groups;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (size_t)gridDim.x * 256) {
+        const int b = (int)(t / groups), g = (int)(t % groups), k = 8 * g;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (k < I) {                                                  // I % 8 == 0: a group is inside or outside as a whole
+            const float4 f0 = *reinterpret_cast<const float4*>(x + (size_t)b * ldx + k);
+            const float4 f1 = *reinterpret_cast<const float4*>(x + (size_t)b * ldx + k + 4);
+            v[0] = f0.x; v[1] = f0.y; v[2] = f0.z; v[3] = f0.w; v[4] = f1.x; v[5] = f1.y; v[6] = f1.z; v[7] = f1.w;
+        }
+        uint32_t h[4], l[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            h[u] = cvt_pk_h(v[2 * u], v[2 * u + 1]);
+            l[u] = cvt_pk_h(v[2 * u] - h_lo(h[u]), v[2 * u + 1] - h_hi(h[u]));
+        }
+        char* p = planes + (size_t)b * ldp * 4 + (size_t)(k >> 5) * 128 + ((k >> 3) & 3) * 32;
+        *reinterpret_cast<uint4*>(p) = make_uint4(h[0], h[1], h[2], h[3]);
+        *reinterpret_cast<uint4*>(p + 16) = make_uint4(l[0], l[1], l[2], l[3]);
+    }
+}
+
+}  // namespace
+
+extern "C" int lbbnn_format_x(const float* x, int ldx, void* planes, int ldp, int B, int I, void* stream) {
+    if (B == 0) return 0;
+    if (!x || !planes) return LBBNN_E_NULL;
+    if (B < 0 || I <= 0 || ldx < I || ldp < I) return LBBNN_E_SHAPE;
+    if ((I & 7) || (ldx & 3) || (ldp & 31) || (reinterpret_cast<uintptr_t>(x) & 15u) || (reinterpret_cast<uintptr_t>(planes) & 15u))
+        return LBBNN_E_ALIGN;
+    const size_t n = (size_t)B * (ldp >> 3);
+    const int blocks = (int)min((size_t)2048, (n + 255) / 256);
+    hipLaunchKernelGGL(format_x_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx,
+                       static_cast<char*>(planes), ldp, B, I);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lbbnn_lrt_gemm_ex(const lbbnn_gemm_desc_t* d, void* stream) {
+    if (!d) return LBBNN_E_NULL;
+    const int B = d->B, I = d->I, O = d->O, flags = d->flags;
+    if (flags & ~(LBBNN_F_RELU | LBBNN_F_F16S | LBBNN_F_VAR1 | LBBNN_F_XPLANES)) return LBBNN_E_FLAGS;
+    if (!(flags & LBBNN_F_F16S)) return LBBNN_E_FLAGS;             // the descriptor form serves the fp16 format (the others: lbbnn_lrt_gemm*)
+    if (B == 0 && I > 0 && O > 0 && d->n_layers == 0 && !d->advance) return 0;
+    if (!d->x || !d->e_w || !d->var_w || !d->mean_scale || !d->wvar_scale || (!d->out && !d->out_planes)) return LBBNN_E_NULL;
+    if (!d->eps && !d->rng) return LBBNN_E_NOISE;
+    if (B <= 0 || I <= 0 || O <= 16 || d->ldx < I || (d->out && d->ldo < O)) return LBBNN_E_SHAPE;
+    const bool xpl = (flags & LBBNN_F_XPLANES) != 0;
+    if (d->ld < I || (d->ld & 31) || (I & 7)) return LBBNN_E_ALIGN;
+    if ((I % BKS) != 0 && (d->ld - I) < 8) return LBBNN_E_ALIGN;
+    if ((reinterpret_cast<uintptr_t>(d->e_w) | reinterpret_cast<uintptr_t>(d->var_w) | reinterpret_cast<uintptr_t>(d->x)) & 15u) return LBBNN_E_ALIGN;
+    if (xpl ? (d->ldx & 31) != 0 : (d->ldx & 3) != 0) return LBBNN_E_ALIGN;
+    if (d->out_planes && ((O & 7) || (d->ldp & 31) || d->ldp < O || (reinterpret_cast<uintptr_t>(d->out_planes) & 15u))) return LBBNN_E_ALIGN;
+    if ((size_t)B * d->ldx * 4 >= 0x7FFFFFF0u || (size_t)O * d->ld * 4 >= 0x7FFFFFF0u) return LBBNN_E_SHAPE;   // 32-bit buffer offsets
+    if (d->n_layers < 0 || (d->n_layers > 0 && !d->layers) || (d->advance && !d->rng_live)) return LBBNN_E_NULL;
+
+    G16Args a;
+    a.x = static_cast<const char*>(d->x); a.e_w = static_cast<const char*>(d->e_w); a.var_w = static_cast<const char*>(d->var_w);
+    a.mean_scale = d->mean_scale; a.wvar_scale = d->wvar_scale;
+    a.bias_mean = d->bias_mean; a.bias_var = d->bias_var; a.var_scale = d->var_scale;
+    a.eps = d->eps; a.rng = d->rng; a.out = d->out; a.out_planes = static_cast<char*>(d->out_planes); a.std_out = d->std_out;
+    a.row_offset = d->row_offset; a.ldx = d->ldx; a.ld = d->ld; a.ldo = d->ldo; a.ldp = d->ldp; a.B = B; a.I = I; a.O = O;
+    a.rng_stream = d->rng_stream; a.relu = (flags & LBBNN_F_RELU) ? 1 : 0;
+    a.fin = FinalizePiggy{};
+    const bool want_fin = d->n_layers > 0 || d->advance;
+    if (d->n_layers > 0) {
+        if (const int rc = fill_finalize_args(d->layers, d->n_layers, d->fin_rng, a.fin.l, a.fin.active)) return rc;
+        if (d->kl_total) for (int i = 0; i < d->n_layers; ++i) if (!a.fin.active[i]) return LBBNN_E_NULL;
+        a.fin.n = d->n_layers; a.fin.total = d->kl_total;
+        a.fin.rng_adv = d->advance ? d->rng_live : nullptr; a.fin.adv = d->advance;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int npv = (flags & LBBNN_F_VAR1) ? 1 : 3;
+    bool hosted = false;
+    const long blocks_big = (long)((O + 79) / 80) * ((B + 127) / 128);
+    int rc;
+    if (blocks_big >= 256 && B >= 96) rc = launch16<5, 2, 4>(a, npv, xpl, s, &hosted);
+    else rc = launch16<5, 1, 2>(a, npv, xpl, s, &hosted);
+    if (rc || !want_fin || hosted) return rc;
+    if (d->n_layers > 0)
+        return launch_kl_finalize_all(a.fin.l, a.fin.active, d->n_layers, d->advance ? d->rng_live : nullptr, d->advance,
+                                      d->kl_total, s);
+    return lbbnn_rng_advance(d->rng_live, d->advance, stream);
+}

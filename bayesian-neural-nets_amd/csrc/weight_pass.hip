@@ -59,6 +59,36 @@ __device__ __forceinline__ void split4(const float4 w, uint2& hi, uint2& lo) {
                     cvt_pk(w.z - __uint_as_float(h1 << 16), w.w - __uint_as_float(h1 & 0xFFFF0000u)));
 }
 
+// fp16 forms for the row-scaled format (LBBNN_F_F16S): w * scale = hi + lo, both IEEE fp16 (v_cvt_pk_f16_f32, RNE)
+typedef _Float16 k1_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cvt_pk_h(float a, float b) {
+    const k1_floatx2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, k1_f16x2));
+}
+__device__ __forceinline__ void split4_h(const float4 w, uint2& hi, uint2& lo) {
+    const uint32_t h0 = cvt_pk_h(w.x, w.y), h1 = cvt_pk_h(w.z, w.w);
+    const k1_f16x2 f0 = __builtin_bit_cast(k1_f16x2, h0), f1 = __builtin_bit_cast(k1_f16x2, h1);
+    hi = make_uint2(h0, h1);
+    lo = make_uint2(cvt_pk_h(w.x - (float)f0[0], w.y - (float)f0[1]), cvt_pk_h(w.z - (float)f1[0], w.w - (float)f1[1]));
+}
+// max over the 64 lanes (every lane gets it); v >= 0
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, dpp_get<0xB1>(v));
+    v = fmaxf(v, dpp_get<0x4E>(v));
+    v = fmaxf(v, dpp_get<0x141>(v));
+    v = fmaxf(v, dpp_get<0x140>(v));
+    return fmaxf(fmaxf(lane_get(v, 0), lane_get(v, 16)), fmaxf(lane_get(v, 32), lane_get(v, 48)));
+}
+// Exact power-of-two scale that puts a row maximum m into [2^13, 2^14) (fp16 overflows at 65504 = 2^16 - 32: headroom for
+// the RNE of hi), and its inverse -- the factor the GEMM epilogue applies to the accumulators.  m == 0 (or denormal): 1.
+__device__ __forceinline__ void pow2_scale(float m, float& scale, float& inv) {
+    int eb = (int)((__float_as_uint(m) >> 23) & 0xFFu);           // biased exponent: m in [2^(eb-127), 2^(eb-126))
+    if (eb == 0) { scale = 1.f; inv = 1.f; return; }
+    eb = eb < 20 ? 20 : (eb > 230 ? 230 : eb);
+    scale = __uint_as_float((uint32_t)(267 - eb) << 23);          // 2^(13 - (eb - 127))
+    inv = __uint_as_float((uint32_t)(eb - 13) << 23);
+}
+
 // All per-weight arithmetic (LBBNN-GP-MF-LRT.py:167-171,189-192; LBBNN-GP-MF-MNF.py:195-196,211-212,230-233).
 //
 // The pass must stay HBM-bound (20 B per weight), so the ~7 transcendentals per weight use the
@@ -260,6 +290,7 @@ __device__ __forceinline__ float4 fma4(const float4 u, float s, const float4 z) 
 }
 __device__ __forceinline__ uint32_t dpp_xor1(uint32_t v) { return (uint32_t)dpp_mov<0xB1>((int)v); }   // lane ^ 1
 
+template <bool F16S>
 __global__ __launch_bounds__(256, 3) void weight_rows_kernel(const WeightRowsBatch bt_) {
     const LBBNN_CONST_AS WeightRowsBatch* bt = kernarg_as<WeightRowsBatch>();
     extern __shared__ __attribute__((aligned(16))) float sm[];          // zf[P] | zk[P] | rc[P]
@@ -440,11 +471,17 @@ __global__ __launch_bounds__(256, 3) void weight_rows_kernel(const WeightRowsBat
     if (!has_row) return;
     const ElemConst ec = {a.mu_prior, a.log_sp, a.log_ap, a.log_1map, a.inv_2sp2};
     float kl = 0.f, amu = 0.f, avar = 0.f;
-    const bool split = a.split != 0;
+    const bool split = a.split == 1;
     float* const ewp = a.e_w ? a.e_w + (size_t)mem * a.O * P : nullptr;
     float* const vwp = mem == 0 ? a.var_w : nullptr;
     // kRowB float4 groups per lane at a time, all of their loads in flight together: rows up to 64 * 4 * 5 = 1280 floats
     // (every layer of the BASELINE configs but the 3072 / 4096-wide VD ones, which take the generic kernel) are one batch
+    // F16S instantiation: launches in which SOME layer takes row-scaled fp16 operands (split == 2).  The host guarantees
+    // G <= kRowB for EVERY layer of such a launch (one batch), and every row keeps its operands in registers until the row
+    // maxima are known -- the other layers of the launch (the fp32 10-class head) store theirs from the same place, so the
+    // loop below has one shape per instantiation
+    const bool f16s = F16S && a.split == 2;
+    float4 ew_keep[F16S ? kRowB : 1], vw_keep[F16S ? kRowB : 1];
     for (int g0 = 0; g0 < G; g0 += kRowB) {
         float4 mu[kRowB], rho[kRowB], lam[kRowB];
 #pragma unroll
@@ -470,7 +507,9 @@ __global__ __launch_bounds__(256, 3) void weight_rows_kernel(const WeightRowsBat
                 amu += (e0.amu + e1.amu) + (e2.amu + e3.amu);
                 avar += (e0.avar + e1.avar) + (e2.avar + e3.avar);
             }
-            if (!split) {
+            if constexpr (F16S) {
+                ew_keep[g] = ew; vw_keep[g] = vw;           // stored below, once the row maxima are known
+            } else if (!split) {
                 if (j < nq) {
                     if (ewp) reinterpret_cast<float4*>(ewp + (size_t)o * P)[j] = ew;
                     if (vwp) reinterpret_cast<float4*>(vwp + (size_t)o * P)[j] = vw;
@@ -496,6 +535,59 @@ __global__ __launch_bounds__(256, 3) void weight_rows_kernel(const WeightRowsBat
             }
         }
     }
+    if constexpr (F16S) {
+        // LBBNN_F_F16S: one exact power-of-two scale per row and operand, then hi | lo fp16 units exactly as the bf16 form
+        // lays them out (even lane of a pair: the hi unit, odd lane: the lo unit).  Layers of the launch in another format
+        // (split 0 / 1) store the operands they kept, unscaled, in their own format.
+        float se = 1.f, ie = 1.f, sv = 1.f, iv = 1.f;
+        if (f16s) {
+            float me = 0.f, mv = 0.f;
+#pragma unroll
+            for (int g = 0; g < kRowB; ++g) {
+                if (g >= G) break;
+                me = fmaxf(me, fmaxf(fmaxf(fabsf(ew_keep[g].x), fabsf(ew_keep[g].y)), fmaxf(fabsf(ew_keep[g].z), fabsf(ew_keep[g].w))));
+                mv = fmaxf(mv, fmaxf(fmaxf(vw_keep[g].x, vw_keep[g].y), fmaxf(vw_keep[g].z, vw_keep[g].w)));
+            }
+            me = wave_max(me); mv = wave_max(mv);
+            pow2_scale(me, se, ie);
+            pow2_scale(mv, sv, iv);
+        }
+        const bool odd = lane & 1;
+#pragma unroll
+        for (int g = 0; g < kRowB; ++g) {
+            if (g >= G) break;
+            const int j = lane + 64 * g;
+            if (a.split == 0) {
+                if (j < nq) {
+                    if (ewp) reinterpret_cast<float4*>(ewp + (size_t)o * P)[j] = ew_keep[g];
+                    if (vwp) reinterpret_cast<float4*>(vwp + (size_t)o * P)[j] = vw_keep[g];
+                }
+                continue;
+            }
+            const size_t at = split_hi_index((size_t)o, 4 * (j & ~1), P) + (odd ? kSplitLoOffset : 0);
+            uint2 hi, lo;
+            {
+                const float4 w = ew_keep[g];
+                if (f16s) split4_h(make_float4(w.x * se, w.y * se, w.z * se, w.w * se), hi, lo);
+                else split4(w, hi, lo);
+                const uint32_t r0 = dpp_xor1(odd ? hi.x : lo.x), r1 = dpp_xor1(odd ? hi.y : lo.y);
+                const uint4 unit = make_uint4(odd ? r0 : hi.x, odd ? r1 : hi.y, odd ? lo.x : r0, odd ? lo.y : r1);
+                if (ewp && j < nq) *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(ewp) + at) = unit;
+            }
+            if (vwp) {
+                const float4 w = vw_keep[g];
+                if (f16s) split4_h(make_float4(w.x * sv, w.y * sv, w.z * sv, w.w * sv), hi, lo);
+                else split4(w, hi, lo);
+                const uint32_t r0 = dpp_xor1(odd ? hi.x : lo.x), r1 = dpp_xor1(odd ? hi.y : lo.y);
+                const uint4 unit = make_uint4(odd ? r0 : hi.x, odd ? r1 : hi.y, odd ? lo.x : r0, odd ? lo.y : r1);
+                if (j < nq) *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(vwp) + at) = unit;
+            }
+        }
+        if (f16s && lane == 0) {
+            if (a.e_scale) a.e_scale[o] = ie;
+            if (a.v_scale && vwp) a.v_scale[o] = iv;
+        }
+    }
     if (want_kl || want_act) {
         kl = wave_sum(kl); amu = wave_sum(amu); avar = wave_sum(avar);
         if (lane == 0) {
@@ -518,8 +610,11 @@ namespace lbbnn {
 int make_weight_pass_args(WeightPassArgs& a, const float* mu, const float* rho, const float* lambdal,
                           const float* z_fwd, const float* z_kl, const float* r0_c, const float* bias_rho,
                           const lbbnn_priors_t* priors, void* e_w, void* var_w, int ld,
-                          float* kl_rows, float* act_mu, float* act_var, float* bias_var, int O, int I, int split) {
+                          float* kl_rows, float* act_mu, float* act_var, float* bias_var, int O, int I, int split,
+                          float* e_scale, float* v_scale) {
     if (!mu || !rho || !lambdal || !priors) return LBBNN_E_NULL;
+    if (split == 2 && ((e_w && !e_scale) || (var_w && !v_scale))) return LBBNN_E_NULL;
+    if (split < 0 || split > 2) return LBBNN_E_FLAGS;
     if (O <= 0 || I <= 0) return LBBNN_E_SHAPE;
     if ((e_w || var_w) && (ld < I || (ld & 31))) return LBBNN_E_ALIGN;
     if ((act_mu == nullptr) != (act_var == nullptr)) return LBBNN_E_NULL;
@@ -535,9 +630,12 @@ int make_weight_pass_args(WeightPassArgs& a, const float* mu, const float* rho, 
     a.log_sp = logf(priors->sigma_prior); a.log_ap = logf(priors->alpha_prior); a.log_1map = logf(1.f - priors->alpha_prior);
     a.inv_2sp2 = 1.f / (2.f * priors->sigma_prior * priors->sigma_prior);
     a.split = split;
+    a.e_scale = e_scale; a.v_scale = v_scale;
     a.vec = ((I % 4 == 0) && aligned16(mu) && aligned16(rho) && aligned16(lambdal) &&
              (!z_fwd || aligned16(z_fwd)) && (!z_kl || aligned16(z_kl)) && (!r0_c || aligned16(r0_c))) ? 1 : 0;
     if (split && !a.vec) return LBBNN_E_ALIGN;          // split operands need the vector path (I % 4 == 0, aligned)
+    // the row-scaled fp16 format needs the whole row in one batch of the row kernel (the scale is the row maximum's)
+    if (split == 2 && a.ld > 64 * 4 * 5) return LBBNN_E_SHAPE;
     return 0;
 }
 
@@ -569,6 +667,13 @@ int launch_weight_pass(const WeightPassArgs* a, int n, hipStream_t s, uint64_t* 
     // LBBNN_K1_ROWS=0 (environment, read once): A/B switch for measurements -- the one-row-per-workgroup kernel of round 1
     static const bool rows_allowed = [] { const char* e = getenv("LBBNN_K1_ROWS"); return !(e && e[0] == '0'); }();
     rows_ok = rows_ok && rows_allowed;
+    bool any_f16 = false;
+    for (int i = 0; i < n; ++i) any_f16 = any_f16 || a[i].split == 2;
+    if (any_f16) {
+        for (int i = 0; i < n; ++i) if (!a[i].vec || a[i].ld > 64 * 4 * kRowB) return LBBNN_E_SHAPE;   // every layer: one batch
+        if (members > 1) return LBBNN_E_FLAGS;               // (the ensemble's member dimension keeps the bf16 format)
+        rows_ok = true;
+    }
     if (rows_ok) {
         WeightRowsBatch bt{};
         bt.rng = rng; bt.rng_snap = (rng && rng_snap) ? rng_snap : nullptr; bt.advance = advance;
@@ -584,8 +689,11 @@ int launch_weight_pass(const WeightPassArgs* a, int n, hipStream_t s, uint64_t* 
         bt.n = n;
         bt.members = members;
         if (members > 1) for (int i = 0; i < n; ++i) if (bt.f[i].on || a[i].kl_rows || a[i].act_mu) return LBBNN_E_FLAGS;
-        hipLaunchKernelGGL(weight_rows_kernel, dim3(wgs, members > 1 ? members : 1), dim3(256),
-                           (size_t)3 * maxld * sizeof(float), s, bt);
+        if (any_f16)
+            hipLaunchKernelGGL(weight_rows_kernel<true>, dim3(wgs, 1), dim3(256), (size_t)3 * maxld * sizeof(float), s, bt);
+        else
+            hipLaunchKernelGGL(weight_rows_kernel<false>, dim3(wgs, members > 1 ? members : 1), dim3(256),
+                               (size_t)3 * maxld * sizeof(float), s, bt);
         return (int)hipGetLastError();
     }
     if (members > 1) return LBBNN_E_ALIGN;                  // the member dimension exists in the row kernel only
@@ -603,6 +711,19 @@ int launch_weight_pass(const WeightPassArgs* a, int n, hipStream_t s, uint64_t* 
 }  // namespace lbbnn
 
 extern "C" int lbbnn_operand_ld(int I) { return I <= 0 ? 0 : ((I + 31) / 32) * 32; }
+
+extern "C" int lbbnn_weight_pass_f16(const float* mu, const float* rho, const float* lambdal,
+                                     const float* z_fwd, const float* z_kl, const float* r0_c,
+                                     const float* bias_rho, const lbbnn_priors_t* priors,
+                                     void* e_w, void* var_w, int ld, float* e_scale, float* v_scale,
+                                     float* kl_rows, float* act_mu, float* act_var, float* bias_var,
+                                     int O, int I, void* stream) {
+    lbbnn::WeightPassArgs a;
+    const int rc = lbbnn::make_weight_pass_args(a, mu, rho, lambdal, z_fwd, z_kl, r0_c, bias_rho, priors, e_w, var_w, ld,
+                                                kl_rows, act_mu, act_var, bias_var, O, I, 2, e_scale, v_scale);
+    if (rc) return rc;
+    return lbbnn::launch_weight_pass(&a, 1, static_cast<hipStream_t>(stream));
+}
 
 extern "C" int lbbnn_weight_pass(const float* mu, const float* rho, const float* lambdal,
                                  const float* z_fwd, const float* z_kl, const float* r0_c,

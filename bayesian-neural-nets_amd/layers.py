@@ -42,6 +42,9 @@ _MASKS_IN_KERNEL = _os.environ.get("LBBNN_TORCH_MASKS", "0") != "1"
 # pass (default: while a HIP graph is being captured they go on a side stream beside the weight pass and the first GEMM -- only
 # the KL finalize needs them; "always": in eager launches too)
 _DENSE_DEFER = {"0": False, "always": "always"}.get(_os.environ.get("LBBNN_DENSE_DEFER", "1"), True)
+# LBBNN_F16_FIRST=f32: the first row-scaled-fp16 layer of a fused forward takes the fp32 network input as it is and splits it
+# in registers (no lbbnn_format_x launch; ~64 more VALU instructions per wave and K step in that GEMM).  Default: planes.
+_F16_FIRST_PLANES = _os.environ.get("LBBNN_F16_FIRST", "planes") != "f32"
 _SIDE = {}
 
 
@@ -265,8 +268,8 @@ class _BayesLinearFn(torch.autograd.Function):
             # (e_w z)^T and var_w^T straight from the parameters in one pass (lbbnn_weight_operands_t)
             from . import _lib
             O, I = layer.out_features, layer.in_features
-            split_m = _operand_split_ok(g, O, I)
-            split_v = _operand_split_ok(g_v, O, I) if stochastic else split_m
+            split_m = _operand_split_ok(g, O, I, layer)
+            split_v = _operand_split_ok(g_v, O, I, layer) if stochastic else split_m
             ld = ops.operand_ld(O)
             e_t = torch.empty((I, ld), dtype=torch.float32, device=x.device)
             v_t = torch.empty((I, ld), dtype=torch.float32, device=x.device) if stochastic else None
@@ -276,25 +279,25 @@ class _BayesLinearFn(torch.autograd.Function):
                     e_t.data_ptr(), v_t.data_ptr() if v_t is not None else None, ld, O, I,
                     ops.F_SPLIT16 if split_m else 0, torch.cuda.current_stream(x.device).cuda_stream), "lbbnn_weight_operands_t")
                 w_shape = torch.empty((O, I), device="meta")       # shape carrier for _hip_matmul_nt
-                gx = _hip_matmul_nt(g, None, w_shape, op=e_t)
+                gx = _hip_matmul_nt(g, None, w_shape, op=e_t, module=layer)
                 if stochastic:
                     if I > 16 and x.stride(1) == 1:
                         # dX = G_m.W_m + 2 x (.) (G_v.W_v): the combination is the second product's epilogue
                         gx = ops.lrt_gemm_combine(g_v, v_t, K=O, N=I, comb_x=x, comb_add=gx, split=split_v)
                     else:
-                        gx = ops.dx_combine(gx, _hip_matmul_nt(g_v, None, w_shape, op=v_t), x)
+                        gx = ops.dx_combine(gx, _hip_matmul_nt(g_v, None, w_shape, op=v_t, module=layer), x)
             else:
                 ws = layer._workspace()
                 bw = ws.backward_operands()
                 ops.weight_pass(mu, rho, lam, z_fwd=z_k, priors=layer.priors, e_w=bw[0],
                                 var_w=bw[1] if stochastic else None)
-                gx = _hip_matmul_nt(g, ops.transpose_operand, bw[0][:, :I])
+                gx = _hip_matmul_nt(g, ops.transpose_operand, bw[0][:, :I], module=layer)
                 if stochastic:
-                    gx = ops.dx_combine(gx, _hip_matmul_nt(g_v, ops.transpose_operand, bw[1][:, :I]), x)
-        pair = _x_operand_pair(x, gT, g_vT) if stochastic else None
-        dWm = _hip_matmul_nt(gT, ops.transpose_operand, x, allow_splitk=True, op=pair[0] if pair else None)
-        dWv = (_hip_matmul_nt(g_vT, ops.transpose_operand, x, square=True, allow_splitk=True, op=pair[1] if pair else None)
-               if stochastic else None)
+                    gx = ops.dx_combine(gx, _hip_matmul_nt(g_v, ops.transpose_operand, bw[1][:, :I], module=layer), x)
+        pair = _x_operand_pair(x, gT, g_vT, layer) if stochastic else None
+        dWm = _hip_matmul_nt(gT, ops.transpose_operand, x, allow_splitk=True, op=pair[0] if pair else None, module=layer)
+        dWv = (_hip_matmul_nt(g_vT, ops.transpose_operand, x, square=True, allow_splitk=True, op=pair[1] if pair else None,
+                              module=layer) if stochastic else None)
         # ---- K1b: the whole (O,I) chain in one pass
         dmu, drho, dlam, dz_k, dz2, dr0c = ops.weight_pass_backward(
             mu, rho, lam, dWm, dWv, z_fwd=z_k, z_kl=z2, r0_c=r0_c, da_mu=da_mu, da_var=da_var, g_kl=g_kl,
@@ -357,12 +360,13 @@ class _BayesLinearFn(torch.autograd.Function):
         return (None, gx, None, dmu, drho, dlam, *vgrads)
 
 
-def _operand_split_ok(a, K, N):
-    return (ops.split_precision() and ops.split_eligible(K, N)
+def _operand_split_ok(a, K, N, module=None):
+    """bf16x3 operands for a backward / mean-only product of ``module`` (any 16-bit precision selects them)?"""
+    return (ops.split_precision(module) and ops.split_eligible(K, N)
             and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0)
 
 
-def _hip_matmul_nt(a, transpose_fn, w, square=False, allow_splitk=False, op=None):
+def _hip_matmul_nt(a, transpose_fn, w, square=False, allow_splitk=False, op=None, module=None):
     """a (M,K) @ f(w) (K,N) with f = identity or square, through lbbnn_lrt_gemm (mean-only):
     the operand is f(w)^T = [N][ld(K)], built by lbbnn_transpose_operand (or handed in as ``op``).  With
     ``allow_splitk`` a long contraction with few output tiles (the weight gradients: K = batch) is cut into k ranges
@@ -370,7 +374,7 @@ def _hip_matmul_nt(a, transpose_fn, w, square=False, allow_splitk=False, op=None
     M, K = a.shape
     N = w.shape[1]
     assert w.shape[0] == K
-    split = _operand_split_ok(a, K, N)
+    split = _operand_split_ok(a, K, N, module)
     if op is None:
         op = transpose_fn(w if w.stride(1) == 1 else w.contiguous(), square=square, split=split)
     if allow_splitk and split and K >= 1024:
@@ -382,15 +386,15 @@ def _hip_matmul_nt(a, transpose_fn, w, square=False, allow_splitk=False, op=None
     return ops.lrt_gemm(a, op, None, I=K, O=N, mean_only=True, split=split)
 
 
-def _x_operand_pair(x, gT, g_vT):
+def _x_operand_pair(x, gT, g_vT, module=None):
     """x^T and (x^2)^T as GEMM operands from ONE pass over x (lbbnn_vd_operands: the variational-dropout kernel does
     exactly this for theta) when both weight-gradient products use the same operand format; else None."""
     from . import _lib
     B, I = x.shape
     if not x.is_contiguous():
         return None
-    split = _operand_split_ok(gT, B, I)
-    if split != _operand_split_ok(g_vT, B, I):
+    split = _operand_split_ok(gT, B, I, module)
+    if split != _operand_split_ok(g_vT, B, I, module):
         return None
     ld = ops.operand_ld(B)
     xt = torch.empty((I, ld), dtype=torch.float32, device=x.device)
@@ -456,14 +460,26 @@ class _BayesLinearBase(nn.Module):
     def _alpha_now(self):
         return 1 / (1 + torch.exp(-self.lambdal))
 
-    def _split(self, x=None):
-        """Use the split-precision (bf16x3) operands/kernels for this layer call?"""
-        if not ops.split_precision() or not ops.split_eligible(self.in_features, self.out_features):
-            return False
+    precision = None              # None: the process-wide default (ops.set_precision); else one of ops.PRECISIONS
+
+    def _split(self, x=None, cfg=None):
+        """Operand format of this layer call: 0 fp32, 1 bf16 hi | lo (bf16x3 and the reduced single-product modes), 2
+        row-scaled fp16 hi | lo (fp16x3 / fp16x3f: the dual-moment GEMM only -- a posterior-mean call takes format 1)."""
+        if not ops.split_precision(self) or not ops.split_eligible(self.in_features, self.out_features):
+            return 0
         if x is not None and (x.stride(0) % 4 != 0 or x.data_ptr() % 16 != 0 or x.stride(1) != 1
                               or x.shape[0] * x.stride(0) * 4 >= 0x7FFFFFF0):      # 32-bit buffer offsets in the split kernel
-            return False
-        return True
+            return 0
+        if (ops.f16s_precision(self) and (cfg is None or cfg[0]) and ops.f16s_eligible(self.in_features, self.out_features)
+                and getattr(self, "_f16s_net_ok", True)):
+            return 2
+        return 1
+
+    def _var1(self):
+        return ops.get_precision(self) == "fp16x3f"
+
+    def _single(self):
+        return ops.get_precision(self) in ("bf16", "fp16")
 
     @property
     def alpha_q(self):
@@ -489,10 +505,34 @@ class _BayesLinearBase(nn.Module):
         d.stochastic, d.want_kl = int(cfg[0]), int(cfg[1])
         d.split = int(self._split_now)
         d.e_w, d.var_w = ws.e_w.data_ptr(), ws.var_w.data_ptr()
+        d.e_scale, d.v_scale = ws.e_scale.data_ptr(), ws.v_scale.data_ptr()
         d.kl_rows, d.bias_var = ws.kl_rows.data_ptr(), ws.bias_var.data_ptr()
         d.kl_layer = kl_layer.data_ptr() if kl_layer is not None else None
         d.q0_mean = None
         return ws, noise
+
+    def _gemm(self, x, cfg, rng, log_softmax=False, std_out=None, finalize=None, out=None, x_planes=False,
+              out_planes=None, want_out=True):
+        """The layer's GEMM launch on the operands ``_prep`` (or the network's batched prepare) left in the workspace.
+        Format 2 (row-scaled fp16): lbbnn_lrt_gemm_ex -- ``x`` may be the plane buffer the previous layer wrote
+        (``x_planes``), and the call may write planes for the next layer (``out_planes``) instead of / beside fp32 ``out``
+        (``want_out``); returns ``out`` (None when only planes were asked for)."""
+        stochastic, _, relu = cfg
+        ws = self._workspace()
+        eps = (self.noise or {}).get("eps_out")
+        stream_id = ops.STREAM_EPS_OUT * 64 + self._layer_id
+        if self._split_now == 2:
+            assert stochastic and not log_softmax
+            o, _ = ops.lrt_gemm16(x, ws.e_w, ws.var_w, ws.e_scale, ws.v_scale, I=self.in_features, O=self.out_features,
+                                  bias_mean=self.bias_mu, bias_var=ws.bias_var, eps=eps, rng=rng, rng_stream=stream_id,
+                                  row_offset=self.row_offset, relu=relu, var1=self._var1(), x_planes=x_planes, out=out,
+                                  want_out=want_out, out_planes=out_planes, std_out=std_out, finalize=finalize)
+            return o
+        return ops.lrt_gemm(x, ws.e_w, ws.var_w, I=self.in_features, O=self.out_features,
+                            bias_mean=self.bias_mu, bias_var=ws.bias_var, eps=eps, rng=rng,
+                            rng_stream=stream_id, row_offset=self.row_offset,
+                            relu=relu, mean_only=not stochastic, log_softmax=log_softmax, split=bool(self._split_now),
+                            std_out=std_out, finalize=finalize, out=out, single=self._single())
 
     def _forward_hip(self, x, cfg, advance=True, save_rng=False, want_std=False):
         """One layer, sequentially on the current stream: prep kernels, GEMM, RNG advance.
@@ -508,7 +548,7 @@ class _BayesLinearBase(nn.Module):
             saved["rng"] = (pre_["snap"] if (pre_ is not None and pre_.get("snap") is not None) else rng.clone()) if save_rng else None
         kl = torch.empty((), dtype=torch.float32, device=x.device) if cfg[1] else None
         self._cur_B = x.shape[0]
-        self._split_now = self._split(x)
+        self._split_now = self._split(x, cfg)
         self._last_masks = None
         # the layer's KL tail (K5) depends on parameters only: it rides in the GEMM's launch (lbbnn_lrt_gemm_finalize)
         # instead of a launch of its own between the weight pass and the GEMM
@@ -586,7 +626,8 @@ class LRTBayesianLinear(_BayesLinearBase):
         ws = self._workspace()
         ops.weight_pass(self.weight_mu, self.weight_rho, self.lambdal, bias_rho=self.bias_rho,
                         priors=self.priors, e_w=ws.e_w, var_w=ws.var_w if stochastic else None,
-                        kl_rows=ws.kl_rows if want_kl else None, bias_var=ws.bias_var, split=self._split_now)
+                        kl_rows=ws.kl_rows if want_kl else None, bias_var=ws.bias_var, split=self._split_now,
+                        e_scale=ws.e_scale, v_scale=ws.v_scale)
         if want_kl and finalize:
             self._finalize(rng, kl_layer, kl_total, accumulate)
 
@@ -594,16 +635,6 @@ class LRTBayesianLinear(_BayesLinearBase):
         ws = self._workspace()
         ops.kl_finalize(ws.kl_rows, self.bias_mu, self.bias_rho, priors=self.priors, kl_layer=kl_layer,
                         kl_out=kl_total, accumulate=accumulate)
-
-    def _gemm(self, x, cfg, rng, log_softmax=False, std_out=None, finalize=None, out=None):
-        stochastic, _, relu = cfg
-        ws = self._workspace()
-        eps = (self.noise or {}).get("eps_out")
-        return ops.lrt_gemm(x, ws.e_w, ws.var_w, I=self.in_features, O=self.out_features,
-                            bias_mean=self.bias_mu, bias_var=ws.bias_var, eps=eps, rng=rng,
-                            rng_stream=ops.STREAM_EPS_OUT * 64 + self._layer_id, row_offset=self.row_offset,
-                            relu=relu, mean_only=not stochastic, log_softmax=log_softmax, split=self._split_now,
-                            std_out=std_out, finalize=finalize, out=out)
 
     def _noise_for_backward(self, saved, B, need_out=True):
         if saved.get("noise") and "eps_out" in saved["noise"]:
@@ -887,7 +918,7 @@ class MNFBayesianLinear(_BayesLinearBase):
                         var_w=ws.var_w if stochastic else None,
                         kl_rows=ws.kl_rows if want_kl else None,
                         act_mu=ws.act_mu if want_kl else None, act_var=ws.act_var if want_kl else None,
-                        bias_var=ws.bias_var, split=self._split_now)
+                        bias_var=ws.bias_var, split=self._split_now, e_scale=ws.e_scale, v_scale=ws.v_scale)
         if want_kl and finalize:
             self._finalize(rng, kl_layer, kl_total, accumulate)
 
@@ -897,15 +928,6 @@ class MNFBayesianLinear(_BayesLinearBase):
                         act_mu=ws.act_mu, act_var=ws.act_var, eps_act=(self.noise or {}).get("eps_act"),
                         r0_b1=self.r0_b1, r0_b2=self.r0_b2, scal=ws.scal, rng=rng,
                         layer_id=self._layer_id, kl_layer=kl_layer, kl_out=kl_total, accumulate=accumulate)
-
-    def _gemm(self, x, cfg, rng, log_softmax=False, std_out=None, finalize=None, out=None):
-        stochastic, _, relu = cfg
-        ws = self._workspace()
-        return ops.lrt_gemm(x, ws.e_w, ws.var_w, I=self.in_features, O=self.out_features,
-                            bias_mean=self.bias_mu, bias_var=ws.bias_var, eps=(self.noise or {}).get("eps_out"),
-                            rng=rng, rng_stream=ops.STREAM_EPS_OUT * 64 + self._layer_id,
-                            row_offset=self.row_offset, relu=relu, mean_only=not stochastic,
-                            log_softmax=log_softmax, split=self._split_now, std_out=std_out, finalize=finalize, out=out)
 
     def _noise_for_backward(self, saved, B, need_out=True):
         masks = saved.get("masks") or {}
@@ -982,6 +1004,33 @@ class _NetworkBase(nn.Module):
         data-parallel job, and a re-run of the same script with one more model in it, see the same streams."""
         for i, l in enumerate(self._layers()):
             l._layer_id = i
+        # the batched weight pass of a network is ONE launch: the row-scaled fp16 format needs every row of every layer in
+        # one register batch there (<= 1280 weights per row, weight_pass.hip), so a network with a wider layer keeps bf16x3
+        ok = all(ops.operand_ld(l.in_features) <= 1280 for l in self._layers())
+        for l in self._layers():
+            l._f16s_net_ok = ok
+        self._plane_cache = {}
+
+    precision = None
+
+    def set_precision(self, name):
+        """GEMM arithmetic of THIS network (ops.PRECISIONS; None = follow the process-wide default of ops.set_precision)."""
+        if name is not None and name not in ops.PRECISIONS:
+            raise ValueError("precision must be one of %s or None" % (ops.PRECISIONS,))
+        self.precision = name
+        for l in self._layers():
+            l.precision = name
+        return self
+
+    def _planes(self, key, B, width, dev, plan=None):
+        """A (B, plane_ld(width)) zero-initialised fp32-sized buffer for fp16 hi | lo planes: the tail slots past `width` are
+        never written afterwards, so they stay zero (the consuming GEMM reads whole 128-B lines)."""
+        store = plan if plan is not None else self._plane_cache
+        k = ("planes", key, B, width, str(dev))
+        buf = store.get(k)
+        if buf is None:
+            buf = store[k] = torch.zeros((B, ops.plane_ld(width)), dtype=torch.float32, device=dev)
+        return buf
 
     def forward(self, x, sample=False):
         x = x.view(-1, self.dims[0])                                  # …LRT.py:207
@@ -1075,7 +1124,7 @@ class _NetworkBase(nn.Module):
             if l._mnf:
                 for name in (("act_mu", "act_var") if f == "dense" else ("z_fwd", "z_kl", "scal", "act_mu", "act_var")):
                     setattr(ws, name, torch.empty_like(getattr(ws, name)))
-            l._split_now = l._split(xin if i == 0 else None) and (i == 0 or layers[i - 1].out_features % 4 == 0)
+            l._split_now = l._split(xin if i == 0 else None, c) if (i == 0 or layers[i - 1].out_features % 4 == 0) else 0
             kl = torch.empty((), dtype=torch.float32, device=dev) if c[1] else None
             kls.append(kl)
             keep.append(l._fill_desc(descs[i], c, kl))
@@ -1131,7 +1180,7 @@ class _NetworkBase(nn.Module):
             plan["keep"] = keep
         for i, (l, c) in enumerate(zip(layers, cfgs)):
             # activations produced by our own GEMMs are dense 16-B aligned rows; the network input is checked
-            l._split_now = l._split(x if i == 0 else None) and (i == 0 or layers[i - 1].out_features % 4 == 0)
+            l._split_now = l._split(x if i == 0 else None, c) if (i == 0 or layers[i - 1].out_features % 4 == 0) else 0
             keep.append(l._fill_desc(descs[i], c, kls[i] if c[1] else None))
         stream = torch.cuda.current_stream(dev).cuda_stream
         # flows that are not planar run first (K4 batched over the layers; 1-D chains per layer), then lbbnn_layers_operands
@@ -1195,6 +1244,7 @@ class _NetworkBase(nn.Module):
             defer_ev.record(side)
         all_kl = want_kl and all(c[1] for c in cfgs)
         fin_at = 1 if defer_ev is not None else 0
+        B, x_planes = x.shape[0], False
         for i, (l, c) in enumerate(zip(layers, cfgs)):
             # the KL finalize of all layers (parameters only) rides in the first GEMM's launch as one extra workgroup (in the
             # second's when part of the dense flows was deferred: it waits for the side stream first)
@@ -1205,10 +1255,20 @@ class _NetworkBase(nn.Module):
                 fin = (descs if want_kl else None, n if want_kl else 0, snap.data_ptr() if snap is not None else None,
                        kls[n:].data_ptr() if all_kl else None, rng.data_ptr() if rng is not None else None,
                        1 if rng is not None else 0)
+            # row-scaled fp16 layers hand their activations on as fp16 hi | lo PLANES (written by the GEMM epilogue, read by
+            # the next GEMM's LDS-DMA as they lie): no fp32 copy of a hidden activation is stored in this no-grad forward
+            fmt = l._split_now
+            give_planes = (fmt == 2 and i + 1 < n and layers[i + 1]._split_now == 2 and l.out_features % 8 == 0)
+            if fmt == 2 and i == 0 and _F16_FIRST_PLANES and not x_planes:
+                x = ops.format_x(x, self._planes("in", B, l.in_features, dev, plan))
+                x_planes = True
             obuf = None
-            if plan is not None:
-                obuf = plan.setdefault("out%d" % i, torch.empty(x.shape[0], l.out_features, dtype=torch.float32, device=dev))
-            x = l._gemm(x, c, snap, log_softmax=(i == n - 1 and l.out_features <= 16), finalize=fin, out=obuf)
+            if plan is not None and not give_planes:
+                obuf = plan.setdefault("out%d" % i, torch.empty(B, l.out_features, dtype=torch.float32, device=dev))
+            pbuf = self._planes(i, B, l.out_features, dev, plan) if give_planes else None
+            y = l._gemm(x, c, snap, log_softmax=(i == n - 1 and l.out_features <= 16), finalize=fin, out=obuf,
+                        x_planes=x_planes, out_planes=pbuf, want_out=not give_planes)
+            x, x_planes = (pbuf, True) if give_planes else (y, False)
         if layers[-1].out_features > 16:
             x = F.log_softmax(x, dim=1)
         for i, (l, c) in enumerate(zip(layers, cfgs)):

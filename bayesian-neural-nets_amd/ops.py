@@ -18,6 +18,9 @@ F_SPLIT16 = 0x4
 F_LOG_SOFTMAX = 0x8
 F_SINGLE16 = 0x10
 F_HALF16 = 0x20
+F_F16S = 0x40
+F_VAR1 = 0x80
+F_XPLANES = 0x100
 
 STREAM_EPS_OUT = 0
 STREAM_EPS_Z = 1
@@ -29,36 +32,58 @@ STREAM_MASK = 6
 STREAM_ROW_MASK = 7
 
 
-# GEMM arithmetic: "fp32" = exact fp32 MFMA path; "bf16x3" = split-precision path (bf16 hi/lo mean
-# products + bf16 variance product on the bf16 matrix cores, fp32 accumulation; ~1e-5 relative on the
-# layer output, inside the 1e-4 contract).  Layers fall back to fp32 where the split format does not apply.
+# GEMM arithmetic.  A name selects the operand FORMAT of the forward's dual-moment GEMM:
+#   "fp32"     exact fp32 MFMA (v_mfma_f32_16x16x4_f32): the reference's own precision
+#   "fp16x3"   row-scaled fp16 hi + lo operands, 3 + 3 products (LBBNN_F_F16S): 2-3e-8 of max|out| against fp64 -- tighter than an
+#              fp32-accumulate torch.mm; the contract-grade 16-bit mode
+#   "fp16x3f"  the same operands, ONE product for the variance GEMM (LBBNN_F_VAR1, 3 + 1): 1.4-1.8e-5 (contract 1e-4), 4 MFMAs
+#              per tile step instead of 6; x^2 from the fp16 planes by packed fp16 math
+#   "bf16x3"   bf16 hi + lo operands, 3 + 3 products (round 1-2 headline): 2.7e-6
+#   "bf16" / "fp16"   ONE product per moment: reduced-precision modes OUTSIDE the contract (2e-3 / 3e-4), own tolerances
+# The backward products and every mean-only product stay on the bf16x3 kernels whatever 16-bit mode is chosen.
+# The process-wide default below applies to every module that has no ``precision`` attribute of its own:
+# ``net.set_precision(name)`` (layers._NetworkBase) / ``layer.precision = name`` select per network / per layer.
+PRECISIONS = ("fp32", "bf16x3", "bf16", "fp16", "fp16x3", "fp16x3f")
 _PRECISION = "fp32"
 
 
 def set_precision(name: str):
+    """Process-wide DEFAULT precision (modules with their own ``precision`` attribute ignore it)."""
     global _PRECISION
-    if name not in ("fp32", "bf16x3", "bf16", "fp16"):
-        raise ValueError("precision must be 'fp32', 'bf16x3', 'bf16' or 'fp16'")
+    if name not in PRECISIONS:
+        raise ValueError("precision must be one of %s" % (PRECISIONS,))
     _PRECISION = name
 
 
-def get_precision() -> str:
+def get_precision(module=None) -> str:
+    """The precision in force for ``module`` (its own ``precision`` attribute if set, else the process default)."""
+    own = getattr(module, "precision", None) if module is not None else None
+    if own is not None:
+        if own not in PRECISIONS:
+            raise ValueError("precision must be one of %s" % (PRECISIONS,))
+        return own
     return _PRECISION
 
 
-def split_precision() -> bool:
-    """Do the GEMMs take 16-bit operand planes ('bf16x3': three products per moment, inside the 1e-4 contract; 'bf16': ONE
-    product per moment in the forward's dual-moment GEMM -- the plain bf16 MFMA arithmetic BASELINE configs[1] names, 2e-3
-    relative on the mean GEMM, a reduced-precision mode with its own tolerance; backward products stay bf16x3; 'fp16': the
-    same with ONE FP16 product per moment in the variational-dropout layer -- BASELINE configs[4]'s "fp16 MFMA", 3e-4 relative
-    -- and the bf16 form everywhere else: the LRT / MNF variance operands (~1e-5) sit in fp16's subnormal range unscaled)?"""
-    return _PRECISION in ("bf16x3", "bf16", "fp16")
+def split_precision(module=None) -> bool:
+    """Do the GEMMs of ``module`` take 16-bit operand planes (every mode but "fp32")?"""
+    return get_precision(module) != "fp32"
+
+
+def f16s_precision(module=None) -> bool:
+    return get_precision(module) in ("fp16x3", "fp16x3f")
 
 
 def split_eligible(I: int, O: int) -> bool:
     """Shapes the split-precision kernels accept (see lbbnn_lrt_gemm, LBBNN_F_SPLIT16); operands and x must also stay
     under 2 GiB each (32-bit buffer offsets), which the callers' batch sizes do by orders of magnitude."""
     return O > 16 and I % 8 == 0 and (I % 32 == 0 or operand_ld(I) - I >= 8) and O * operand_ld(I) * 4 < 0x7FFFFFF0
+
+
+def f16s_eligible(I: int, O: int) -> bool:
+    """Shapes the row-scaled fp16 format takes: what the split kernels take, and rows of at most 1280 weights (the weight
+    pass scales a row by its maximum, which it holds in registers: weight_pass.hip)."""
+    return split_eligible(I, O) and operand_ld(I) <= 1280
 
 
 def _stream() -> int:
@@ -151,10 +176,19 @@ def philox_normal(rng: torch.Tensor, stream_id: int, rows: int, cols: int, row_b
 # ----------------------------------------------------------------------------------------- K1
 def weight_pass(mu, rho, lambdal, *, z_fwd=None, z_kl=None, r0_c=None, bias_rho=None,
                 priors: Priors, e_w=None, var_w=None, kl_rows=None, act_mu=None, act_var=None,
-                bias_var=None, split: bool = False):
-    """lbbnn_weight_pass.  Output tensors are caller-allocated (see LayerWorkspace)."""
+                bias_var=None, split=False, e_scale=None, v_scale=None):
+    """lbbnn_weight_pass.  Output tensors are caller-allocated (see LayerWorkspace).  split: False / 0 fp32 operands,
+    True / 1 bf16 hi | lo, 2 row-scaled fp16 hi | lo (lbbnn_weight_pass_f16: e_scale / v_scale (O) receive the row scales)."""
     O, I = mu.shape
     ld = operand_ld(I)
+    if int(split) == 2:
+        rc = _lib.lib().lbbnn_weight_pass_f16(
+            _ptr(mu, "weight_mu"), _ptr(rho, "weight_rho"), _ptr(lambdal, "lambdal"),
+            _ptr(z_fwd), _ptr(z_kl), _ptr(r0_c), _ptr(bias_rho), ctypes.byref(priors),
+            _ptr(e_w), _ptr(var_w), ld, _ptr(e_scale, "e_scale"), _ptr(v_scale, "v_scale"),
+            _ptr(kl_rows), _ptr(act_mu), _ptr(act_var), _ptr(bias_var), O, I, _stream())
+        _lib.check(rc, "lbbnn_weight_pass_f16")
+        return
     rc = _lib.lib().lbbnn_weight_pass(
         _ptr(mu, "weight_mu"), _ptr(rho, "weight_rho"), _ptr(lambdal, "lambdal"),
         _ptr(z_fwd), _ptr(z_kl), _ptr(r0_c), _ptr(bias_rho), ctypes.byref(priors),
@@ -286,8 +320,9 @@ def lrt_gemm(x, e_w, var_w, *, I: int, O: int, bias_mean=None, bias_var=None, va
              eps=None, rng: Optional[torch.Tensor] = None, rng_stream: int = 0, row_offset: int = 0,
              relu: bool = False, mean_only: bool = False, log_softmax: bool = False,
              split: bool = False, out: Optional[torch.Tensor] = None, std_out: Optional[torch.Tensor] = None,
-             finalize=None, half: bool = False):
+             finalize=None, half: bool = False, single: Optional[bool] = None):
     """lbbnn_lrt_gemm: out = x.e_w^T + b [+ sqrt(x^2.var_w^T + bv) * eps] [ReLU].
+    single: ONE 16-bit product per moment (the reduced "bf16" / "fp16" modes; default: what the process-wide precision says).
     finalize = (layer descriptors, n, rng pointer for K5, kl_total pointer[, live rng pointer, advance]):
     lbbnn_lrt_gemm_finalize_adv -- the KL finalize of the whole network (n may be 0) and the forward's RNG advance ride in
     this launch."""
@@ -300,7 +335,7 @@ def lrt_gemm(x, e_w, var_w, *, I: int, O: int, bias_mean=None, bias_var=None, va
         raise RuntimeError("bnn_amd: eps must be (%d,%d), got %s" % (B, O, tuple(eps.shape)))
     flags = ((F_RELU if relu else 0) | (F_MEAN_ONLY if mean_only else 0) | (F_LOG_SOFTMAX if log_softmax else 0)
              | (F_SPLIT16 if split else 0)
-             | (F_SINGLE16 if (split and not mean_only and _PRECISION in ("bf16", "fp16")) else 0)
+             | (F_SINGLE16 if (split and not mean_only and (single if single is not None else _PRECISION in ("bf16", "fp16"))) else 0)
              | (F_HALF16 if (half and split and not mean_only) else 0))
     if B == 0 and finalize is None:    # empty batch: (0,O) activations, as torch.mm gives; the KL side is unaffected
         return out
@@ -335,6 +370,71 @@ def lrt_gemm(x, e_w, var_w, *, I: int, O: int, bias_mean=None, bias_var=None, va
         ev[1].record()
         GEMM_EVENTS.append((B, I, O, ev[0], ev[1]))
     return out
+
+
+def plane_ld(n: int) -> int:
+    return operand_ld(n)
+
+
+def format_x(x, planes=None):
+    """lbbnn_format_x: fp32 rows (B, I) -> fp16 hi | lo planes, a (B, plane_ld(I)) fp32-sized buffer (tail zero)."""
+    B, I = x.shape
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    if planes is None:
+        planes = torch.empty((B, plane_ld(I)), dtype=torch.float32, device=x.device)
+    rc = _lib.lib().lbbnn_format_x(_ptr_rows(x, "input"), x.stride(0), planes.data_ptr(), planes.stride(0), B, I, _stream())
+    _lib.check(rc, "lbbnn_format_x")
+    return planes
+
+
+def lrt_gemm16(x, e_w, var_w, e_scale, v_scale, *, I: int, O: int, bias_mean=None, bias_var=None, var_scale=None,
+               eps=None, rng: Optional[torch.Tensor] = None, rng_stream: int = 0, row_offset: int = 0, relu: bool = False,
+               var1: bool = False, x_planes: bool = False, out: Optional[torch.Tensor] = None, want_out: bool = True,
+               out_planes: Optional[torch.Tensor] = None, std_out: Optional[torch.Tensor] = None, finalize=None):
+    """lbbnn_lrt_gemm_ex on LBBNN_F_F16S operands: the dual-moment GEMM + sampling epilogue of lrt_gemm in the row-scaled fp16
+    format.  x: fp32 rows (B, I), or with ``x_planes`` the (B, plane_ld(I)) plane buffer a previous call / format_x wrote.
+    Outputs: fp32 ``out`` (allocated unless ``want_out`` is False) and / or ``out_planes`` (B, plane_ld(O)) for the next layer.
+    ``finalize`` as in lrt_gemm.  Returns (out or None, out_planes or None)."""
+    B = x.shape[0]
+    if x_planes:
+        if x.dim() != 2 or x.shape[1] != plane_ld(I) or x.stride(1) != 1:
+            raise RuntimeError("bnn_amd: x planes must be (B,%d), got %s" % (plane_ld(I), tuple(x.shape)))
+    elif x.dim() != 2 or x.shape[1] != I:
+        raise RuntimeError("bnn_amd: input must be (B,%d), got %s" % (I, tuple(x.shape)))
+    if out is None and want_out:
+        out = torch.empty((B, O), dtype=torch.float32, device=x.device)
+    if eps is not None and tuple(eps.shape) != (B, O):
+        raise RuntimeError("bnn_amd: eps must be (%d,%d), got %s" % (B, O, tuple(eps.shape)))
+    if B == 0 and finalize is None:
+        return out, out_planes
+    if x.stride(1) != 1 or (x.stride(0) < x.shape[1]):
+        x = x.contiguous()
+    d = _lib.GemmDesc()
+    d.x, d.ldx = _ptr_rows(x, "input"), x.stride(0)
+    d.e_w, d.var_w, d.ld = _ptr(e_w), _ptr(var_w), operand_ld(I)
+    d.mean_scale, d.wvar_scale = _ptr(e_scale, "e_scale"), _ptr(v_scale, "v_scale")
+    d.bias_mean, d.bias_var, d.var_scale, d.eps = _ptr(bias_mean), _ptr(bias_var), _ptr(var_scale), _ptr(eps, "eps")
+    d.rng = rng.data_ptr() if rng is not None else None
+    d.rng_stream, d.row_offset = rng_stream, row_offset
+    d.out, d.ldo = (out.data_ptr(), out.stride(0)) if out is not None else (None, 0)
+    d.out_planes, d.ldp = (out_planes.data_ptr(), out_planes.stride(0)) if out_planes is not None else (None, 0)
+    d.std_out = _ptr(std_out, "std_out")
+    d.B, d.I, d.O = B, I, O
+    d.flags = F_F16S | (F_RELU if relu else 0) | (F_VAR1 if var1 else 0) | (F_XPLANES if x_planes else 0)
+    if finalize is not None:
+        live, adv = (finalize[4], finalize[5]) if len(finalize) > 4 else (None, 0)
+        d.layers = finalize[0] if finalize[0] is not None else None
+        d.n_layers, d.fin_rng, d.kl_total, d.rng_live, d.advance = finalize[1], finalize[2], finalize[3], live, adv
+    ev = GEMM_EVENTS.take() if GEMM_EVENTS is not None else None
+    if ev is not None:
+        ev[0].record()
+    rc = _lib.lib().lbbnn_lrt_gemm_ex(ctypes.byref(d), _stream())
+    _lib.check(rc, "lbbnn_lrt_gemm_ex")
+    if ev is not None:
+        ev[1].record()
+        GEMM_EVENTS.append((B, I, O, ev[0], ev[1]))
+    return out, out_planes
 
 
 def lrt_gemm_combine(a, op, *, K: int, N: int, comb_x, comb_add, split: bool = False):
@@ -702,6 +802,8 @@ class LayerWorkspace:
         self.var_w = torch.empty((O, ld), **f)
         self.kl_rows = torch.empty(O, **f)
         self.bias_var = torch.empty(O, **f)
+        self.e_scale = torch.ones(O, **f)          # LBBNN_F_F16S row scales (written by the weight pass)
+        self.v_scale = torch.ones(O, **f)
         self.kl = torch.zeros((), **f)
         self._bw = None
         if mnf:

@@ -262,7 +262,8 @@ typedef struct lbbnn_layer_desc {
     uint32_t layer_id;
     int stochastic;          /* produce var_w (training or sample)            */
     int want_kl;             /* training or calculate_log_probs               */
-    int split;               /* operands in split-precision format (LBBNN_F_SPLIT16) */
+    int split;               /* operand format: 0 fp32; 1 bf16 hi + lo (LBBNN_F_SPLIT16); 2 fp16 hi + lo with per-row power-of-two
+                                scales (LBBNN_F_F16S: needs e_scale / v_scale below, rows of at most 1280 weights) */
     /* explicit draws; NULL => Philox from rng */
     const float *eps_z, *eps_z2, *eps_act;
     /* caller-owned workspace */
@@ -272,6 +273,9 @@ typedef struct lbbnn_layer_desc {
     float* kl_layer;                             /* 1 float: this layer's KL     */
     int flows_done;          /* nonzero: z_fwd / z_kl / scal were already produced by the caller (lbbnn_layers_dense_flows,
                                 lbbnn_flow_chain): lbbnn_layers_operands then runs K1 only for this layer */
+    /* split == 2 (LBBNN_F_F16S operands): per-output-feature accumulator scales written by K1, (O) floats each, exact
+       powers of two: e_w row o holds fp16 hi + lo of e_w[o,:] / e_scale[o], var_w row o of var_w[o,:] / v_scale[o] */
+    float *e_scale, *v_scale;
 } lbbnn_layer_desc_t;
 
 int lbbnn_layers_prepare(const lbbnn_layer_desc_t* layers, int n, const uint64_t* rng, void* stream);
@@ -728,6 +732,65 @@ int lbbnn_mnf_flow_dense_backward(const lbbnn_dense_bwd_args_t* args, void* stre
  * network's worth takes about the time of one layer.  The layers must agree on Tz, Tr and on having a KL branch
  * (LBBNN_E_SHAPE otherwise), and all of their inputs must be ready: defer the chains to the end of the backward pass. */
 int lbbnn_mnf_flow_dense_backward_batch(const lbbnn_dense_bwd_args_t* args, int n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Round 3: the row-scaled FP16 operand format (LBBNN_F_F16S) and the descriptor form of the dual-moment GEMM.
+ *
+ * Arithmetic (replaces the same reference lines as lbbnn_lrt_gemm: LBBNN-GP-MF-LRT.py:172-175, LBBNN-GP-MF-MNF.py:197-200):
+ *   every operand value w is held as hi + lo, both IEEE fp16, products on v_mfma_f32_16x16x32_f16, fp32 accumulate:
+ *     mean = x.e_w^T    as xh.eh + xh.el + xl.eh                      (the dropped xl.el term is 2^-22 relative)
+ *     var  = x^2.var_w^T as sh.vh + sh.vl + sl.vh, s = x^2 * 2^-8     (LBBNN_F_VAR1: sh.vh alone, sh = RNE16(s))
+ *   fp16 has 5 exponent bits, so the weight operands carry one exact power-of-two scale per output row (e_scale[o],
+ *   v_scale[o]: the row maximum lands in [2^13, 2^14)) which the epilogue takes out of the accumulators again, and x^2 is
+ *   formed from x * 2^-4 (fp16 overflows at 65504: the format holds |x| < 4096; a producer that sees a larger activation
+ *   poisons its output with NaN rather than saturating silently -- `range_guard`).
+ *   Measured against fp64 on the headline layers (tools/format_error.py): 3 + 3 products 2.3-3.0e-8 of max|out| (an fp32
+ *   accumulate of exact products, torch.mm, gives 1-3e-7), 3 + 1 products 1.4-1.8e-5 (contract: 1e-4).
+ *
+ * Layout: a weight row is the 128-B-line form of LBBNN_F_SPLIT16 (lbbnn_device.h) with fp16 values.  x may be given
+ *   - as fp32 rows (the network input): split in registers by the consumer, or
+ *   - as PLANES (LBBNN_F_XPLANES): rows of ldx fp32-sized slots, per 32-k chunk one 128-B line of units
+ *     (xh k0-7 | xl k0-7 | xh k8-15 | xl k8-15 | ...), ldx a multiple of 32, tail k >= I zero -- what this GEMM writes
+ *     to `out_planes` for the next layer (ReLU applied) and what lbbnn_format_x makes from fp32 rows.  A consumer of
+ *     planes spends 4 packed-fp16 instructions per 2 k on x^2 and none on the split.
+ */
+#define LBBNN_F_F16S 0x40      /* operands in the row-scaled fp16 hi + lo format (mean_scale / wvar_scale required) */
+#define LBBNN_F_VAR1 0x80      /* with LBBNN_F_F16S: ONE product for the variance GEMM (3 + 1 products per tile step)  */
+#define LBBNN_F_XPLANES 0x100  /* with LBBNN_F_F16S: x is given as fp16 hi | lo planes                                */
+
+typedef struct lbbnn_gemm_desc {
+    const void* x; int ldx;                      /* (B, I): fp32 rows of ldx floats, or planes (ldx fp32-sized slots per row) */
+    const void* e_w; const void* var_w; int ld;  /* [O][ld] operands from lbbnn_layers_operands (split == 2) / lbbnn_weight_pass_f16 */
+    const float* mean_scale;                     /* (O) e_scale  */
+    const float* wvar_scale;                     /* (O) v_scale  */
+    const float* bias_mean;                      /* (O) or NULL  */
+    const float* bias_var;                       /* (O) or NULL  */
+    const float* var_scale;                      /* (O) or NULL: extra per-feature factor on the variance product */
+    const float* eps;                            /* (B, O) explicit N(0,1) draws, or NULL => Philox(rng)          */
+    const uint64_t* rng; uint32_t rng_stream; int64_t row_offset;
+    float* out; int ldo;                         /* (B, O) fp32 output, or NULL when only planes are wanted       */
+    void* out_planes; int ldp;                   /* (B, ldp) plane rows for the next layer, or NULL; needs O % 8 == 0, ldp % 32 == 0 */
+    float* std_out;                              /* (B, O) sqrt(var) for the backward pass, or NULL               */
+    int B, I, O, flags;                          /* LBBNN_F_RELU | LBBNN_F_F16S | LBBNN_F_VAR1 | LBBNN_F_XPLANES   */
+    /* optional KL finalize of a network carried by one extra workgroup (as lbbnn_lrt_gemm_finalize_adv) */
+    const lbbnn_layer_desc_t* layers; int n_layers; const uint64_t* fin_rng; float* kl_total;
+    uint64_t* rng_live; uint64_t advance;
+} lbbnn_gemm_desc_t;
+
+int lbbnn_lrt_gemm_ex(const lbbnn_gemm_desc_t* d, void* stream);
+
+/* fp32 rows -> fp16 hi | lo planes (the x format above); I % 8 == 0, x 16-B aligned rows, ldp % 32 == 0, ldp >= I.
+ * Writes the whole row of planes (tail slots zero). */
+int lbbnn_format_x(const float* x, int ldx, void* planes, int ldp, int B, int I, void* stream);
+
+/* lbbnn_weight_pass producing LBBNN_F_F16S operands + their row scales (single layer; the batched form is
+ * lbbnn_layers_operands with split == 2). */
+int lbbnn_weight_pass_f16(const float* mu, const float* rho, const float* lambdal,
+                          const float* z_fwd, const float* z_kl, const float* r0_c,
+                          const float* bias_rho, const lbbnn_priors_t* priors,
+                          void* e_w, void* var_w, int ld, float* e_scale, float* v_scale,
+                          float* kl_rows, float* act_mu, float* act_var, float* bias_var,
+                          int O, int I, void* stream);
 
 #ifdef __cplusplus
 }

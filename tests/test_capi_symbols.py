@@ -69,7 +69,8 @@ def test_ctypes_struct_layouts_match_the_header(tmp_path):
     import subprocess
     from bnn_amd import _lib
     pairs = [("lbbnn_priors_t", _lib.Priors, "bias_sigma_prior"), ("lbbnn_planar_flow_t", _lib.PlanarFlow, "T"),
-             ("lbbnn_layer_desc_t", _lib.LayerDesc, "flows_done"), ("lbbnn_dense_transform_t", _lib.DenseTransform, "mask_kl"),
+             ("lbbnn_layer_desc_t", _lib.LayerDesc, "v_scale"), ("lbbnn_gemm_desc_t", _lib.GemmDesc, "advance"),
+             ("lbbnn_dense_transform_t", _lib.DenseTransform, "mask_kl"),
              ("lbbnn_gate_args_t", _lib.GateArgs, None), ("lbbnn_wpb_args_t", _lib.WpbArgs, None),
              ("lbbnn_adam_list_t", _lib.AdamList, None), ("lbbnn_copy_list_t", _lib.CopyList, None),
              ("lbbnn_dense_layer_t", _lib.DenseLayer, "draw_masks"), ("lbbnn_dense_grad_t", _lib.DenseGrad, "b_b"),
@@ -117,3 +118,36 @@ def test_new_entry_points_argument_checks(lib):
     assert lib.lbbnn_layers_dense_flows_phase((_lib.DenseLayer * 1)(), 1, None, -1, None) == -4
     assert lib.lbbnn_layers_dense_flows_phase(None, 1, None, 1, None) == -1
     assert lib.lbbnn_layers_dense_flows_phase((_lib.DenseLayer * 1)(), 0, None, 2, None) == -2
+
+
+def test_round3_entry_points_argument_checks(lib):
+    """lbbnn_lrt_gemm_ex / lbbnn_format_x / lbbnn_weight_pass_f16: early argument checks (nothing is launched)."""
+    from bnn_amd import _lib
+    fake = ctypes.c_void_p(4096)
+    assert lib.lbbnn_lrt_gemm_ex(None, None) == -1
+    d = _lib.GemmDesc()
+    d.flags = 0x4                                           # not the fp16 format: the descriptor form refuses
+    assert lib.lbbnn_lrt_gemm_ex(ctypes.byref(d), None) == -4
+    d.flags = 0x40
+    d.B, d.I, d.O = 4, 64, 80
+    assert lib.lbbnn_lrt_gemm_ex(ctypes.byref(d), None) == -1          # no operands
+    for name in ("x", "e_w", "var_w", "mean_scale", "wvar_scale", "out", "eps"):
+        setattr(d, name, 4096)
+    d.ldx, d.ld, d.ldo = 64, 64, 80
+    d.O = 10
+    assert lib.lbbnn_lrt_gemm_ex(ctypes.byref(d), None) == -2          # the 10-class head is not this kernel's
+    d.O, d.ld = 80, 60
+    assert lib.lbbnn_lrt_gemm_ex(ctypes.byref(d), None) == -3
+    d.ld, d.flags, d.ldx = 64, 0x40 | 0x100, 80                        # planes: ldx must be a multiple of 32
+    assert lib.lbbnn_lrt_gemm_ex(ctypes.byref(d), None) == -3
+    d.flags, d.ldx, d.eps = 0x40, 64, None
+    assert lib.lbbnn_lrt_gemm_ex(ctypes.byref(d), None) == -5          # neither eps nor rng
+    assert lib.lbbnn_format_x(None, 64, fake, 64, 4, 64, None) == -1
+    assert lib.lbbnn_format_x(fake, 64, fake, 48, 4, 64, None) == -2
+    assert lib.lbbnn_format_x(fake, 64, fake, 96, 4, 60, None) == -3   # I % 8
+    assert lib.lbbnn_format_x(fake, 64, fake, 64, 0, 64, None) == 0    # empty batch
+    pr = _lib.Priors()
+    assert lib.lbbnn_weight_pass_f16(fake, fake, fake, None, None, None, None, ctypes.byref(pr), fake, fake, 64, None, fake,
+                                     None, None, None, None, 4, 64, None) == -1      # operands without their scale arrays
+    assert lib.lbbnn_weight_pass_f16(fake, fake, fake, None, None, None, None, ctypes.byref(pr), fake, fake, 2048, fake, fake,
+                                     None, None, None, None, 4, 2048, None) == -2    # rows longer than one register batch
