@@ -174,7 +174,7 @@ SIGNATURES = {
     "lbbnn_weight_pass": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.POINTER(Priors),
                                 c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "lbbnn_weight_pass_f16": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.POINTER(Priors),
-                                    c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
+                                    c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "lbbnn_lrt_gemm_ex": (c_i, [ctypes.POINTER(GemmDesc), c_p]),
     "lbbnn_format_x": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_p]),
     "lbbnn_lrt_gemm": (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_u32, c_i64,

@@ -16,7 +16,8 @@ struct WeightPassArgs {
     float* e_w; float* var_w;
     float* kl_rows; float* act_mu; float* act_var; float* bias_var;
     int O, I, ld, vec;
-    int split;      // 0: fp32 [O][ld]; 1: bf16 hi | lo units (lbbnn_device.h); 2: fp16 hi | lo units of the row-scaled values
+    int split;      // 0: fp32 [O][ld]; 1: bf16 hi | lo units (lbbnn_device.h); 2: fp16 hi | lo units of the row-scaled values;
+                    // 3: as 2 for e_w, var_w as plain fp16 rows of ld halves (the hi part alone: LBBNN_F_VAR1 operands)
     float* e_scale; float* v_scale;      // split == 2: (O) inverse row scales written by the row kernel
     float mu_prior, sigma_prior, alpha_prior;
     float log_sp, log_ap, log_1map, inv_2sp2;     // host-precomputed prior constants

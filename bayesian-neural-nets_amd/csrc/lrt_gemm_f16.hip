@@ -43,6 +43,9 @@ constexpr float kS2 = 0.00390625f;          // 2^-8: the fixed scale of the x^2 
 constexpr float kS2inv = 256.f;
 
 __device__ __forceinline__ int swzx(int r) { return (((r >> 1) & 3) << 1) | ((r >> 3) & 1); }
+// 64-B rows (the hi-only var_w region of the 3 + 1 form): slot s of row r is stored at s ^ F[(r >> 2) & 3], F = {0, 2, 3, 1} --
+// the conflict-free map of the fp32 LDS-DMA kernel (lrt_gemm.hip), whose image has the same shape (16 rows x 64 B per piece)
+__device__ __forceinline__ int swz4(int rowgrp) { return (0x78 >> (2 * (rowgrp & 3))) & 3; }
 
 struct G16Args {
     const char* x; const char* e_w; const char* var_w;
@@ -186,8 +189,12 @@ template <int TO, int TB, int WB, int NPV, bool XPL>
 __device__ __forceinline__ void gemm_f16s_body(const G16Args& a) {
     static_assert(NPV == 1 || NPV == 3, "one or three variance products");
     constexpr int BN = TO * 16, BM = TB * WB * 16;
-    constexpr int XB = BM * 128, WRB = BN * 128, BUFB = XB + 2 * WRB;
-    constexpr int NGX = BM / 8, NGW = BN / 8, NG = NGX + 2 * NGW, NPW = (NG + WB - 1) / WB;
+    // LDS image of one K step: X BM rows x 128 B | E BN rows x 128 B (hi | lo units) | V: BN rows x 128 B (NPV == 3), or
+    // BN rows x 64 B = the hi parts alone, a plain fp16 matrix in memory (NPV == 1: a quarter fewer weight bytes per step)
+    constexpr int VROW = NPV == 1 ? 64 : 128;
+    constexpr int XB = BM * 128, WRB = BN * 128, VRB = BN * VROW, BUFB = XB + WRB + VRB;
+    constexpr int NGX = BM / 8, NGW = BN / 8, NGV = VRB / 1024, NG = NGX + NGW + NGV, NPW = (NG + WB - 1) / WB;
+    static_assert(VRB % 1024 == 0, "whole 1-KiB pieces");
     extern __shared__ __attribute__((aligned(16))) char smc[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -209,7 +216,7 @@ __device__ __forceinline__ void gemm_f16s_body(const G16Args& a) {
     const unsigned wbytes = (unsigned)min((size_t)0x7FFFFFF0u, (size_t)a.O * a.ld * 4);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc((void*)a.e_w, 0, (int)wbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)a.var_w, 0, (int)wbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)a.var_w, 0, (int)(NPV == 1 ? wbytes / 2 : wbytes), 0x00020000);
     int gv[NPW], kx[NPW];
 #pragma unroll
     for (int u = 0; u < NPW; ++u) {
@@ -219,10 +226,15 @@ __device__ __forceinline__ void gemm_f16s_body(const G16Args& a) {
             const int slot = (lane & 7) ^ swzx(row & 15);
             gv[u] = (int)((size_t)min(b0 + row, a.B - 1) * a.ldx * 4) + 16 * slot;
             kx[u] = XPL ? -1 : 4 * slot;
-        } else {
+        } else if (g < NGX + NGW || NPV == 3) {
             const int gw = g - NGX, row = 8 * (gw % NGW) + (lane >> 3);
             const int slot = (lane & 7) ^ swzx(row & 15);
             gv[u] = (int)((size_t)min(o0 + row, a.O - 1) * a.ld * 4) + 16 * slot;
+            kx[u] = -1;
+        } else {
+            const int gw = g - NGX - NGW, row = 16 * gw + (lane >> 2);                   // hi-only var_w: 16 rows x 64 B per piece
+            const int slot = (lane & 3) ^ swz4(row >> 2);
+            gv[u] = (int)((size_t)min(o0 + row, a.O - 1) * a.ld * 2) + 16 * slot;
             kx[u] = -1;
         }
     }
@@ -241,7 +253,7 @@ __device__ __forceinline__ void gemm_f16s_body(const G16Args& a) {
                 auto* dst = (__attribute__((address_space(3))) void*)(buf + loff);
                 if (g < NGX)                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, dst, 16, va[u], c * 128, 0, 0);
                 else if (g - NGX < NGW)      __builtin_amdgcn_raw_ptr_buffer_load_lds(re, dst, 16, va[u], c * 128, 0, 0);
-                else                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, dst, 16, va[u], c * 128, 0, 0);
+                else                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, dst, 16, va[u], c * VROW, 0, 0);
             }
         }
     };
@@ -261,6 +273,7 @@ __device__ __forceinline__ void gemm_f16s_body(const G16Args& a) {
     const int xo1 = (wv * TB * 16 + lr) * 128 + 16 * ((2 * q + 1) ^ gx);
     const int woh = XB + lr * 128 + 16 * ((2 * q) ^ gx);
     const int wol = XB + lr * 128 + 16 * ((2 * q + 1) ^ gx);
+    const int vo1 = XB + WRB + lr * 64 + 16 * (q ^ swz4(lr >> 2));        // NPV == 1: row lr of the 64-B-row V region, unit q
 
     uint4 xu[TB][2];
     uint4 eh[TO], el[TO], vh[TO], vl[TO];
@@ -274,8 +287,12 @@ __device__ __forceinline__ void gemm_f16s_body(const G16Args& a) {
         for (int i = 0; i < TO; ++i) {
             eh[i] = *reinterpret_cast<const uint4*>(cur + woh + i * 16 * 128);
             el[i] = *reinterpret_cast<const uint4*>(cur + wol + i * 16 * 128);
-            vh[i] = *reinterpret_cast<const uint4*>(cur + WRB + woh + i * 16 * 128);
-            if (NPV == 3) vl[i] = *reinterpret_cast<const uint4*>(cur + WRB + wol + i * 16 * 128);
+            if (NPV == 3) {
+                vh[i] = *reinterpret_cast<const uint4*>(cur + WRB + woh + i * 16 * 128);
+                vl[i] = *reinterpret_cast<const uint4*>(cur + WRB + wol + i * 16 * 128);
+            } else {
+                vh[i] = *reinterpret_cast<const uint4*>(cur + vo1 + i * 16 * 64);
+            }
         }
     };
     auto mfmas = [&]() {
@@ -341,6 +358,10 @@ __device__ __forceinline__ void gemm_f16s_body(const G16Args& a) {
         }
     };
 
+    // (Measured and dropped, round 3: drawing the noise of accumulator tile c INSIDE K step c < 8 -- Philox in the shadow of the
+    // step's MFMAs, the VALU port being idle four cycles out of five in this loop -- bit-identical outputs, no spills at 8
+    // tiles, and 0.1499 ms per forward against 0.1473: a wave issues in order, so the 140 instructions lengthen ITS chain of
+    // the step by what the epilogue saves, and the chain of a wave, not the occupancy of a pipe, is what a step costs.)
     dma_step(0, smc);
     __syncthreads();
     for (int c = 0; c < nsteps; ++c) {
@@ -365,7 +386,7 @@ int launch16(G16Args& a, int npv, bool xpl, hipStream_t s, bool* hosted) {
     constexpr int BN = TO * 16, BM = TB * WB * 16;
     dim3 grid((a.O + BN - 1) / BN, (a.B + BM - 1) / BM, 1), block(WB * 64);
     const long nblocks = (long)grid.x * grid.y;
-    const size_t lds = lds_request(2u * (BM * 128 + 2 * BN * 128), nblocks);
+    const size_t lds = lds_request(2u * (BM * 128 + BN * 128 + BN * (npv == 1 ? 64 : 128)), nblocks);
     const int fin_n = a.fin.n;
     a.fin.n = 0;
     if (fin_n > 0 && hosted) {

@@ -45,8 +45,8 @@ static int layers_prepare_impl(const lbbnn_layer_desc_t* L, int n, const uint64_
                                              d.e_w, d.stochastic ? d.var_w : nullptr, lbbnn_operand_ld(d.I),
                                              d.want_kl ? d.kl_rows : nullptr,
                                              (mnf && d.want_kl) ? d.act_mu : nullptr, (mnf && d.want_kl) ? d.act_var : nullptr,
-                                             d.bias_var, d.O, d.I, d.split, d.split == 2 ? d.e_scale : nullptr,
-                                             d.split == 2 ? d.v_scale : nullptr);
+                                             d.bias_var, d.O, d.I, d.split, d.split >= 2 ? d.e_scale : nullptr,
+                                             d.split >= 2 ? d.v_scale : nullptr);
         if (rc) return rc;
         if (d.want_kl) {
             FinalizeArgs& k = ka[nk++];
@@ -128,7 +128,7 @@ extern "C" int lbbnn_ensemble_operands(const lbbnn_layer_desc_t* L, int n, int m
         const int rc = make_weight_pass_args(wa[i], d.weight_mu, d.weight_rho, d.lambdal, mnf ? d.z_fwd : nullptr, nullptr,
                                              nullptr, d.bias_rho, &d.priors, d.e_w, d.var_w, ld, nullptr, nullptr, nullptr,
                                              d.bias_var, d.O, d.I, d.split == 1 ? 1 : 0);
-        if (d.split == 2) return LBBNN_E_FLAGS;
+        if (d.split >= 2) return LBBNN_E_FLAGS;
         if (rc) return rc;
         if (!wa[i].vec || wa[i].ld > 2048) return LBBNN_E_ALIGN;
     }

@@ -480,7 +480,8 @@ __global__ __launch_bounds__(256, 3) void weight_rows_kernel(const WeightRowsBat
     // G <= kRowB for EVERY layer of such a launch (one batch), and every row keeps its operands in registers until the row
     // maxima are known -- the other layers of the launch (the fp32 10-class head) store theirs from the same place, so the
     // loop below has one shape per instantiation
-    const bool f16s = F16S && a.split == 2;
+    const bool f16s = F16S && a.split >= 2;
+    const bool vhi_only = a.split == 3;               // LBBNN_F_VAR1 operands: var_w = plain fp16 rows (the hi part alone)
     float4 ew_keep[F16S ? kRowB : 1], vw_keep[F16S ? kRowB : 1];
     for (int g0 = 0; g0 < G; g0 += kRowB) {
         float4 mu[kRowB], rho[kRowB], lam[kRowB];
@@ -574,7 +575,13 @@ __global__ __launch_bounds__(256, 3) void weight_rows_kernel(const WeightRowsBat
                 const uint4 unit = make_uint4(odd ? r0 : hi.x, odd ? r1 : hi.y, odd ? lo.x : r0, odd ? lo.y : r1);
                 if (ewp && j < nq) *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(ewp) + at) = unit;
             }
-            if (vwp) {
+            if (vwp && vhi_only) {
+                // one RNE fp16 value per weight, row-major with a row stride of P halves: 8 B per lane, a wave-store covers
+                // 512 B contiguous (32 k x 2 B = the 64-B row of one K step in the GEMM's LDS image)
+                const float4 w = vw_keep[g];
+                if (j < nq) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(vwp) + (size_t)o * P + 4 * j) =
+                    make_uint2(cvt_pk_h(w.x * sv, w.y * sv), cvt_pk_h(w.z * sv, w.w * sv));
+            } else if (vwp) {
                 const float4 w = vw_keep[g];
                 if (f16s) split4_h(make_float4(w.x * sv, w.y * sv, w.z * sv, w.w * sv), hi, lo);
                 else split4(w, hi, lo);
@@ -613,8 +620,8 @@ int make_weight_pass_args(WeightPassArgs& a, const float* mu, const float* rho, 
                           float* kl_rows, float* act_mu, float* act_var, float* bias_var, int O, int I, int split,
                           float* e_scale, float* v_scale) {
     if (!mu || !rho || !lambdal || !priors) return LBBNN_E_NULL;
-    if (split == 2 && ((e_w && !e_scale) || (var_w && !v_scale))) return LBBNN_E_NULL;
-    if (split < 0 || split > 2) return LBBNN_E_FLAGS;
+    if (split >= 2 && ((e_w && !e_scale) || (var_w && !v_scale))) return LBBNN_E_NULL;
+    if (split < 0 || split > 3) return LBBNN_E_FLAGS;
     if (O <= 0 || I <= 0) return LBBNN_E_SHAPE;
     if ((e_w || var_w) && (ld < I || (ld & 31))) return LBBNN_E_ALIGN;
     if ((act_mu == nullptr) != (act_var == nullptr)) return LBBNN_E_NULL;
@@ -635,7 +642,7 @@ int make_weight_pass_args(WeightPassArgs& a, const float* mu, const float* rho, 
              (!z_fwd || aligned16(z_fwd)) && (!z_kl || aligned16(z_kl)) && (!r0_c || aligned16(r0_c))) ? 1 : 0;
     if (split && !a.vec) return LBBNN_E_ALIGN;          // split operands need the vector path (I % 4 == 0, aligned)
     // the row-scaled fp16 format needs the whole row in one batch of the row kernel (the scale is the row maximum's)
-    if (split == 2 && a.ld > 64 * 4 * 5) return LBBNN_E_SHAPE;
+    if (split >= 2 && a.ld > 64 * 4 * 5) return LBBNN_E_SHAPE;
     return 0;
 }
 
@@ -668,7 +675,7 @@ int launch_weight_pass(const WeightPassArgs* a, int n, hipStream_t s, uint64_t* 
     static const bool rows_allowed = [] { const char* e = getenv("LBBNN_K1_ROWS"); return !(e && e[0] == '0'); }();
     rows_ok = rows_ok && rows_allowed;
     bool any_f16 = false;
-    for (int i = 0; i < n; ++i) any_f16 = any_f16 || a[i].split == 2;
+    for (int i = 0; i < n; ++i) any_f16 = any_f16 || a[i].split >= 2;
     if (any_f16) {
         for (int i = 0; i < n; ++i) if (!a[i].vec || a[i].ld > 64 * 4 * kRowB) return LBBNN_E_SHAPE;   // every layer: one batch
         if (members > 1) return LBBNN_E_FLAGS;               // (the ensemble's member dimension keeps the bf16 format)
@@ -717,10 +724,12 @@ extern "C" int lbbnn_weight_pass_f16(const float* mu, const float* rho, const fl
                                      const float* bias_rho, const lbbnn_priors_t* priors,
                                      void* e_w, void* var_w, int ld, float* e_scale, float* v_scale,
                                      float* kl_rows, float* act_mu, float* act_var, float* bias_var,
-                                     int O, int I, void* stream) {
+                                     int O, int I, int flags, void* stream) {
+    if (flags & ~LBBNN_F_VAR1) return LBBNN_E_FLAGS;
     lbbnn::WeightPassArgs a;
     const int rc = lbbnn::make_weight_pass_args(a, mu, rho, lambdal, z_fwd, z_kl, r0_c, bias_rho, priors, e_w, var_w, ld,
-                                                kl_rows, act_mu, act_var, bias_var, O, I, 2, e_scale, v_scale);
+                                                kl_rows, act_mu, act_var, bias_var, O, I, (flags & LBBNN_F_VAR1) ? 3 : 2,
+                                                e_scale, v_scale);
     if (rc) return rc;
     return lbbnn::launch_weight_pass(&a, 1, static_cast<hipStream_t>(stream));
 }

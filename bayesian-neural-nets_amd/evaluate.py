@@ -57,7 +57,8 @@ def ensemble_forward_batched(net, data: torch.Tensor, samples: int = 10) -> torc
     keep, e_all, z_all = [], [], []
     for i, l in enumerate(layers):
         cfg = (True, False, i < n - 1)
-        l._split_now = l._split(x if i == 0 else None) and (i == 0 or layers[i - 1].out_features % 4 == 0)
+        # (the member dimension of the batched ensemble exists in the bf16 hi | lo format: any 16-bit precision selects it)
+        l._split_now = int(bool(l._split(x if i == 0 else None)) and (i == 0 or layers[i - 1].out_features % 4 == 0))
         keep.append(l._fill_desc(descs[i], cfg, None))
         ld = ops.operand_ld(l.in_features)
         e = torch.empty((S, l.out_features, ld), **f)

@@ -42,9 +42,11 @@ _MASKS_IN_KERNEL = _os.environ.get("LBBNN_TORCH_MASKS", "0") != "1"
 # pass (default: while a HIP graph is being captured they go on a side stream beside the weight pass and the first GEMM -- only
 # the KL finalize needs them; "always": in eager launches too)
 _DENSE_DEFER = {"0": False, "always": "always"}.get(_os.environ.get("LBBNN_DENSE_DEFER", "1"), True)
-# LBBNN_F16_FIRST=f32: the first row-scaled-fp16 layer of a fused forward takes the fp32 network input as it is and splits it
-# in registers (no lbbnn_format_x launch; ~64 more VALU instructions per wave and K step in that GEMM).  Default: planes.
-_F16_FIRST_PLANES = _os.environ.get("LBBNN_F16_FIRST", "planes") != "f32"
+# LBBNN_F16_FIRST=planes: the first row-scaled-fp16 layer of a fused forward is given its input as planes made by an
+# lbbnn_format_x launch.  Default (f32): it takes the fp32 network input as it is and splits it in registers -- measured on the
+# headline net (tools/precision_time.py, same process): 0.1487 ms against 0.1543 ms per forward; the 6.9 us launch costs more
+# than the in-register split of the first layer's x (~1.3 us of its GEMM).
+_F16_FIRST_PLANES = _os.environ.get("LBBNN_F16_FIRST", "f32") != "f32"
 _SIDE = {}
 
 
@@ -464,7 +466,8 @@ class _BayesLinearBase(nn.Module):
 
     def _split(self, x=None, cfg=None):
         """Operand format of this layer call: 0 fp32, 1 bf16 hi | lo (bf16x3 and the reduced single-product modes), 2
-        row-scaled fp16 hi | lo (fp16x3 / fp16x3f: the dual-moment GEMM only -- a posterior-mean call takes format 1)."""
+        row-scaled fp16 hi | lo (fp16x3), 3 the same with var_w as its hi part alone (fp16x3f: one variance product).  2 / 3
+        serve the dual-moment GEMM only -- a posterior-mean call takes format 1."""
         if not ops.split_precision(self) or not ops.split_eligible(self.in_features, self.out_features):
             return 0
         if x is not None and (x.stride(0) % 4 != 0 or x.data_ptr() % 16 != 0 or x.stride(1) != 1
@@ -472,11 +475,8 @@ class _BayesLinearBase(nn.Module):
             return 0
         if (ops.f16s_precision(self) and (cfg is None or cfg[0]) and ops.f16s_eligible(self.in_features, self.out_features)
                 and getattr(self, "_f16s_net_ok", True)):
-            return 2
+            return 3 if ops.get_precision(self) == "fp16x3f" else 2
         return 1
-
-    def _var1(self):
-        return ops.get_precision(self) == "fp16x3f"
 
     def _single(self):
         return ops.get_precision(self) in ("bf16", "fp16")
@@ -521,17 +521,17 @@ class _BayesLinearBase(nn.Module):
         ws = self._workspace()
         eps = (self.noise or {}).get("eps_out")
         stream_id = ops.STREAM_EPS_OUT * 64 + self._layer_id
-        if self._split_now == 2:
+        if self._split_now >= 2:
             assert stochastic and not log_softmax
             o, _ = ops.lrt_gemm16(x, ws.e_w, ws.var_w, ws.e_scale, ws.v_scale, I=self.in_features, O=self.out_features,
                                   bias_mean=self.bias_mu, bias_var=ws.bias_var, eps=eps, rng=rng, rng_stream=stream_id,
-                                  row_offset=self.row_offset, relu=relu, var1=self._var1(), x_planes=x_planes, out=out,
+                                  row_offset=self.row_offset, relu=relu, var1=(self._split_now == 3), x_planes=x_planes, out=out,
                                   want_out=want_out, out_planes=out_planes, std_out=std_out, finalize=finalize)
             return o
         return ops.lrt_gemm(x, ws.e_w, ws.var_w, I=self.in_features, O=self.out_features,
                             bias_mean=self.bias_mu, bias_var=ws.bias_var, eps=eps, rng=rng,
                             rng_stream=stream_id, row_offset=self.row_offset,
-                            relu=relu, mean_only=not stochastic, log_softmax=log_softmax, split=bool(self._split_now),
+                            relu=relu, mean_only=not stochastic, log_softmax=log_softmax, split=(self._split_now == 1),
                             std_out=std_out, finalize=finalize, out=out, single=self._single())
 
     def _forward_hip(self, x, cfg, advance=True, save_rng=False, want_std=False):
@@ -1258,8 +1258,8 @@ class _NetworkBase(nn.Module):
             # row-scaled fp16 layers hand their activations on as fp16 hi | lo PLANES (written by the GEMM epilogue, read by
             # the next GEMM's LDS-DMA as they lie): no fp32 copy of a hidden activation is stored in this no-grad forward
             fmt = l._split_now
-            give_planes = (fmt == 2 and i + 1 < n and layers[i + 1]._split_now == 2 and l.out_features % 8 == 0)
-            if fmt == 2 and i == 0 and _F16_FIRST_PLANES and not x_planes:
+            give_planes = (fmt >= 2 and i + 1 < n and layers[i + 1]._split_now >= 2 and l.out_features % 8 == 0)
+            if fmt >= 2 and i == 0 and _F16_FIRST_PLANES and not x_planes:
                 x = ops.format_x(x, self._planes("in", B, l.in_features, dev, plan))
                 x_planes = True
             obuf = None

@@ -178,15 +178,16 @@ def weight_pass(mu, rho, lambdal, *, z_fwd=None, z_kl=None, r0_c=None, bias_rho=
                 priors: Priors, e_w=None, var_w=None, kl_rows=None, act_mu=None, act_var=None,
                 bias_var=None, split=False, e_scale=None, v_scale=None):
     """lbbnn_weight_pass.  Output tensors are caller-allocated (see LayerWorkspace).  split: False / 0 fp32 operands,
-    True / 1 bf16 hi | lo, 2 row-scaled fp16 hi | lo (lbbnn_weight_pass_f16: e_scale / v_scale (O) receive the row scales)."""
+    True / 1 bf16 hi | lo, 2 row-scaled fp16 hi | lo (lbbnn_weight_pass_f16: e_scale / v_scale (O) receive the row scales), 3 the same
+    with var_w as plain fp16 rows (hi part only: the operands of the 3 + 1 product form)."""
     O, I = mu.shape
     ld = operand_ld(I)
-    if int(split) == 2:
+    if int(split) >= 2:
         rc = _lib.lib().lbbnn_weight_pass_f16(
             _ptr(mu, "weight_mu"), _ptr(rho, "weight_rho"), _ptr(lambdal, "lambdal"),
             _ptr(z_fwd), _ptr(z_kl), _ptr(r0_c), _ptr(bias_rho), ctypes.byref(priors),
             _ptr(e_w), _ptr(var_w), ld, _ptr(e_scale, "e_scale"), _ptr(v_scale, "v_scale"),
-            _ptr(kl_rows), _ptr(act_mu), _ptr(act_var), _ptr(bias_var), O, I, _stream())
+            _ptr(kl_rows), _ptr(act_mu), _ptr(act_var), _ptr(bias_var), O, I, F_VAR1 if int(split) == 3 else 0, _stream())
         _lib.check(rc, "lbbnn_weight_pass_f16")
         return
     rc = _lib.lib().lbbnn_weight_pass(

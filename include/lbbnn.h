@@ -263,7 +263,8 @@ typedef struct lbbnn_layer_desc {
     int stochastic;          /* produce var_w (training or sample)            */
     int want_kl;             /* training or calculate_log_probs               */
     int split;               /* operand format: 0 fp32; 1 bf16 hi + lo (LBBNN_F_SPLIT16); 2 fp16 hi + lo with per-row power-of-two
-                                scales (LBBNN_F_F16S: needs e_scale / v_scale below, rows of at most 1280 weights) */
+                                scales (LBBNN_F_F16S: needs e_scale / v_scale below, rows of at most 1280 weights); 3 the same
+                                for e_w and var_w as plain fp16 rows, hi part only (the operands of LBBNN_F_F16S | LBBNN_F_VAR1) */
     /* explicit draws; NULL => Philox from rng */
     const float *eps_z, *eps_z2, *eps_act;
     /* caller-owned workspace */
@@ -755,7 +756,8 @@ int lbbnn_mnf_flow_dense_backward_batch(const lbbnn_dense_bwd_args_t* args, int 
  *     planes spends 4 packed-fp16 instructions per 2 k on x^2 and none on the split.
  */
 #define LBBNN_F_F16S 0x40      /* operands in the row-scaled fp16 hi + lo format (mean_scale / wvar_scale required) */
-#define LBBNN_F_VAR1 0x80      /* with LBBNN_F_F16S: ONE product for the variance GEMM (3 + 1 products per tile step)  */
+#define LBBNN_F_VAR1 0x80      /* with LBBNN_F_F16S: ONE product for the variance GEMM (3 + 1 products per tile step); var_w is then a
+                                  plain fp16 matrix [O][ld] halves (the hi part alone: 64 B per row and K step instead of 128)  */
 #define LBBNN_F_XPLANES 0x100  /* with LBBNN_F_F16S: x is given as fp16 hi | lo planes                                */
 
 typedef struct lbbnn_gemm_desc {
@@ -790,7 +792,7 @@ int lbbnn_weight_pass_f16(const float* mu, const float* rho, const float* lambda
                           const float* bias_rho, const lbbnn_priors_t* priors,
                           void* e_w, void* var_w, int ld, float* e_scale, float* v_scale,
                           float* kl_rows, float* act_mu, float* act_var, float* bias_var,
-                          int O, int I, void* stream);
+                          int O, int I, int flags /* 0 | LBBNN_F_VAR1 */, void* stream);
 
 #ifdef __cplusplus
 }

@@ -148,6 +148,8 @@ def test_round3_entry_points_argument_checks(lib):
     assert lib.lbbnn_format_x(fake, 64, fake, 64, 0, 64, None) == 0    # empty batch
     pr = _lib.Priors()
     assert lib.lbbnn_weight_pass_f16(fake, fake, fake, None, None, None, None, ctypes.byref(pr), fake, fake, 64, None, fake,
-                                     None, None, None, None, 4, 64, None) == -1      # operands without their scale arrays
+                                     None, None, None, None, 4, 64, 0, None) == -1   # operands without their scale arrays
     assert lib.lbbnn_weight_pass_f16(fake, fake, fake, None, None, None, None, ctypes.byref(pr), fake, fake, 2048, fake, fake,
-                                     None, None, None, None, 4, 2048, None) == -2    # rows longer than one register batch
+                                     None, None, None, None, 4, 2048, 0x80, None) == -2   # rows longer than one register batch
+    assert lib.lbbnn_weight_pass_f16(fake, fake, fake, None, None, None, None, ctypes.byref(pr), fake, fake, 64, fake, fake,
+                                     None, None, None, None, 4, 64, 0x4, None) == -4      # only LBBNN_F_VAR1 is a flag here

@@ -40,7 +40,14 @@ def _decode_units(buf, rows, I):
     return hi, lo
 
 
-def _operands(bnn, dev, I, O, g, mnf=True):
+def _decode_rows16(buf, rows):
+    """plain fp16 rows of ld halves (the hi-only var_w of the 3 + 1 form), packed at the start of an fp32-typed (rows, ld)
+    buffer -> (rows, ld) fp64; the buffer's second half is unused."""
+    ld = buf.shape[1]
+    return buf.cpu().contiguous().view(torch.float16).reshape(-1)[:rows * ld].view(rows, ld).double()
+
+
+def _operands(bnn, dev, I, O, g, mnf=True, fmt=2):
     ops = bnn.ops
     p = orc.init_mnf_params(I, O, g)
     z = 1 + 0.1 * torch.randn(I, generator=g)
@@ -49,7 +56,7 @@ def _operands(bnn, dev, I, O, g, mnf=True):
     ws = {"e_w": torch.empty(O, ld, device=dev), "var_w": torch.empty(O, ld, device=dev), "bias_var": torch.empty(O, device=dev),
           "e_scale": torch.empty(O, device=dev), "v_scale": torch.empty(O, device=dev)}
     ops.weight_pass(d["weight_mu"], d["weight_rho"], d["lambdal"], z_fwd=z.to(dev), bias_rho=d["bias_rho"],
-                    priors=bnn.Priors(), e_w=ws["e_w"], var_w=ws["var_w"], bias_var=ws["bias_var"], split=2,
+                    priors=bnn.Priors(), e_w=ws["e_w"], var_w=ws["var_w"], bias_var=ws["bias_var"], split=fmt,
                     e_scale=ws["e_scale"], v_scale=ws["v_scale"])
     alpha = orc.alpha_of(p["lambdal"].double()); sigma = orc.sigma_of(p["weight_rho"].double())
     ew = p["weight_mu"].double() * alpha * z.double()
@@ -58,12 +65,21 @@ def _operands(bnn, dev, I, O, g, mnf=True):
 
 
 @pytest.mark.parametrize("O,I", [(80, 64), (400, 784), (1200, 1200), (33, 1272), (17, 40)])
-def test_weight_pass_f16_operands_and_scales(bnn, dev, O, I):
+@pytest.mark.parametrize("fmt", [2, 3])
+def test_weight_pass_f16_operands_and_scales(bnn, dev, O, I, fmt):
     """K1 in the row-scaled fp16 format: (hi + lo) * scale reproduces the fp64 operands to 2e-6 relative per ROW maximum,
     the scales are exact powers of two that put each row's maximum into [2^13, 2^14), the k tail is zero."""
     g = torch.Generator().manual_seed(O * 7 + I)
-    p, d, ws, ew, vw = _operands(bnn, dev, I, O, g)
-    for name, ref, sc in (("e_w", ew, ws["e_scale"]), ("var_w", vw, ws["v_scale"])):
+    p, d, ws, ew, vw = _operands(bnn, dev, I, O, g, fmt=fmt)
+    if fmt == 3:
+        # var_w of the 3 + 1 form: one RNE fp16 per weight, plain rows of ld halves
+        vh = _decode_rows16(ws["var_w"], O)
+        s = ws["v_scale"].cpu().double()
+        assert torch.equal(torch.frexp(s)[0], torch.full_like(s, 0.5))
+        assert float(((vh[:, :I] * s[:, None] - vw).abs() / vw.abs().amax(dim=1, keepdim=True)).max()) < 2.0 ** -11
+        assert float(vh[:, I:].abs().max() if vh.shape[1] > I else 0.0) == 0.0
+        assert bool(((vh.amax(dim=1) >= 2.0 ** 13 * 0.999) & (vh.amax(dim=1) <= 2.0 ** 14)).all())
+    for name, ref, sc in (("e_w", ew, ws["e_scale"]),) + ((("var_w", vw, ws["v_scale"]),) if fmt == 2 else ()):
         hi, lo = _decode_units(ws[name], O, I)
         s = sc.cpu().double()
         assert torch.equal(torch.frexp(s)[0], torch.full_like(s, 0.5)), name          # exact powers of two
@@ -100,7 +116,7 @@ def test_gemm16_vs_fp64(bnn, dev, B, I, O, prec, xsrc):
     ops = bnn.ops
     g = torch.Generator().manual_seed(B + I + O)
     x = torch.rand(B, I, generator=g)
-    p, d, ws, ew, vw = _operands(bnn, dev, I, O, g)
+    p, d, ws, ew, vw = _operands(bnn, dev, I, O, g, fmt=3 if prec == "fp16x3f" else 2)
     eps = torch.randn(B, O, generator=g)
     xin = x.to(dev)
     if xsrc == "planes":
@@ -124,7 +140,7 @@ def test_gemm16_plane_output_feeds_the_next_layer_bitwise(bnn, dev, B, I, O, pre
     ops = bnn.ops
     g = torch.Generator().manual_seed(B * 3 + I + O)
     x = torch.rand(B, I, generator=g).to(dev)
-    p, d, ws, ew, vw = _operands(bnn, dev, I, O, g)
+    p, d, ws, ew, vw = _operands(bnn, dev, I, O, g, fmt=3 if prec == "fp16x3f" else 2)
     rng = torch.tensor([1234, 7, 0, 0], dtype=torch.int64, device=dev)
     kw = dict(I=I, O=O, bias_mean=d["bias_mu"], bias_var=ws["bias_var"], rng=rng, rng_stream=5, row_offset=11, relu=True,
               var1=(prec == "fp16x3f"))
@@ -160,16 +176,20 @@ def test_range_overflow_is_loud(bnn, dev):
     x = torch.rand(B, I, generator=g)
     x[7, 13] = 5000.0
     x[9, 3] = 1.0e6
-    p, d, ws, ew, vw = _operands(bnn, dev, I, O, g)
+    p, d, ws2, ew, vw = _operands(bnn, dev, I, O, torch.Generator().manual_seed(4), fmt=2)
+    p, d, ws3, ew, vw = _operands(bnn, dev, I, O, torch.Generator().manual_seed(4), fmt=3)
+    ws = ws2
     eps = torch.randn(B, O, generator=g).to(dev)
     for xin, planes in ((x.to(dev), False), (ops.format_x(x.to(dev)), True)):
         for var1 in (False, True):
+            ws = ws3 if var1 else ws2
             out, _ = ops.lrt_gemm16(xin, ws["e_w"], ws["var_w"], ws["e_scale"], ws["v_scale"], I=I, O=O,
                                     bias_mean=d["bias_mu"], bias_var=ws["bias_var"], eps=eps, var1=var1, x_planes=planes)
             fin = torch.isfinite(out).all(dim=1).cpu()
             assert not bool(fin[7]) and not bool(fin[9]), (planes, var1)
             assert bool(fin[torch.arange(B)[(torch.arange(B) != 7) & (torch.arange(B) != 9)]].all())
     # ... and in range up to the documented limit the result is still accurate
+    ws = ws2
     x2 = torch.rand(B, I, generator=g) * 4000.0
     out, _ = ops.lrt_gemm16(x2.to(dev), ws["e_w"], ws["var_w"], ws["e_scale"], ws["v_scale"], I=I, O=O,
                             bias_mean=d["bias_mu"], bias_var=ws["bias_var"], eps=eps)
@@ -216,7 +236,7 @@ def test_f16_headline_network_vs_oracle(bnn, dev, prec, first, monkeypatch):
     assert bnn.get_precision() == "fp32" and bnn.get_precision(net.l2) == prec          # per network, not global
     with torch.no_grad():
         out = net(x.to(dev), sample=True)
-        assert net.l1._split_now == 2 and net.l2._split_now == 2 and net.l3._split_now == 0
+        assert net.l1._split_now == net.l2._split_now == (3 if prec == "fp16x3f" else 2) and net.l3._split_now == 0
         kls = [l.kl.clone() for l in layers]
     bar, atol = BARS[prec]
     # the log-probabilities are O(2.3): the bars apply to the hidden activations; the head is the exact fp32 skinny kernel
@@ -264,7 +284,7 @@ def test_f16_row_sharded_forward_and_plan_and_graph_bitwise(bnn, dev, prec):
         bnn.manual_seed(99, 3)
         full = net(x, sample=True).clone()
         kl_full = net.kl().clone()
-        assert net.l1._split_now == 2 and net.l2._split_now == 2
+        assert net.l1._split_now >= 2 and net.l2._split_now >= 2
         parts = []
         for lo in (0, B // 2):
             bnn.manual_seed(99, 3)
