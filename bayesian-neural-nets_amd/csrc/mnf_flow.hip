@@ -11,6 +11,7 @@
 // K5  kl_finalize     : O(O+I) tail of the KL: kl_bias, tanh/mean of the auxiliary activations,
 //     log_rb, and the final scalar; kl_finalize_all_kernel does it for every layer of a network, adds the
 //     network total and advances the RNG offset in one launch.
+#include <cstdlib>
 #include "lbbnn_device.h"
 #include "lbbnn_internal.h"
 
@@ -336,6 +337,131 @@ __global__ __launch_bounds__(kFastThreads) void mnf_flow_planar_fast_kernel(cons
     }
 }
 
+// ---- round 3: the same short-chain form with everything in REGISTERS (rows of I % 4 == 0 <= 2048 floats, 16-B aligned
+// vectors: every layer of the BASELINE configurations).  What the LDS form above spends its 12.7 us on (flow_stamps, round
+// 2: inputs landed 3.8 us, sweep done 6.4 us, end 11.1 us) is a chain of dependent latencies on ONE workgroup: LDS-DMA
+// staging + wait + LDS re-reads, one Philox call PER ELEMENT (four threads recompute the same counter), 15 double-precision
+// accumulators reduced by 6-step DPP chains, libm tanhf.  Here a thread owns one float4 column group: its 2 + 2 NT input
+// float4s are requested back to back straight into registers (one memory latency, no LDS round trip), ONE Philox call
+// gives its four draws, the 15 partial sums are floats over four elements, reduced per wave by DPP in float and combined
+// across the 8 waves in double in a fixed order (deterministic), tanh through one hardware exp (tanh_fast: ~1e-7
+// absolute), z written as float4.  Same draws, same z0 bits; the dot products differ from the double-accumulated form by
+// ~1e-7 relative.
+constexpr int kVecThreads = 512;
+
+__global__ __launch_bounds__(kVecThreads) void mnf_flow_planar_vec_kernel(const FlowBatch bt) {
+    const LBBNN_CONST_AS FlowArgs& a = kernarg_as<FlowBatch>()->l[blockIdx.y];
+    const bool klblk = blockIdx.x == 1;
+    if (klblk && !a.want_kl) return;
+    constexpr int NV = 2 * kFastT + kFastT * (kFastT - 1) / 2 + 1;      // 15 reduced values
+    constexpr int NW = kVecThreads / 64;
+    __shared__ float red[NV][NW];
+    const int I = a.I, nq = I >> 2, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bool on = tid < nq;
+    const float* eps = klblk ? a.eps_kl : a.eps_fwd;
+    const int Tz = a.zf.T, Tr = klblk ? a.rf.T : 0, NT = Tz + Tr;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 qm = zero4, lv = zero4, ep = zero4, u[kFastT], w[kFastT];
+    float bias[kFastT];
+#pragma unroll
+    for (int t = 0; t < kFastT; ++t) { u[t] = zero4; w[t] = zero4; bias[t] = 0.f; }
+    if (on) {
+        qm = reinterpret_cast<const float4*>(a.q0_mean)[tid];
+        lv = reinterpret_cast<const float4*>(a.q0_log_var)[tid];
+        if (eps) ep = reinterpret_cast<const float4*>(eps)[tid];
+    }
+#pragma unroll
+    for (int t = 0; t < kFastT; ++t) {
+        if (t < NT) {                                                          // uniform
+            const float* up = t < Tz ? a.zf.u[t] : a.rf.u[t - Tz];
+            const float* wp = t < Tz ? a.zf.w[t] : a.rf.w[t - Tz];
+            if (on) { u[t] = reinterpret_cast<const float4*>(up)[tid]; w[t] = reinterpret_cast<const float4*>(wp)[tid]; }
+            bias[t] = (t < Tz ? a.zf.b[t] : a.rf.b[t - Tz])[0];
+        }
+    }
+    float e[4] = {ep.x, ep.y, ep.z, ep.w};
+    if (!eps && on) {
+        const uint64_t seed = a.rng[0], offs = a.rng[1] + (uint64_t)blockIdx.z * kernarg_as<FlowBatch>()->m_adv;
+        const uint32_t stream = (klblk ? LBBNN_STREAM_EPS_Z2 : LBBNN_STREAM_EPS_Z) * 64u + a.layer;
+        philox_normal4(seed, offs, stream, (uint64_t)tid, 0u, e);
+    }
+    const float qmv[4] = {qm.x, qm.y, qm.z, qm.w}, lvv[4] = {lv.x, lv.y, lv.z, lv.w};
+    float z0[4] = {0.f, 0.f, 0.f, 0.f};
+    float acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] = 0.f;
+    if (on) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float ev = expf(lvv[c]);
+            z0[c] = qmv[c] + sqrtf(ev) * e[c];                                                   // ...MNF.py:183-185
+            if (klblk) {
+                const float d = z0[c] - qmv[c];
+                acc[NV - 1] += -0.5f * 1.1447298858494002f - 0.5f * lvv[c] - 0.5f * ((d * d) / ev);   // :213-214
+            }
+        }
+        const float4 z4 = make_float4(z0[0], z0[1], z0[2], z0[3]);
+        int qx = 2 * kFastT;
+#pragma unroll
+        for (int t = 0; t < kFastT; ++t) {
+            acc[t] = (w[t].x * z4.x + w[t].y * z4.y) + (w[t].z * z4.z + w[t].w * z4.w);
+            acc[kFastT + t] = (u[t].x * w[t].x + u[t].y * w[t].y) + (u[t].z * w[t].z + u[t].w * w[t].w);
+#pragma unroll
+            for (int s2 = 0; s2 < t; ++s2)
+                acc[qx++] = (w[t].x * u[s2].x + w[t].y * u[s2].y) + (w[t].z * u[s2].z + w[t].w * u[s2].w);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] = wave_sum(acc[k]);
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) red[k][wv] = acc[k];
+    __syncthreads();
+    double tot[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double t2 = 0.0;
+#pragma unroll
+        for (int w2 = 0; w2 < NW; ++w2) t2 += (double)red[k][w2];
+        tot[k] = t2;
+    }
+    // scalar chain (flows2.py:87-95), every thread redundantly
+    float th[kFastT], ld_q = 0.f, ld_r = 0.f;
+    {
+        int qx = 2 * kFastT;
+#pragma unroll
+        for (int t = 0; t < kFastT; ++t) {
+            double inner = tot[t];
+#pragma unroll
+            for (int s2 = 0; s2 < t; ++s2) inner += (double)th[s2] * tot[qx++];
+            th[t] = 0.f;
+            if (t < NT) {
+                th[t] = tanh_fast((float)inner + bias[t]);
+                const float ld = logf(fabsf(1.f + (1.f - th[t] * th[t]) * (float)tot[kFastT + t]));
+                if (t < Tz) ld_q += ld; else ld_r += ld;
+            }
+        }
+    }
+    float* zo = (klblk ? a.z_kl : a.z_fwd) + (long long)blockIdx.z * kernarg_as<FlowBatch>()->z_ms;
+    if (on) {
+        float v[4] = {z0[0], z0[1], z0[2], z0[3]};
+#pragma unroll
+        for (int t = 0; t < kFastT; ++t)
+            if (t < Tz) { v[0] += u[t].x * th[t]; v[1] += u[t].y * th[t]; v[2] += u[t].z * th[t]; v[3] += u[t].w * th[t]; }
+        reinterpret_cast<float4*>(zo)[tid] = make_float4(v[0], v[1], v[2], v[3]);
+        if (klblk && tid == nq - 1) {
+            float zl = v[3];
+#pragma unroll
+            for (int t = 0; t < kFastT; ++t) if (t >= Tz && t < NT) zl += u[t].w * th[t];
+            a.scal[3] = zl;                                                  // z_b[-1]: last ELEMENT (:224)
+        }
+    }
+    if (tid == 0) {
+        if (!klblk) { if (a.scal) a.scal[4] = ld_q; }
+        else { a.scal[0] = ld_q; a.scal[1] = (float)tot[NV - 1]; a.scal[2] = ld_r; }
+    }
+}
+
 // -------------------------------------------------------------------------------------------- K5
 __global__ __launch_bounds__(256) void kl_finalize_kernel(const FinalizeBatch bt) {
     const FinalizeArgs& a = bt.l[blockIdx.x];
@@ -650,7 +776,20 @@ int launch_flow_planar(const FlowArgs* a, int n, hipStream_t s, int members, uns
         }
         bool fast = true;
         for (int i = 0; i < n; ++i) fast = fast && (a[i].zf.T + (a[i].want_kl ? a[i].rf.T : 0) <= kFastT);
-        if (fast) hipLaunchKernelGGL(mnf_flow_planar_fast_kernel, grid, dim3(kFastThreads), need, s, bt);
+        // the register form: float4 column groups, one per thread
+        static const bool vec_allowed = [] { const char* e = getenv("LBBNN_K3_VEC"); return !(e && e[0] == '0'); }();   // A/B knob
+        bool vec = fast && vec_allowed;
+        auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+        for (int i = 0; i < n && vec; ++i) {
+            const FlowArgs& f = a[i];
+            vec = (f.I % 4 == 0) && f.I <= 4 * kVecThreads && al16(f.q0_mean) && al16(f.q0_log_var) && al16(f.z_fwd) &&
+                  (!f.eps_fwd || al16(f.eps_fwd)) && (!f.want_kl || (al16(f.z_kl) && (!f.eps_kl || al16(f.eps_kl)))) &&
+                  (z_ms % 4 == 0);
+            for (int t = 0; t < f.zf.T && vec; ++t) vec = al16(f.zf.u[t]) && al16(f.zf.w[t]);
+            for (int t = 0; t < (f.want_kl ? f.rf.T : 0) && vec; ++t) vec = al16(f.rf.u[t]) && al16(f.rf.w[t]);
+        }
+        if (vec) hipLaunchKernelGGL(mnf_flow_planar_vec_kernel, grid, dim3(kVecThreads), 0, s, bt);
+        else if (fast) hipLaunchKernelGGL(mnf_flow_planar_fast_kernel, grid, dim3(kFastThreads), need, s, bt);
         else if (members > 1) return LBBNN_E_SHAPE;                     // the member dimension exists in the fast form only
         else      hipLaunchKernelGGL(mnf_flow_planar_lds_kernel, grid, block, need, s, bt);
     } else {
