@@ -90,25 +90,54 @@ def parse():
     ap.add_argument("--eager", dest="launch", action="store_const", const="eager",
                     help="launch every step from Python (~100 us of host time against ~165 us of GPU time: as fast as the plan in "
                          "a long run, 0-8 %% slower in a 20-step region that starts from an idle queue)")
-    ap.add_argument("--precision", choices=("bf16x3", "fp32"), default="bf16x3",
-                    help="GEMM arithmetic of the headline leg: bf16x3 = split-precision products on the bf16 matrix cores "
-                         "with fp32 accumulation (measured 3e-6 relative on layer outputs, contract 1e-4); fp32 = exact "
-                         "fp32 MFMA (then there is no secondary leg)")
+    ap.add_argument("--precision", choices=("fp16x3f", "fp16x3", "bf16x3", "fp32"), default="fp16x3f",
+                    help="GEMM arithmetic of the headline leg (bnn_amd.ops.PRECISIONS): fp16x3f = row-scaled fp16 hi + lo operands, "
+                         "3 mean + 1 variance products on the fp16 matrix cores, fp32 accumulate (1.4-1.8e-5 of max|out| against "
+                         "fp64 on the headline layers; contract 1e-4); fp16x3 = the same operands, 3 + 3 products (3e-8: tighter "
+                         "than an fp32-accumulate torch.mm); bf16x3 = round 2's headline format (2.7e-6); fp32 = exact fp32 MFMA")
     return ap.parse_args()
+
+
+PROFILE_TAG = "r03"
 
 
 def pmc_traffic(precision):
     """HBM-side bytes per launch of the dominant GEMM from the committed rocprofv3 PMC pass (FETCH_SIZE x2 gfx950
     correction + WRITE_SIZE; counters cannot be read from inside the process) -- None if no pass is committed for
     this precision."""
-    for name in ("r02_pmc_gemm_traffic.json", "r01_e_pmc_gemm_traffic.json"):
+    for name in ("%s_pmc_gemm_traffic.json" % PROFILE_TAG, "r02_pmc_gemm_traffic.json", "r01_e_pmc_gemm_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)
-            if d.get("precision") == precision:
-                return d["hbm_bytes_per_launch"], d["source"]
+            for rec in (d if isinstance(d, list) else [d]):
+                if rec.get("precision") == precision:
+                    return rec["hbm_bytes_per_launch"], rec["source"]
         except (OSError, ValueError, KeyError):
             pass
+    return None, None
+
+
+# the dominant GEMM instantiation of each precision as rocprofv3 prints it (demangled; both x sources of the fp16 kernel)
+KERNEL_OF = {"fp16x3f": "lrt_gemm_f16s_kernel<5, 2, 4, 1,", "fp16x3": "lrt_gemm_f16s_kernel<5, 2, 4, 3,",
+             "bf16x3": "lrt_gemm_bf16x3_kernel<5, 2, 4, false, 3,", "bf16": "lrt_gemm_bf16x3_kernel<5, 2, 4, false, 1,",
+             "fp32": "lrt_gemm_f32_dma_kernel<5, 2, 4,"}
+
+
+def rocprof_avg_us(precision):
+    """Average dispatch duration (us) of this precision's dominant GEMM kernel in the committed `rocprofv3 --kernel-trace
+    --stats` summary of the bench command (profiles/<tag>_kernel_stats_bench_default.csv), or (None, None)."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "%s_kernel_stats_bench_default.csv" % PROFILE_TAG)
+    try:
+        with open(path, newline="") as f:
+            tot = cnt = 0.0
+            for row in csv.DictReader(f):
+                if KERNEL_OF.get(precision, "?") in row.get("Name", ""):
+                    tot += float(row["TotalDurationNs"]); cnt += float(row["Calls"])
+        if cnt:
+            return tot / cnt / 1e3, os.path.relpath(path, ROOT)
+    except (OSError, ValueError, KeyError):
+        pass
     return None, None
 
 
@@ -332,34 +361,40 @@ def roofline_object(events, precision, ms_per_step, sampled_in):
             avg_ms * 1e3, ms_per_step * 1e3)
     if share > 1.0:
         return None, "bracketed GEMM time per step is %.2f x the timed region's step time" % share
-    split = precision == "bf16x3"
-    single = precision == "bf16"
-    peak = BF16_MFMA_PEAK_TFLOPS if (split or single) else FP32_MFMA_PEAK_TFLOPS
+    # products executed per algorithmic product on the 16-bit matrix cores: bf16x3 / fp16x3 3 + 3 of 2, fp16x3f 3 + 1 of 2
+    executed = {"bf16x3": 3.0, "fp16x3": 3.0, "fp16x3f": 2.0, "bf16": 1.0, "fp32": 1.0}[precision]
+    peak = FP32_MFMA_PEAK_TFLOPS if precision == "fp32" else BF16_MFMA_PEAK_TFLOPS      # fp16 and bf16 MFMA: the same rate
+    kernel = {"fp16x3f": "lrt_gemm_f16s_kernel<5,2,4,NPV=1>", "fp16x3": "lrt_gemm_f16s_kernel<5,2,4,NPV=3>",
+              "bf16x3": "lrt_gemm_bf16x3_kernel<5,2,4>", "bf16": "lrt_gemm_bf16x3_kernel<5,2,4,NP=1>",
+              "fp32": "lrt_gemm_f32_dma_kernel<5,2,4>"}[precision]
     ach = flops / (avg_ms * 1e-3) / 1e12
     traffic, traffic_src = pmc_traffic(precision)
-    return {"bound": "mfma",
-            "kernel": ("lrt_gemm_bf16x3_kernel<5,2,4>" if split else "lrt_gemm_bf16x3_kernel<5,2,4,NP=1>" if single
-                       else "lrt_gemm_f32_dma_kernel<5,2,4>") + " (dual-moment GEMM, 80x128 tile)",
+    prof_us, prof_src = rocprof_avg_us(precision)
+    roof = {"bound": "mfma", "kernel": kernel + " (dual-moment GEMM, 80x128 tile)",
             "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
             "traffic": traffic, "traffic_unit": "HBM-side bytes per launch", "traffic_source": traffic_src,
-            "traffic_note": "FETCH_SIZE x2 + WRITE_SIZE = what the 8 private L2s request from the fabric (Infinity-Cache hits included); "
-                            "the structural minimum for 8 L2s is 85.4 MB fetched + 19.7 MB written at the 1200x1200 layer "
-                            "(4 x 2 XCD ownership of the tile grid, DESIGN.md 7.4), the algorithmic 45.5 MB would need one shared L2",
-            "executed_mfma_tflops": ach * (3.0 if split else 1.0),
-            "note": ("achieved = ALGORITHMIC 4*B*I*O flop per launch / HIP-event time; the bf16x3 path executes 3 bf16 "
-                     "products per algorithmic product") if split else
+            "traffic_note": "FETCH_SIZE x2 + WRITE_SIZE = what the 8 private L2s request from the fabric (Infinity-Cache hits "
+                            "included); DESIGN.md 7.4",
+            "executed_mfma_tflops": ach * executed,
+            "note": "achieved = ALGORITHMIC 4*B*I*O flop per launch / HIP-event time; this format executes %g 16-bit MFMA "
+                    "products per algorithmic product" % executed if executed != 1.0 else
                     "achieved = ALGORITHMIC 4*B*I*O flop per launch / HIP-event time",
             "avg_launch_us": avg_ms * 1e3, "median_launch_us": med_ms * 1e3, "launches": len(big),
             "event_bracket_floor_us": floor_us,
-            "event_bracket_note": "the same two HIP events around a ~1 us kernel read event_bracket_floor_us: a bracket includes the "
-                                  "dispatch latency of an isolated launch, which rocprofv3's per-dispatch duration does not "
-                                  "(profiles/r02_kernel_stats_bench_default.csv: 61.0 us for this kernel in the same command)",
-            "gemm_share_of_step": share, "sampled_steps": n_steps, "sampled_in": sampled_in}, None
+            "event_bracket_note": "the same two HIP events around a ~1 us kernel read event_bracket_floor_us: a bracket includes "
+                                  "the dispatch latency of an isolated launch, which rocprofv3's per-dispatch duration does not",
+            "gemm_share_of_step": share, "sampled_steps": n_steps, "sampled_in": sampled_in}
+    if prof_us:
+        # the same fraction from the COMMITTED rocprofv3 summary of this command: line and profiles/ agree
+        roof["rocprof_avg_launch_us"] = prof_us
+        roof["frac_rocprof"] = flops / (prof_us * 1e-6) / 1e12 / peak
+        roof["rocprof_source"] = prof_src
+    return roof, None
 
 
 def forward_leg(args, bnn_amd, ops, net, x, sync, precision, world):
     """warm-up -> settle -> timed region -> roofline pass for one GEMM precision.  Returns a dict of raw results."""
-    bnn_amd.set_precision(precision)
+    net.set_precision(precision)
 
     def step():
         out = net(x, sample=True)
@@ -415,7 +450,7 @@ def train_leg(args, bnn_amd, net, x, sync, world, rank):
     ONE flat-bucket gradient all-reduce (RCCL when world > 1), bnn_amd.optim.Adam on the reduced bucket."""
     from bnn_amd import parallel, optim
     dev = x.device
-    bnn_amd.set_precision(args.precision)
+    net.set_precision(args.precision)
     dp = parallel.DataParallelELBO(net)
     opt = optim.Adam(net.parameters(), lr=1e-3)
     y = torch.randint(0, DIMS[-1], (x.shape[0],), device=dev, generator=torch.Generator(device=dev).manual_seed(7 + rank))
@@ -460,6 +495,11 @@ def train_leg(args, bnn_amd, net, x, sync, world, rank):
            "bucket_bytes": dp.bucket_numel() * 4, "collective": dp.describe_collective()}
     step_stats(res, per_step)
     return res
+
+
+DTYPE_OF = {"fp16x3f": "f16 (row-scaled fp16 hi + lo split of the f32 operands: 3 mean + 1 variance MFMA products, f32 accumulate)",
+            "fp16x3": "f16 (row-scaled fp16 hi + lo split of the f32 operands: 3 + 3 MFMA products, f32 accumulate)",
+            "bf16x3": "bf16 (hi + lo split of the f32 operands: 3 + 3 MFMA products, f32 accumulate)", "fp32": "f32"}
 
 
 def _free_port():
@@ -626,10 +666,13 @@ def main():
         torch.cuda.synchronize()
 
     legs = {args.precision: forward_leg(args, bnn_amd, ops, net, x, sync, args.precision, world)}
-    if args.precision == "bf16x3" and not args.no_secondary:
+    if args.precision != "fp32" and not args.no_secondary:
         legs["fp32"] = forward_leg(args, bnn_amd, ops, net, x, sync, "fp32", world)
-    if args.precision == "bf16x3" and not args.no_reduced and world == 1:
+        if args.precision != "fp16x3" and world == 1:
+            legs["fp16x3"] = forward_leg(args, bnn_amd, ops, net, x, sync, "fp16x3", world)
+    if args.precision != "fp32" and not args.no_reduced and world == 1:
         legs["bf16"] = forward_leg(args, bnn_amd, ops, net, x, sync, "bf16", world)
+    net.set_precision(args.precision)
     strong = None
     if world > 1 and B % world == 0 and not args.no_secondary:
         # SURVEY.md 8(d) asks for both scalings: the SAME 4096 rows split N ways (rank r takes rows [r B/N, (r+1) B/N)), no
@@ -653,7 +696,7 @@ def main():
             "value": total / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16x3 split of f32 operands, f32 accumulate" if args.precision == "bf16x3" else "f32",
+            "dtype": DTYPE_OF[args.precision], "precision": args.precision,
             "data": "synthetic", "hip_graph": main_leg["launch"] == "graph",
             "launch": {"plan": "recorded launch plan (bnn_amd.graphs.LaunchPlan: the forward's 4 C calls = 5 kernels, replayed from a list)",
                        "graph": "one HIP-graph replay per step", "eager": "5 launches per step from Python"}[main_leg["launch"]],
@@ -686,6 +729,21 @@ def main():
                 else:
                     sec["roofline_invalid"] = why
             res["secondary"] = sec
+        if "fp16x3" in legs and args.precision != "fp16x3":
+            leg = legs["fp16x3"]
+            st3 = {"dtype": DTYPE_OF["fp16x3"], "precision": "fp16x3",
+                   "what": "the same step with 3 + 3 products (2-3e-8 of max|out| against fp64: tighter than an fp32-accumulate "
+                           "torch.mm), same process",
+                   "value": total / leg["elapsed"], "unit": "samples/s", "steps": args.steps,
+                   "ms_per_step": leg["elapsed"] / args.steps * 1e3, "settle": leg["settle"], "timed_attempts": leg["attempts"]}
+            step_stats(st3, leg["per_step"])
+            if leg["events"]:
+                roof, why = roofline_object(leg["events"], "fp16x3", st3["ms_per_step"], sampled_in)
+                if roof is not None:
+                    st3["roofline"] = roof
+                else:
+                    st3["roofline_invalid"] = why
+            res["secondary_strict_fp16x3"] = st3
         if "bf16" in legs:
             leg = legs["bf16"]
             red = {"dtype": "bf16 (ONE product per moment)",

@@ -1917,8 +1917,10 @@ def test_propagate_flow_standalone_autograd_1d(bnn, dev, kind):
 def test_bench_contract_json_line():
     """bench.py, run exactly as the driver runs it (--gpus 1 --steps 20 --warmup 5; only the CPU-baseline budget is cut):
     ONE JSON line with the contract keys, a roofline that is consistent with the timed region, an fp32 secondary leg,
-    and a headline within 25 % of the committed reference run of the same command (profiles/r02_bench_driver_cmd.json; three
-    runs on three boxes were 23.70 / 23.77 / 23.88 M samples/s) -- round 1's driver line (2.05 ms/step against 0.18) fails here."""
+    and a headline within 25 % of the committed reference run of the same command (profiles/r03_bench_driver_cmd.json: round
+    3's row-scaled fp16 format, 27.9 M samples/s; round 2's bf16x3 line read 24.7-24.9 M) -- round 1's driver line (2.05 ms/step
+    against 0.18) fails here.  The line also carries the strict 3 + 3 product leg and roofline.frac_rocprof, the same fraction
+    computed from the COMMITTED rocprofv3 summary of this command."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
@@ -1947,7 +1949,11 @@ def test_bench_contract_json_line():
     assert abs(d["ms_per_step"] - d["ms_per_step_median"]) < 0.25 * d["ms_per_step_median"], d
     # within 25 % of the committed run of the same command (recorded launch plan: ~30 us of host time per step)
     assert d["launch"].startswith("recorded launch plan") and d["launch_fallback_reason"] is None
-    ref_path = os.path.join(root, "profiles", "r02_bench_driver_cmd.json")
+    assert d["precision"] == "fp16x3f" and d["dtype"].startswith("f16")
+    assert "frac_rocprof" in rf and 0.5 * rf["frac"] < rf["frac_rocprof"] < 2.0 * rf["frac"], rf
+    st3 = d["secondary_strict_fp16x3"]
+    assert st3["precision"] == "fp16x3" and 0.5 * d["value"] < st3["value"] <= 1.1 * d["value"], st3
+    ref_path = os.path.join(root, "profiles", "r03_bench_driver_cmd.json")
     ref = json.loads(open(ref_path).read().strip().splitlines()[-1])
     assert 0.75 * ref["value"] < d["value"] < 1.33 * ref["value"], (d["value"], ref["value"], d)
     sec = d["secondary"]

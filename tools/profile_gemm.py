@@ -14,6 +14,8 @@ from bnn_amd import ops
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 SPLIT = os.environ.get("SPLIT", "0") == "1"
+FMT = int(os.environ.get("FMT", "0"))        # 2: row-scaled fp16, 3 + 3 products; 3: 3 + 1 products (as the forward runs them:
+                                             # layer 1 on fp32 x writing planes, layer 2 on planes writing fp32)
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 dev = torch.device("cuda:0")
 st = ops.RngState.get(dev)
@@ -30,6 +32,28 @@ for (I, O) in [(784, 1200), (1200, 1200)]:
         ops.weight_pass(mu, rho, lam, priors=bnn_amd.Priors(), e_w=ew, var_w=vw, split=True)
     bm = torch.rand(O, device=dev, generator=g); bv = 1e-4 * torch.rand(O, device=dev, generator=g)
     out = torch.empty(B, O, device=dev)
+    if FMT >= 2:
+        mu = 0.02 * (torch.rand(O, I, device=dev, generator=g) - 0.5); rho = -5 + torch.rand(O, I, device=dev, generator=g)
+        lam = torch.rand(O, I, device=dev, generator=g)
+        es, vs = torch.empty(O, device=dev), torch.empty(O, device=dev)
+        ops.weight_pass(mu, rho, lam, priors=bnn_amd.Priors(), e_w=ew, var_w=vw, split=FMT, e_scale=es, v_scale=vs)
+        first = I == 784
+        xin = x if first else ops.format_x(x)
+        pl = torch.zeros(B, ops.plane_ld(O), device=dev) if first else None
+        kw = dict(I=I, O=O, bias_mean=bm, bias_var=bv, rng=st.t, relu=True, var1=(FMT == 3), x_planes=not first,
+                  out=None if first else out, want_out=not first, out_planes=pl)
+        for _ in range(3):
+            ops.lrt_gemm16(xin, ew, vw, es, vs, **kw)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(N):
+            ops.lrt_gemm16(xin, ew, vw, es, vs, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / N
+        res.append((I, O, us, 4.0 * B * I * O / us / 1e6))
+        continue
     for _ in range(3):
         ops.lrt_gemm(x, ew, vw, I=I, O=O, bias_mean=bm, bias_var=bv, rng=st.t, relu=True, out=out, split=SPLIT)
     torch.cuda.synchronize()
