@@ -223,6 +223,7 @@ SIGNATURES = {
                                 ctypes.POINTER(Priors), c_p, c_u32, c_p, c_p, c_i, c_p]),
     "lbbnn_layers_prepare": (c_i, [ctypes.POINTER(LayerDesc), c_i, c_p, c_p]),
     "lbbnn_layers_operands_snap": (c_i, [ctypes.POINTER(LayerDesc), c_i, c_p, c_p, c_u64, c_p]),
+    "lbbnn_layers_operands_x": (c_i, [ctypes.POINTER(LayerDesc), c_i, c_p, c_p, c_u64, c_p, c_i, c_p, c_i, c_i, c_i, c_p]),
     "lbbnn_lrt_gemm_finalize": (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_u32, c_i64,
                                       c_p, c_i, c_p, c_i, c_i, c_i, c_i, ctypes.POINTER(LayerDesc), c_i, c_p, c_p, c_p]),
     "lbbnn_lrt_gemm_finalize_adv": (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_u32, c_i64,

@@ -90,6 +90,40 @@ __host__ __device__ __forceinline__ size_t split_hi_index(size_t row, int k, int
 }
 constexpr int kSplitLoOffset = 8;       // lo part of the same k: the next 16-B unit (+8 bf16)
 
+// ------------------------------------------------------------------------------------------ x planes (LBBNN_F_XPLANES)
+// fp32 rows -> fp16 hi | lo planes (include/lbbnn.h): one work item per 8 consecutive k -- two float4 in, the hi unit and
+// the lo unit (16 B each) out; groups past I (the zero tail of the plane row) are written as zeros.  `first` / `stride`:
+// the calling kernel's grid-stride loop.  I % 8 == 0.
+struct FormatJob { const float* x; char* planes; int ldx, ldp, B, I; };
+
+__device__ __forceinline__ void format_x_items(const FormatJob& j, size_t first, size_t stride) {
+    typedef _Float16 fx_h2 __attribute__((ext_vector_type(2)));
+    typedef float fx_f2 __attribute__((ext_vector_type(2)));
+    const int groups = j.ldp >> 3;
+    const size_t n = (size_t)j.B * groups;
+    for (size_t t = first; t < n; t += stride) {
+        const int b = (int)(t / groups), g = (int)(t % groups), k = 8 * g;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (k < j.I) {
+            const float4 f0 = *reinterpret_cast<const float4*>(j.x + (size_t)b * j.ldx + k);
+            const float4 f1 = *reinterpret_cast<const float4*>(j.x + (size_t)b * j.ldx + k + 4);
+            v[0] = f0.x; v[1] = f0.y; v[2] = f0.z; v[3] = f0.w; v[4] = f1.x; v[5] = f1.y; v[6] = f1.z; v[7] = f1.w;
+        }
+        uint32_t h[4], l[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const fx_f2 pv = {v[2 * u], v[2 * u + 1]};
+            const fx_h2 ph = __builtin_convertvector(pv, fx_h2);
+            const fx_f2 lv = {v[2 * u] - (float)ph[0], v[2 * u + 1] - (float)ph[1]};
+            h[u] = __builtin_bit_cast(uint32_t, ph);
+            l[u] = __builtin_bit_cast(uint32_t, __builtin_convertvector(lv, fx_h2));
+        }
+        char* p = j.planes + (size_t)b * j.ldp * 4 + (size_t)(k >> 5) * 128 + ((k >> 3) & 3) * 32;
+        *reinterpret_cast<uint4*>(p) = make_uint4(h[0], h[1], h[2], h[3]);
+        *reinterpret_cast<uint4*>(p + 16) = make_uint4(l[0], l[1], l[2], l[3]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ kernel arguments as memory
 // A by-value kernel-argument struct indexed with a RUNTIME index (bt.l[blockIdx.y], a.zf.u[t]) is copied to scratch
 // memory by hipcc (measured: 872 B/lane in the flow kernel, every pointer fetch then a private-memory round trip on a

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/lbbnn.h"
+#include "lbbnn_device.h"
 
 namespace lbbnn {
 
@@ -81,8 +82,9 @@ LBBNN_HIDDEN int launch_weight_pass(const WeightPassArgs* a, int n, hipStream_t 
 // planar flows of a layer computed inside the weight pass's workgroups instead of by launch_flow_planar (advance must be 0)
 LBBNN_HIDDEN bool in_flow_eligible(const FlowArgs& f, const WeightPassArgs& w);
 LBBNN_HIDDEN void make_in_flow(InFlow& o, const FlowArgs& f);
+// fmt (optional): an lbbnn_format_x job for the launch to carry on otherwise idle CUs; *fmt_done says whether it did
 LBBNN_HIDDEN int launch_flow_planar(const FlowArgs* a, int n, hipStream_t s, int members = 1, unsigned long long m_adv = 0,
-                                    long long z_ms = 0);
+                                    long long z_ms = 0, const struct FormatJob* fmt = nullptr, bool* fmt_done = nullptr);
 LBBNN_HIDDEN int launch_kl_finalize_all(const FinalizeArgs* a, const int* active, int n, uint64_t* rng, uint64_t advance,
                                         float* kl_total, hipStream_t s);
 LBBNN_HIDDEN int launch_kl_finalize(const FinalizeArgs* a, int n, hipStream_t s);

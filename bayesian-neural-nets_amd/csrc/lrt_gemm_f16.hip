@@ -402,28 +402,10 @@ int launch16(G16Args& a, int npv, bool xpl, hipStream_t s, bool* hosted) {
     return launch_one(lrt_gemm_f16s_kernel<TO, TB, WB, 3, false>, grid, block, lds, s, a);
 }
 
-// fp32 rows -> planes: one thread per 8 consecutive k (two float4 in, the hi unit and the lo unit out)
-__global__ __launch_bounds__(256) void format_x_kernel(const float* x, int ldx, char* planes, int ldp, int B, int I) {
-    const int groups = ldp >> 3;                                      // 8-k groups per row, zero tail included
-    const size_t n = (size_t)B * groups;
-    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (size_t)gridDim.x * 256) {
-        const int b = (int)(t / groups), g = (int)(t % groups), k = 8 * g;
-        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (k < I) {                                                  // I % 8 == 0: a group is inside or outside as a whole
-            const float4 f0 = *reinterpret_cast<const float4*>(x + (size_t)b * ldx + k);
-            const float4 f1 = *reinterpret_cast<const float4*>(x + (size_t)b * ldx + k + 4);
-            v[0] = f0.x; v[1] = f0.y; v[2] = f0.z; v[3] = f0.w; v[4] = f1.x; v[5] = f1.y; v[6] = f1.z; v[7] = f1.w;
-        }
-        uint32_t h[4], l[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            h[u] = cvt_pk_h(v[2 * u], v[2 * u + 1]);
-            l[u] = cvt_pk_h(v[2 * u] - h_lo(h[u]), v[2 * u + 1] - h_hi(h[u]));
-        }
-        char* p = planes + (size_t)b * ldp * 4 + (size_t)(k >> 5) * 128 + ((k >> 3) & 3) * 32;
-        *reinterpret_cast<uint4*>(p) = make_uint4(h[0], h[1], h[2], h[3]);
-        *reinterpret_cast<uint4*>(p + 16) = make_uint4(l[0], l[1], l[2], l[3]);
-    }
+// fp32 rows -> planes as a launch of its own (lbbnn_device.h: format_x_items; a fused forward lets the same job ride in the
+// launch of the planar flows instead: lbbnn_layers_operands_x)
+__global__ __launch_bounds__(256) void format_x_kernel(const FormatJob j) {
+    format_x_items(j, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
 }
 
 }  // namespace
@@ -436,8 +418,8 @@ extern "C" int lbbnn_format_x(const float* x, int ldx, void* planes, int ldp, in
         return LBBNN_E_ALIGN;
     const size_t n = (size_t)B * (ldp >> 3);
     const int blocks = (int)min((size_t)2048, (n + 255) / 256);
-    hipLaunchKernelGGL(format_x_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx,
-                       static_cast<char*>(planes), ldp, B, I);
+    const FormatJob j{x, static_cast<char*>(planes), ldx, ldp, B, I};
+    hipLaunchKernelGGL(format_x_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), j);
     return (int)hipGetLastError();
 }
 

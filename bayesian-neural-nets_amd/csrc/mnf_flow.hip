@@ -22,7 +22,10 @@ using namespace lbbnn;
 typedef lbbnn_planar_flow_t PlanarSet;
 struct FlowBatch { FlowArgs l[LBBNN_MAX_LAYERS];
                    // ensemble (fast kernel only): gridDim.z members, member m draws at offset rng[1] + m*m_adv, writes z_fwd + m*z_ms
-                   unsigned long long m_adv; long long z_ms; };
+                   unsigned long long m_adv; long long z_ms;
+                   // register kernel only: fmt.x != NULL => gridDim.x = 2 + fmt_blocks, and the extra workgroups of layer row 0
+                   // turn the network input into fp16 hi | lo planes (lbbnn_format_x's job) while the flow chains run
+                   FormatJob fmt; int fmt_blocks; };
 struct FinalizeBatch { FinalizeArgs l[LBBNN_MAX_LAYERS]; };
 
 // Apply the T planar transforms of `ps` to the LDS-resident z (flows2.py:86-95); returns sum of log-dets.
@@ -350,6 +353,13 @@ __global__ __launch_bounds__(kFastThreads) void mnf_flow_planar_fast_kernel(cons
 constexpr int kVecThreads = 512;
 
 __global__ __launch_bounds__(kVecThreads) void mnf_flow_planar_vec_kernel(const FlowBatch bt) {
+    if (blockIdx.x >= 2) {
+        // The flow chains are two latency-bound workgroups per layer on a 256-CU chip; the x-format job (25.6 MB of traffic
+        // for the headline batch, ~7 us as a launch of its own) runs on the CUs they leave idle, inside the same launch.
+        if (blockIdx.y == 0 && blockIdx.z == 0)
+            format_x_items(bt.fmt, (size_t)(blockIdx.x - 2) * kVecThreads + threadIdx.x, (size_t)bt.fmt_blocks * kVecThreads);
+        return;
+    }
     const LBBNN_CONST_AS FlowArgs& a = kernarg_as<FlowBatch>()->l[blockIdx.y];
     const bool klblk = blockIdx.x == 1;
     if (klblk && !a.want_kl) return;
@@ -749,9 +759,12 @@ bool fill_set(PlanarSet& ps, const float* const* u, const float* const* w, const
 
 namespace lbbnn {
 
-int launch_flow_planar(const FlowArgs* a, int n, hipStream_t s, int members, unsigned long long m_adv, long long z_ms) {
+int launch_flow_planar(const FlowArgs* a, int n, hipStream_t s, int members, unsigned long long m_adv, long long z_ms,
+                       const FormatJob* fmt, bool* fmt_done) {
     FlowBatch bt;
     bt.m_adv = m_adv; bt.z_ms = z_ms;
+    bt.fmt = FormatJob{}; bt.fmt_blocks = 0;
+    if (fmt_done) *fmt_done = false;
     int maxI = 0; bool small_t = true, any_kl = false;
     for (int i = 0; i < n; ++i) {
         bt.l[i] = a[i];
@@ -788,7 +801,15 @@ int launch_flow_planar(const FlowArgs* a, int n, hipStream_t s, int members, uns
             for (int t = 0; t < f.zf.T && vec; ++t) vec = al16(f.zf.u[t]) && al16(f.zf.w[t]);
             for (int t = 0; t < (f.want_kl ? f.rf.T : 0) && vec; ++t) vec = al16(f.rf.u[t]) && al16(f.rf.w[t]);
         }
-        if (vec) hipLaunchKernelGGL(mnf_flow_planar_vec_kernel, grid, dim3(kVecThreads), 0, s, bt);
+        if (vec && fmt && fmt->x && any_kl) {
+            // (any_kl: gridDim.x == 2, so the format workgroups are blockIdx.x >= 2)
+            const size_t items = (size_t)fmt->B * (fmt->ldp >> 3);
+            bt.fmt = *fmt;
+            bt.fmt_blocks = (int)((items + kVecThreads - 1) / kVecThreads < 1024 ? (items + kVecThreads - 1) / kVecThreads : 1024);
+            dim3 g2(2 + bt.fmt_blocks, n, grid.z);
+            hipLaunchKernelGGL(mnf_flow_planar_vec_kernel, g2, dim3(kVecThreads), 0, s, bt);
+            if (fmt_done) *fmt_done = true;
+        } else if (vec) hipLaunchKernelGGL(mnf_flow_planar_vec_kernel, grid, dim3(kVecThreads), 0, s, bt);
         else if (fast) hipLaunchKernelGGL(mnf_flow_planar_fast_kernel, grid, dim3(kFastThreads), need, s, bt);
         else if (members > 1) return LBBNN_E_SHAPE;                     // the member dimension exists in the fast form only
         else      hipLaunchKernelGGL(mnf_flow_planar_lds_kernel, grid, block, need, s, bt);

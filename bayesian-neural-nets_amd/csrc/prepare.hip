@@ -7,7 +7,8 @@
 using namespace lbbnn;
 
 static int layers_prepare_impl(const lbbnn_layer_desc_t* L, int n, const uint64_t* rng, void* stream, bool with_k5,
-                               uint64_t* rng_live = nullptr, uint64_t* rng_snap = nullptr, uint64_t advance = 0) {
+                               uint64_t* rng_live = nullptr, uint64_t* rng_snap = nullptr, uint64_t advance = 0,
+                               const FormatJob* fmt = nullptr) {
     if (!L) return LBBNN_E_NULL;
     if (n <= 0 || n > LBBNN_MAX_LAYERS) return LBBNN_E_SHAPE;
     FlowArgs fa[LBBNN_MAX_LAYERS];
@@ -75,7 +76,12 @@ static int layers_prepare_impl(const lbbnn_layer_desc_t* L, int n, const uint64_
     if (in_kernel) {
         for (int i = 0; i < n; ++i) if (flow_of[i] >= 0) make_in_flow(inf[i], fa[flow_of[i]]);
     } else if (nf) {
-        rc = launch_flow_planar(fa, nf, s); if (rc) return rc;
+        bool fmt_done = false;
+        rc = launch_flow_planar(fa, nf, s, 1, 0, 0, fmt, &fmt_done); if (rc) return rc;
+        if (fmt_done) fmt = nullptr;
+    }
+    if (fmt) {          // no flow launch to ride in (LRT layers, in-kernel flows, shapes the register kernel does not take)
+        rc = lbbnn_format_x(fmt->x, fmt->ldx, fmt->planes, fmt->ldp, fmt->B, fmt->I, stream); if (rc) return rc;
     }
     rc = launch_weight_pass(wa, n, s, rng_live, rng_snap, advance, in_kernel ? inf : nullptr); if (rc) return rc;
     if (nk && with_k5) { rc = launch_kl_finalize(ka, nk, s); if (rc) return rc; }
@@ -94,6 +100,17 @@ extern "C" int lbbnn_layers_operands_snap(const lbbnn_layer_desc_t* L, int n, ui
                                           uint64_t advance, void* stream) {
     if (rng && !rng_snap) return LBBNN_E_NULL;
     return layers_prepare_impl(L, n, rng, stream, false, rng, rng_snap, advance);
+}
+
+extern "C" int lbbnn_layers_operands_x(const lbbnn_layer_desc_t* L, int n, uint64_t* rng, uint64_t* rng_snap, uint64_t advance,
+                                       const float* x, int ldx, void* planes, int ldp, int B, int I, void* stream) {
+    if (rng && !rng_snap) return LBBNN_E_NULL;
+    if (!x || !planes) return LBBNN_E_NULL;
+    if (B <= 0 || I <= 0 || ldx < I || ldp < I) return LBBNN_E_SHAPE;
+    if ((I & 7) || (ldx & 3) || (ldp & 31) || (reinterpret_cast<uintptr_t>(x) & 15u) || (reinterpret_cast<uintptr_t>(planes) & 15u))
+        return LBBNN_E_ALIGN;
+    const FormatJob j{x, static_cast<char*>(planes), ldx, ldp, B, I};
+    return layers_prepare_impl(L, n, rng, stream, false, rng, rng_snap, advance, &j);
 }
 
 extern "C" int lbbnn_ensemble_operands(const lbbnn_layer_desc_t* L, int n, int members, const uint64_t* rng,

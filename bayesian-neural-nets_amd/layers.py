@@ -42,10 +42,12 @@ _MASKS_IN_KERNEL = _os.environ.get("LBBNN_TORCH_MASKS", "0") != "1"
 # pass (default: while a HIP graph is being captured they go on a side stream beside the weight pass and the first GEMM -- only
 # the KL finalize needs them; "always": in eager launches too)
 _DENSE_DEFER = {"0": False, "always": "always"}.get(_os.environ.get("LBBNN_DENSE_DEFER", "1"), True)
-# LBBNN_F16_FIRST=planes: the first row-scaled-fp16 layer of a fused forward is given its input as planes made by an
-# lbbnn_format_x launch.  Default (f32): it takes the fp32 network input as it is and splits it in registers -- measured on the
-# headline net (tools/precision_time.py, same process): 0.1487 ms against 0.1543 ms per forward; the 6.9 us launch costs more
-# than the in-register split of the first layer's x (~1.3 us of its GEMM).
+# LBBNN_F16_FIRST=planes: the first row-scaled-fp16 layer of a fused forward reads the network input as fp16 hi | lo planes,
+# made by extra workgroups of the flow launch (lbbnn_layers_operands_x).  Default (f32): it takes the fp32 input as it is and
+# splits it in registers.  Measured on the headline net (tools/precision_time.py, one process, interleaved): the in-register
+# split costs the first GEMM's K loop 1.33 us per step instead of 1.08 (~6 us); the format pass costs 6.9 us as a launch of its
+# own (0.1543 against 0.1487 ms per forward) and as much as it saves when it rides in the flow launch (0.1401 against
+# 0.1392 ms): no form of the pre-pass beats the in-register split, so the simpler one is the default.
 _F16_FIRST_PLANES = _os.environ.get("LBBNN_F16_FIRST", "f32") != "f32"
 _SIDE = {}
 
@@ -1229,9 +1231,22 @@ class _NetworkBase(nn.Module):
         # snapshots the Philox state for the rest of this forward.  The live offset is advanced by the extra workgroup of
         # the first GEMM's launch (lbbnn_lrt_gemm_finalize_adv): every workgroup of THIS launch reads it.
         snap = st.t[2:4] if st is not None else None
-        _lib.check(_lib.lib().lbbnn_layers_operands_snap(descs, n, rng.data_ptr() if rng is not None else None,
-                                                         snap.data_ptr() if snap is not None else None, 0, stream),
-                   "lbbnn_layers_operands_snap")
+        # A first layer in the row-scaled fp16 format reads its x as fp16 hi | lo planes: the format pass over the network
+        # input rides in the SAME launch as the planar flows (lbbnn_layers_operands_x: extra workgroups on the CUs the two
+        # flow workgroups per layer leave idle), so the first GEMM spends no VALU on the split and no launch is added.
+        B, x_planes = x.shape[0], False
+        if (layers[0]._split_now >= 2 and _F16_FIRST_PLANES and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+                and B > 0):
+            xp = self._planes("in", B, layers[0].in_features, dev, plan)
+            _lib.check(_lib.lib().lbbnn_layers_operands_x(descs, n, rng.data_ptr() if rng is not None else None,
+                                                          snap.data_ptr() if snap is not None else None, 0,
+                                                          x.data_ptr(), x.stride(0), xp.data_ptr(), xp.stride(0), B,
+                                                          layers[0].in_features, stream), "lbbnn_layers_operands_x")
+            x, x_planes = xp, True
+        else:
+            _lib.check(_lib.lib().lbbnn_layers_operands_snap(descs, n, rng.data_ptr() if rng is not None else None,
+                                                             snap.data_ptr() if snap is not None else None, 0, stream),
+                       "lbbnn_layers_operands_snap")
         if deferred is not None:
             # enqueued AFTER the weight pass: a captured graph keeps the first-recorded successor of a fork on the parent's queue,
             # and a hop to another queue costs ~11 us -- it must be the side branch that pays it, not the weight pass
@@ -1244,7 +1259,6 @@ class _NetworkBase(nn.Module):
             defer_ev.record(side)
         all_kl = want_kl and all(c[1] for c in cfgs)
         fin_at = 1 if defer_ev is not None else 0
-        B, x_planes = x.shape[0], False
         for i, (l, c) in enumerate(zip(layers, cfgs)):
             # the KL finalize of all layers (parameters only) rides in the first GEMM's launch as one extra workgroup (in the
             # second's when part of the dense flows was deferred: it waits for the side stream first)
@@ -1259,9 +1273,6 @@ class _NetworkBase(nn.Module):
             # the next GEMM's LDS-DMA as they lie): no fp32 copy of a hidden activation is stored in this no-grad forward
             fmt = l._split_now
             give_planes = (fmt >= 2 and i + 1 < n and layers[i + 1]._split_now >= 2 and l.out_features % 8 == 0)
-            if fmt >= 2 and i == 0 and _F16_FIRST_PLANES and not x_planes:
-                x = ops.format_x(x, self._planes("in", B, l.in_features, dev, plan))
-                x_planes = True
             obuf = None
             if plan is not None and not give_planes:
                 obuf = plan.setdefault("out%d" % i, torch.empty(B, l.out_features, dtype=torch.float32, device=dev))

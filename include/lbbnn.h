@@ -785,6 +785,13 @@ int lbbnn_lrt_gemm_ex(const lbbnn_gemm_desc_t* d, void* stream);
  * Writes the whole row of planes (tail slots zero). */
 int lbbnn_format_x(const float* x, int ldx, void* planes, int ldp, int B, int I, void* stream);
 
+/* lbbnn_layers_operands_snap + lbbnn_format_x of the network input in the SAME launches: the planar flows of a network are two
+ * latency-bound workgroups per layer, and the format job (one pass over x) runs as extra workgroups of that launch on the CUs
+ * it leaves idle -- no launch of its own, nothing added to the critical path.  Falls back to a separate lbbnn_format_x launch
+ * when the flow launch cannot carry it (no planar flows, shapes outside the register form of the flow kernel). */
+int lbbnn_layers_operands_x(const lbbnn_layer_desc_t* layers, int n, uint64_t* rng, uint64_t* rng_snap, uint64_t advance,
+                            const float* x, int ldx, void* planes, int ldp, int B, int I, void* stream);
+
 /* lbbnn_weight_pass producing LBBNN_F_F16S operands + their row scales (single layer; the batched form is
  * lbbnn_layers_operands with split == 2). */
 int lbbnn_weight_pass_f16(const float* mu, const float* rho, const float* lambdal,
