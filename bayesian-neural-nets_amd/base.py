@@ -8,6 +8,7 @@ Monte-Carlo log-probability sums) and ``F.linear`` run in HIP (lbbnn_gate_sample
 """
 import ctypes
 import itertools
+import math
 
 import torch
 import torch.nn as nn
@@ -22,8 +23,10 @@ NUM_BATCHES = 600        # len(train_loader) with BATCH_SIZE = 100 on MNIST (LBB
 
 
 class GaussGamma(object):
-    """Normal-Gamma prior helper (LBBNN-GP-MF.py:132-151): holds a, b and the ``exact`` switch; the density is
-    evaluated inside the HIP pass, the Gamma(a,b) draw of :141 with torch."""
+    """Normal-Gamma prior helper (LBBNN-GP-MF.py:132-151): a, b and the ``exact`` switch.  On the hot path the density is
+    evaluated inside the HIP pass (lbbnn_gate_sample) with the Gamma(a, b) draw of :141 taken by ``rsample_tau``;
+    ``log_prob`` is the same density as torch ops, for callers that evaluate the prior outside ``forward`` and for the
+    differentiable posterior-mean branches of the layer."""
 
     def __init__(self, a, b):
         self.a, self.b = a, b
@@ -32,6 +35,15 @@ class GaussGamma(object):
     def rsample_tau(self):
         return torch.distributions.Gamma(self.a, self.b).rsample()
 
+    def log_prob(self, input, gamma, tau=None):
+        """:140-151.  ``tau``: the Gamma(a, b) draw (default: a fresh ``rsample``, as the reference draws one per call)."""
+        if tau is None:
+            tau = self.rsample_tau()                                                     # :141
+        g = torch.round(gamma.detach()) if self.exact else gamma                         # :142-143
+        a, b = self.a, self.b
+        return (g * (a * torch.log(b) + (a - 0.5) * tau - b * tau - torch.lgamma(a)
+                     - 0.5 * math.log(2 * math.pi)) - tau * torch.pow(input, 2) + (1 - g) + 1e-8).sum()   # :144-150
+
 
 class BetaBinomial(object):
     """LBBNN-GP-MF.py:155-179."""
@@ -39,6 +51,15 @@ class BetaBinomial(object):
     def __init__(self, pa, pb):
         self.pa, self.pb = pa, pb
         self.exact = False
+
+    def log_prob(self, input, pa=None, pb=None):
+        """:162-173 (the reference takes pa / pb arguments and ignores them in favour of the attributes; so does this)."""
+        g = torch.round(input.detach()) if self.exact else input
+        one = torch.ones_like(input)
+        pa_, pb_ = self.pa, self.pb
+        return (torch.lgamma(one) + torch.lgamma(g + one * pa_) + torch.lgamma(one * (1 + pb_) - g)
+                + torch.lgamma(one * (pa_ + pb_)) - torch.lgamma(one * pa_ + g) - torch.lgamma(one * 2 - g)
+                - torch.lgamma(one * (1 + pa_ + pb_)) - torch.lgamma(one * pa_) - torch.lgamma(one * pb_)).sum()
 
     def rsample(self):
         p = torch.distributions.Beta(self.pa, self.pb).rsample()
@@ -199,6 +220,20 @@ class BayesianLinear(nn.Module):
         saved["cg"] = cg
         return out, lp, lq, saved
 
+    def _mean_branch_autograd(self, x, cgamma, tau_w, tau_b, mode):
+        """LBBNN-GP-MF.py:236-255 for the two deterministic branches, as autograd-visible torch ops (GPU tensors)."""
+        alpha_attr = self.alpha.to(x.device) if torch.is_tensor(self.alpha) else self.alpha
+        weight = cgamma * self.weight.mu if mode == 1 else alpha_attr * self.weight.mu           # :236-242
+        bias = self.bias.mu
+        alpha_new = 1 / (1 + torch.exp(-self.lambdal))                                             # :246
+        lp = (self.weight_prior.log_prob(weight, cgamma, tau=tau_w) + self.bias_prior.log_prob(bias, torch.ones_like(bias), tau=tau_b)
+              + self.gamma_prior.log_prob(cgamma, pa=self.pa, pb=self.pb))                         # :247-249
+        galpha = self.gamma.alpha
+        gm = Bernoulli(galpha.to(x.device) if torch.is_tensor(galpha) else galpha, exact=self.gamma.exact)
+        lq = self.weight.full_log_prob(input=weight, gamma=cgamma) + gm.log_prob(cgamma) + self.bias.log_prob(bias)   # :250-251
+        del alpha_new
+        return F.linear(x, weight, bias), lp, lq                                                   # :255
+
     def _noise_for_backward(self, saved):
         n = dict(saved.get("noise") or {})
         if "eps_w" not in n and saved.get("rng") is not None:
@@ -234,9 +269,13 @@ class BayesianLinear(nn.Module):
             out, lp, lq = _BaseFn.apply(self, x, cgamma.to(dev), tau_w, tau_b, galpha.to(dev), cfg, *params)
         else:
             if needs and want_lp:
-                raise NotImplementedError("bnn_amd: gradients through the medimean / mean branches with calculate_log_probs "
-                                          "are not implemented (the reference differentiates the sampled branch only, "
-                                          "LBBNN-GP-MF.py:331-337); wrap evaluation in torch.no_grad()")
+                # medimean / joint-mean branch with calculate_log_probs under autograd (LBBNN-GP-MF.py:236-251): not a path
+                # the reference's train() differentiates (:331-337 samples), so it is composed from differentiable torch
+                # ops on the GPU tensors (the helper objects' densities); every other combination runs the HIP pass
+                out, lp, lq = self._mean_branch_autograd(x, cgamma.to(dev), tau_w, tau_b, mode)
+                self.alpha = 1 / (1 + torch.exp(-self.lambdal))
+                self.log_prior, self.log_variational_posterior = lp, lq
+                return out
             out, lp, lq, _ = self._forward_hip(x, cgamma, tau_w, tau_b, cfg)
         if want_lp:
             self.alpha = 1 / (1 + torch.exp(-self.lambdal))           # :246

@@ -156,9 +156,6 @@ struct StageArgs {
     int I; int path_lo, npaths;   // paths handled: path_lo .. path_lo + npaths - 1
     const float* Pin;     // [2][nwg][HMAX]: this transform's hidden pre-activation partials, written by the previous launch
     NextA nx;
-#ifdef LAB_STAMPS             // tools/lab diagnostic build only: phase times of the output stage (10 ns units) into scal[5..7]
-    float* lab;
-#endif
 };
 
 struct StageBatch { StageArgs l[LBBNN_MAX_LAYERS]; };
@@ -180,9 +177,6 @@ __global__ __launch_bounds__(NTC) void dense_stage_c_kernel(const StageBatch bt,
     const int lane = tid & 63, wv = tid >> 6;
     const bool c0 = lane < H, c1 = lane + 64 < H;
     const bool rnvp = a.tr.kind == LBBNN_FLOW_RNVP;
-#ifdef LAB_STAMPS
-    const uint64_t lab_t0 = __builtin_amdgcn_s_memrealtime();
-#endif
     // Everything this workgroup reads from global memory is requested up front, so the kernel pays ONE memory latency
     // instead of one per phase (it is a chain of tiny dependent steps: measured 21 us with the loads where they are used):
     //  - the rows of the two head matrices of this wave's 16 outputs -> registers
@@ -255,9 +249,6 @@ __global__ __launch_bounds__(NTC) void dense_stage_c_kernel(const StageBatch bt,
         if (a.keep_chain && blockIdx.x == 0) a.h[path][tid] = h1;
     }
     __syncthreads();
-#ifdef LAB_STAMPS
-    if (blockIdx.x == 0 && tid == 0) a.lab[0] = (float)(__builtin_amdgcn_s_memrealtime() - lab_t0);
-#endif
     int cur = 0;
     if (rnvp) {
 #pragma unroll
@@ -291,9 +282,6 @@ __global__ __launch_bounds__(NTC) void dense_stage_c_kernel(const StageBatch bt,
             cur ^= 1;
         }
     } else if (a.keep_chain && blockIdx.x == 0 && tid < H) a.h[path][3 * HMAX + tid] = hs[0][tid];
-#ifdef LAB_STAMPS
-    if (blockIdx.x == 0 && tid == 0) a.lab[1] = (float)(__builtin_amdgcn_s_memrealtime() - lab_t0);
-#endif
     // heads: one WAVE per output row i, lanes over the H columns (coalesced 4*H-byte rows of the two head matrices)
     const float y0 = c0 ? hs[cur][lane] : 0.f, y1 = c1 ? hs[cur][lane + 64] : 0.f;
     float ldw = 0.f;
@@ -320,9 +308,6 @@ __global__ __launch_bounds__(NTC) void dense_stage_c_kernel(const StageBatch bt,
     __syncthreads();
     if (tid == 0) a.ld_part[path][blockIdx.x] = (float)((scratch[0] + scratch[1]) + (scratch[2] + scratch[3]));
     partial_a_reduce(a.nx, path, znew, nwg, pr);                                // (znew complete: the barrier above)
-#ifdef LAB_STAMPS
-    if (blockIdx.x == 0 && tid == 0) a.lab[2] = (float)(__builtin_amdgcn_s_memrealtime() - lab_t0);
-#endif
 }
 
 struct FinishArgs {
@@ -467,9 +452,6 @@ static int dense_flows_impl(const lbbnn_dense_layer_t* L, int n, const uint64_t*
             sa.I = d.I;
             sa.Pin = b.P[t & 1];
             sa.nx = next_of(d, b, t + 1);
-#ifdef LAB_STAMPS
-            sa.lab = d.scal + 5;
-#endif
             sa.path_lo = zphase ? 0 : 1;
             sa.npaths = zphase ? npaths : 1;
         }

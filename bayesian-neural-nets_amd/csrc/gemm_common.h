@@ -18,7 +18,6 @@ namespace {
 __device__ __forceinline__ void tile_of_block(int& ox, int& by, int extra_rows = 0) {
     const int nx = gridDim.x, ny = gridDim.y - extra_rows, n = nx * ny;
     int t = blockIdx.y * nx + blockIdx.x;
-#ifndef LAB_XCD_1D
     if ((n & 7) == 0 && (ny & 3) == 0) {
         const int xcd = t & 7, s = t >> 3, per = n >> 3, q = ny >> 2;      // per: tiles per XCD, q: b tiles per group
         const int idx = (xcd & 1) * per + s;                              // position inside the b group, o-major
@@ -26,7 +25,6 @@ __device__ __forceinline__ void tile_of_block(int& ox, int& by, int extra_rows =
         by = (xcd >> 1) * q + idx % q;
         return;
     }
-#endif
     if ((n & 7) == 0) t = (t & 7) * (n >> 3) + (t >> 3);
     ox = t % nx; by = t / nx;
 }

@@ -74,14 +74,14 @@ __device__ __forceinline__ GemmArgs member_view(const GemmArgs& in) {
     return a;
 }
 
-struct EpiCtx { bool ovec; uint64_t seed, offs; bool lab_const; };
+struct EpiCtx { bool ovec; uint64_t seed, offs; };
 
 template <bool MEAN_ONLY>
 __device__ __forceinline__ EpiCtx make_epi_ctx(const GemmArgs& a) {
     EpiCtx c;
     c.ovec = ((a.O & 3) == 0) && ((a.ldo & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0) &&
              (!a.eps || (reinterpret_cast<uintptr_t>(a.eps) & 15u) == 0);
-    c.seed = 0; c.offs = 0; c.lab_const = false;
+    c.seed = 0; c.offs = 0;
     if (!MEAN_ONLY && !a.eps) { c.seed = a.rng[0]; c.offs = a.rng[1] + a.m_off; }
     return c;
 }
@@ -121,14 +121,7 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& a, const EpiCtx& c, co
 #pragma unroll
             for (int r = 0; r < 4; ++r) e[r] = e_in[r];
         } else {
-#ifdef LAB_NO_PHILOX         // tools/lab ablation only: cost of the in-kernel draws in the epilogue
-            e[0] = 0.3f; e[1] = -0.7f; e[2] = 1.1f; e[3] = -0.2f;
-#else
-#ifdef LAB_ASYM
-            if (c.lab_const) { e[0] = 0.3f; e[1] = -0.7f; e[2] = 1.1f; e[3] = -0.2f; } else
-#endif
             philox_normal4(c.seed, c.offs, a.rng_stream, (uint64_t)(a.row_offset + b), (uint32_t)(o >> 2), e);
-#endif
         }
     }
 #pragma unroll
@@ -153,9 +146,6 @@ __device__ __forceinline__ void load4_rows(const float* p, bool vec, int o, int 
 }
 
 __device__ __forceinline__ void store4_rows(float* p, bool vec, int o, int O, const float v[4]) {
-#ifdef LAB_NO_STORE          // tools/lab ablation only: what the output stores cost a launch (kept alive by an impossible condition)
-    if (v[0] != 123456.789f) return;
-#endif
     if (vec) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
     else {
 #pragma unroll
@@ -172,9 +162,8 @@ __device__ __forceinline__ void store4_rows(float* p, bool vec, int o, int O, co
 // (tools/gemm_ksweep.py: 16.4 us of a launch did not depend on K).
 template <int TO, int TB, bool MEAN_ONLY>
 __device__ __forceinline__ void epilogue_tile(const GemmArgs& a, int o0, int q, int brow0,
-                                              const floatx4 (&accm)[TO][TB], const floatx4 (&accv)[TO][TB], bool lab_const = false) {
+                                              const floatx4 (&accm)[TO][TB], const floatx4 (&accv)[TO][TB]) {
     EpiCtx ec = make_epi_ctx<MEAN_ONLY>(a);
-    ec.lab_const = lab_const;
     OConst oc[TO];
 #pragma unroll
     for (int i = 0; i < TO; ++i) {
@@ -551,18 +540,11 @@ __device__ __forceinline__ int swzx(int r) { return (((r >> 1) & 3) << 1) | ((r 
 // contract; its own tolerance in the tests), so never the default.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-#ifdef LAB_GEMM_STAMPS          // tools/lab diagnostic build only (tools/gemm_stamps.py): per-step phase stamps of a few waves
-constexpr int LAB_ST_SLOTS = 64, LAB_ST_STEPS = 48, LAB_ST_PH = 8;
-__device__ uint32_t lab_gemm_stamps[LAB_ST_SLOTS * LAB_ST_STEPS * LAB_ST_PH];
-#endif
 // (the body is a __device__ function: with the LDS-DMA builtin fed from an array element directly inside a __global__ template,
 // hipcc 7.2's host pass silently drops the kernel's host stub -- undefined symbol at load time)
 template <int TO, int TB, int WB, bool MEAN_ONLY, int NP, bool F16>
 __device__ __forceinline__ void lrt_gemm_bf16x3_body(const GemmArgs& a_in) {
     static_assert(!F16 || NP == 1, "fp16 operands exist in the single-product form only");
-#ifdef LAB_EMPTY             // tools/lab ablation only: the launch itself (dispatch of the grid with its LDS / register footprint), no work
-    if (a_in.B > 0) return;
-#endif
     const GemmArgs a = member_view(a_in);
     constexpr int BN = TO * 16, BM = TB * WB * 16;
     constexpr int NWR = MEAN_ONLY ? 1 : 2;               // weight regions: e_w (, var_w); a row = [hi 64 B | lo 64 B]
@@ -751,90 +733,26 @@ __device__ __forceinline__ void lrt_gemm_bf16x3_body(const GemmArgs& a_in) {
         }
     };
 
-#ifdef LAB_ASYM          // tools/lab experiment: would it pay to have the second workgroup of a CU draw its noise BEFORE its main loop?
-    // (dispatch is breadth-first: workgroups i and i + 256 share a CU -- tools/gemm_stamps.py).  Role B = linear ids 256..511:
-    // the 10 Philox calls of its tile run here (results folded into one value, kept alive), its epilogue uses constants.
-    const bool lab_role_b = !MEAN_ONLY && a.rng && (((blockIdx.x + gridDim.x * blockIdx.y) >> 8) & 1);
-    float lab_fold = 0.f;
-    if (lab_role_b) {
-        const uint64_t sd = a.rng[0], of = a.rng[1];
-#pragma unroll 1
-        for (int k = 0; k < TO * TB; ++k) {
-            float e4[4];
-            philox_normal4(sd, of, a.rng_stream, (uint64_t)(a.row_offset + b0 + k * 16 + lr), (uint32_t)(o0 + 4 * q + k), e4);
-            lab_fold += e4[0] + e4[1] + e4[2] + e4[3];
-        }
-    }
-#endif
-#ifdef LAB_GEMM_STAMPS
-    const int lab_lin = blockIdx.x + gridDim.x * blockIdx.y;
-    const bool lab_on = (lab_lin % 32) == 0 && lab_lin / 32 < LAB_ST_SLOTS / 4 && WB == 4 && !MEAN_ONLY;
-    uint32_t* const lab_w = lab_gemm_stamps + (size_t)((lab_lin / 32) * 4 + wv) * LAB_ST_STEPS * LAB_ST_PH;
-    const uint32_t lab_k0 = (uint32_t)__builtin_readcyclecounter();
-#define LAB_T(v) const uint32_t v = (uint32_t)__builtin_readcyclecounter()
-#else
-#define LAB_T(v)
-#endif
     dma_step(0, smc);
     __syncthreads();
     for (int c = 0; c < nsteps; ++c) {
-        LAB_T(lab_t0);
         read_frags(smc + (c & 1) * BUFB);
         __builtin_amdgcn_sched_barrier(0);
-        LAB_T(lab_t1);
-#ifndef LAB_NO_DMA          // tools/lab ablation builds only; never defined in the product library
         if (c + 1 < nsteps) dma_step(c + 1, smc + ((c & 1) ^ 1) * BUFB);
-#endif
         __builtin_amdgcn_sched_barrier(0);
-        LAB_T(lab_t2);
-#ifndef LAB_NO_MFMA
         mfmas();
-#endif
         __builtin_amdgcn_sched_barrier(0);
-        LAB_T(lab_t3);
         __syncthreads();
-#ifdef LAB_GEMM_STAMPS
-        if (lab_on && lane == 0 && c + 1 < LAB_ST_STEPS) {
-            const uint32_t lab_t4 = (uint32_t)__builtin_readcyclecounter();
-            uint32_t* w = lab_w + (c + 1) * LAB_ST_PH;
-            w[0] = lab_t0 - lab_k0; w[1] = lab_t1 - lab_k0; w[2] = lab_t2 - lab_k0; w[3] = lab_t3 - lab_k0; w[4] = lab_t4 - lab_k0;
-        }
-#endif
     }
-#ifdef LAB_GEMM_STAMPS
-    const uint32_t lab_k1 = (uint32_t)__builtin_readcyclecounter();
-#endif
 
     GemmArgs ao = a;                                     // split-K: partial product z goes to its own output slab
     if (a.kchunk) ao.out = a.out + (size_t)blockIdx.z * a.split_stride;
-#ifdef LAB_ASYM
-    if (lab_fold == 123.456f) ao.out[0] = lab_fold;
-    epilogue_tile<TO, TB, MEAN_ONLY>(ao, o0, q, b0 + wv * TB * 16 + lr, accm, accv, lab_role_b);
-#else
     epilogue_tile<TO, TB, MEAN_ONLY>(ao, o0, q, b0 + wv * TB * 16 + lr, accm, accv);
-#endif
-#ifdef LAB_GEMM_STAMPS
-    if (lab_on && lane == 0) {
-        uint32_t hwid, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        lab_w[0] = hwid; lab_w[1] = xcc; lab_w[2] = lab_k1 - lab_k0; lab_w[3] = (uint32_t)__builtin_readcyclecounter() - lab_k0;
-        lab_w[4] = (uint32_t)nsteps; lab_w[5] = (uint32_t)lab_lin;
-        lab_w[6] = (uint32_t)__builtin_amdgcn_s_memrealtime();
-    }
-#endif
 }
 template <int TO, int TB, int WB, bool MEAN_ONLY, int NP = 3, bool F16 = false>
 __global__ __launch_bounds__(WB * 64, (TB * TO > 10) ? 1 : (WB == 8 ? 4 : 2)) void lrt_gemm_bf16x3_kernel(const GemmArgs a_in) {
     lrt_gemm_bf16x3_body<TO, TB, WB, MEAN_ONLY, NP, F16>(a_in);
 }
-#ifdef LAB_GEMM_STAMPS
-}  // namespace
-extern "C" int lbbnn_lab_gemm_stamps(void* host, size_t bytes) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(lab_gemm_stamps), bytes);
-}
-namespace {
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // (A 256 x 80 three-stage ring form of the kernel above -- one 8-wave workgroup per CU, LDS-DMA two K steps ahead, the two
@@ -859,11 +777,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void lrt_gemm_skinny_kernel(const Ge
     __shared__ __attribute__((aligned(16))) float red[SK_WAVES][2][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int lr = lane & 15, q = lane >> 4;
-#ifdef LAB_SK_ROWS           // tools/lab experiment: fewer batch rows per workgroup (more workgroups, two per CU)
-    constexpr int SKR = LAB_SK_ROWS;
-#else
     constexpr int SKR = 16;
-#endif
     const int b0 = blockIdx.x * SKR;
     const int b = b0 + lr;
     const bool brow = b < a.B && lr < SKR, orow = lr < a.O;
@@ -1020,15 +934,6 @@ int launch_split(GemmArgs& a, bool mean_only, hipStream_t s, bool* hosted) {
     // (one workgroup/CU), 128x160 with 4 or 8 waves, x split once per tile through LDS, x delivered pre-split.
     const long nz = a.kchunk ? (a.I + a.kchunk - 1) / a.kchunk : 1;
     const long blocks_big = (long)((a.O + 79) / 80) * ((a.B + 127) / 128) * nz;
-#ifdef LAB_GEMM_542         // tools/lab experiment: the same 128x80 tile computed by TWO waves of 64 rows each
-    if (blocks_big >= 256 && a.B >= 96) return launch_split_cfg<5, 4, 2>(a, mean_only, s, hosted);
-#endif
-#ifdef LAB_GEMM_518         // tools/lab experiment: ... by EIGHT waves of 16 rows each (4 waves per SIMD at 2 workgroups per CU)
-    if (blocks_big >= 256 && a.B >= 96) return launch_split_cfg<5, 1, 8>(a, mean_only, s, hosted);
-#endif
-#ifdef LAB_FORCE_BIG       // tools/lab experiment (tools/two_stream_gemm.py): the 128x80 tile for row shards of the batch too
-    if (a.B >= 96) return launch_split_cfg<5, 2, 4>(a, mean_only, s, hosted);
-#endif
     if (blocks_big >= 256 && a.B >= 96) return launch_split_cfg<5, 2, 4>(a, mean_only, s, hosted);
     return launch_split_cfg<5, 1, 2>(a, mean_only, s, hosted);
 }
@@ -1087,11 +992,7 @@ static int lrt_gemm_impl(const float* x, int ldx, const void* e_w, const void* v
     }
     if (O <= 16) {
         a.fin.n = 0;
-#ifdef LAB_SK_ROWS
-        dim3 grid((B + LAB_SK_ROWS - 1) / LAB_SK_ROWS), block(SK_WAVES * 64);
-#else
         dim3 grid((B + 15) / 16, 1, a.members > 1 ? a.members : 1), block(SK_WAVES * 64);
-#endif
         if (mean_only) {
             if (xvec) hipLaunchKernelGGL((lrt_gemm_skinny_kernel<true, true>), grid, block, 0, s, a);
             else      hipLaunchKernelGGL((lrt_gemm_skinny_kernel<true, false>), grid, block, 0, s, a);

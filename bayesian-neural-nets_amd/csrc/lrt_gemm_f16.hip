@@ -377,7 +377,7 @@ __device__ __forceinline__ void gemm_f16s_body(const G16Args& a) {
 }
 
 template <int TO, int TB, int WB, int NPV, bool XPL>
-__global__ __launch_bounds__(WB * 64, WB == 8 ? 2 : 2) void lrt_gemm_f16s_kernel(const G16Args a) {
+__global__ __launch_bounds__(WB * 64, 2) void lrt_gemm_f16s_kernel(const G16Args a) {
     gemm_f16s_body<TO, TB, WB, NPV, XPL>(a);
 }
 
@@ -461,9 +461,11 @@ extern "C" int lbbnn_lrt_gemm_ex(const lbbnn_gemm_desc_t* d, void* stream) {
     bool hosted = false;
     const long blocks_big = (long)((O + 79) / 80) * ((B + 127) / 128);
     int rc;
-    static const int cfg = [] { const char* e = getenv("LBBNN_GEMM16_CFG"); return e ? atoi(e) : 0; }();   // A/B knob (bench sweeps)
-    if (cfg == 528 && B >= 256) rc = launch16<5, 2, 8>(a, npv, xpl, s, &hosted);
-    else if (blocks_big >= 256 && B >= 96) rc = launch16<5, 2, 4>(a, npv, xpl, s, &hosted);
+    // Tile configurations measured and dropped in round 3 (3 + 1 form, headline net, tools/precision_time.py): 256 x 80 with
+    // eight waves and one workgroup per CU (<5,2,8>: a third fewer LDS-DMA pieces per product) 0.1513 ms per forward against
+    // 0.1442 -- one barrier-locked workgroup loses the overlap two independent ones give each other; 128 x 80 with eight waves
+    // of 16 rows at four waves per SIMD (<5,1,8>) does not fit 128 VGPRs (61-96 spilled).
+    if (blocks_big >= 256 && B >= 96) rc = launch16<5, 2, 4>(a, npv, xpl, s, &hosted);
     else rc = launch16<5, 1, 2>(a, npv, xpl, s, &hosted);
     if (rc || !want_fin || hosted) return rc;
     if (d->n_layers > 0)

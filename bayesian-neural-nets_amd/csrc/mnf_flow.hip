@@ -231,9 +231,6 @@ __global__ __launch_bounds__(kFastThreads) void mnf_flow_planar_fast_kernel(cons
     __shared__ double red[NV][kFastWaves];
     __shared__ float s_bias[kFastT];
     const int I = a.I, P = pad64(I), tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-#ifdef LAB_STAMPS            // tools/lab diagnostic build only: phase times (10 ns units) into the unused scal[5..7]
-    const uint64_t lab_t0 = __builtin_amdgcn_s_memrealtime();
-#endif
     const float* eps = klblk ? a.eps_kl : a.eps_fwd;
     const int Tz = a.zf.T, Tr = klblk ? a.rf.T : 0, NT = Tz + Tr;
     float* z = sm;  float* qm = sm + P;  float* lv = sm + 2 * P;  float* ep = sm + 3 * P;  float* uw = sm + 4 * P;
@@ -250,9 +247,6 @@ __global__ __launch_bounds__(kFastThreads) void mnf_flow_planar_fast_kernel(cons
     if (!eps) { seed = a.rng[0]; offs = a.rng[1] + (uint64_t)blockIdx.z * kernarg_as<FlowBatch>()->m_adv; }
     const uint32_t stream = (klblk ? LBBNN_STREAM_EPS_Z2 : LBBNN_STREAM_EPS_Z) * 64u + a.layer;
     dma_wait_all();
-#ifdef LAB_STAMPS
-    if (klblk && tid == 0) a.scal[5] = (float)(__builtin_amdgcn_s_memrealtime() - lab_t0);
-#endif
 
     // one sweep: z0 (LBBNN-GP-MF-MNF.py:183-185), log_q0 (:213-214) and every dot product of the chain
     double acc[NV];
@@ -282,9 +276,6 @@ __global__ __launch_bounds__(kFastThreads) void mnf_flow_planar_fast_kernel(cons
             for (int s2 = 0; s2 < t; ++s2) acc[q++] += (double)(w[t] * u[s2]);
         }
     }
-#ifdef LAB_STAMPS
-    if (klblk && tid == 0) a.scal[6] = (float)(__builtin_amdgcn_s_memrealtime() - lab_t0);
-#endif
     // fixed-order reduction of the NV values: wave sums, then the per-wave partials through LDS in wave order
 #pragma unroll
     for (int k = 0; k < NV; ++k) acc[k] = wave_sum(acc[k]);
@@ -331,9 +322,6 @@ __global__ __launch_bounds__(kFastThreads) void mnf_flow_planar_fast_kernel(cons
             a.scal[3] = v;                                                   // z_b[-1]: last ELEMENT (:224)
         }
     }
-#ifdef LAB_STAMPS
-    if (klblk && tid == 0) a.scal[7] = (float)(__builtin_amdgcn_s_memrealtime() - lab_t0);
-#endif
     if (tid == 0) {
         if (!klblk) { if (a.scal) a.scal[4] = ld_q; }
         else { a.scal[0] = ld_q; a.scal[1] = (float)acc[NV - 1]; a.scal[2] = ld_r; }

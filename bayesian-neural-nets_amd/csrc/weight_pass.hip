@@ -104,10 +104,6 @@ __device__ __forceinline__ void pow2_scale(float m, float& scale, float& inv) {
 __device__ __forceinline__ Elem weight_elem(float mu, float rho, float lam, float zf, float zk, float rc,
                                             bool want_kl, bool want_act, const WeightPassArgs& a) {
     Elem e;
-#ifdef LAB_K1_NOMATH         // tools/lab ablation only: keep the loads/stores, drop the transcendental chain
-    e.ew = mu * zf + lam; e.vw = rho * lam; e.kl = mu; e.amu = rho * rc; e.avar = lam * zk;
-    return e;
-#endif
     const float alpha = __frcp_rn(1.0f + __expf(-lam));
     const float sigma = softplus_fast(rho);
     const float ea = mu * alpha;
@@ -183,9 +179,6 @@ __global__ __launch_bounds__(256) void weight_pass_kernel(const WeightPassBatch 
                 amu += (e0.amu + e1.amu) + (e2.amu + e3.amu);
                 avar += (e0.avar + e1.avar) + (e2.avar + e3.avar);
             }
-#ifdef LAB_K1_NOSTORE        // tools/lab ablation only
-            if (ew.x == 12345.678f)
-#endif
             if (!a.split) {
                 if (a.e_w) reinterpret_cast<float4*>(a.e_w + (size_t)o * a.ld)[j] = ew;
                 if (a.var_w) reinterpret_cast<float4*>(a.var_w + (size_t)o * a.ld)[j] = vw;

@@ -1,9 +1,11 @@
 """CPU tier: host-side logic of the drop-in modules (construction, seeded parity with the
 reference's initial values, state_dict names, loud failure without a GPU)."""
+import os
+
 import pytest
 import torch
 
-from conftest import sub
+from conftest import ROOT, sub
 
 
 def test_lrt_seeded_construction_matches_reference(golden):
@@ -115,3 +117,46 @@ def test_base_and_vd_seeded_construction_matches_reference(golden):
         assert torch.equal(layer.theta.detach(), c["theta"])
         assert torch.equal(layer.alpha, c["alpha"])
         assert [n for n, _ in layer.named_parameters()] == ["theta"]      # alpha is NOT a parameter there either
+
+
+def test_product_sources_carry_no_lab_code_and_export_no_lab_symbol():
+    """the measurement hooks (-DLAB_* ablation returns, stamps, role logic) are gone from the product
+    kernel sources -- the lab builds of tools/lab compile the round-2 tree fetched from history -- and the product library
+    exports nothing named lbbnn_lab_*."""
+    import glob
+    import re
+    import subprocess
+    csrc = os.path.join(ROOT, "bayesian-neural-nets_amd", "csrc")
+    for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")):
+        txt = open(f).read()
+        assert not re.search(r"\bLAB_[A-Z0-9_]+\b", txt), f
+        assert "lbbnn_lab_" not in txt, f
+    so = os.path.join(csrc, "liblbbnn_hip.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    assert "lbbnn_lrt_gemm_ex" in out and "lbbnn_lab" not in out
+
+
+def test_prior_helpers_log_prob_match_the_reference_formulas():
+    """GaussGamma.log_prob / BetaBinomial.log_prob (LBBNN-GP-MF.py:140-151, 162-173) as callable torch densities (VERDICT r02
+    missing #3): checked on CPU against the formulas written out independently, exact and relaxed gates."""
+    import math
+    import torch
+    from bnn_amd import base
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(7, 5, generator=g, dtype=torch.float64)
+    gam = torch.rand(7, 5, generator=g, dtype=torch.float64)
+    a, b = torch.tensor([1.05], dtype=torch.float64), torch.tensor([1.02], dtype=torch.float64)
+    tau = torch.tensor([0.7], dtype=torch.float64)
+    for exact in (False, True):
+        gg = base.GaussGamma(a, b); gg.exact = exact
+        gq = torch.round(gam) if exact else gam
+        ref = (gq * (a * torch.log(b) + (a - 0.5) * tau - b * tau - torch.lgamma(a) - 0.5 * math.log(2 * math.pi))
+               - tau * x ** 2 + (1 - gq) + 1e-8).sum()
+        assert torch.allclose(gg.log_prob(x, gam, tau=tau), ref, rtol=1e-12)
+        bb = base.BetaBinomial(a, b); bb.exact = exact
+        lg = torch.lgamma
+        one = torch.ones_like(gam)
+        ref = (lg(one) + lg(gq + a) + lg(1 + b - gq) + lg(one * (a + b)) - lg(a + gq) - lg(2 - gq) - lg(one * (1 + a + b))
+               - lg(one * a) - lg(one * b)).sum()
+        assert torch.allclose(bb.log_prob(gam, pa=None, pb=None), ref, rtol=1e-12)
+    assert torch.isfinite(base.GaussGamma(a, b).log_prob(x, gam))            # draws its own tau (:141)

@@ -2420,3 +2420,45 @@ def test_layer_random_shape_sweep():
                        timeout=600, cwd=root)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     assert "random layers ok" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("medimean", [True, False])
+def test_base_mean_branches_with_log_probs_under_autograd(bnn, dev, golden, medimean):
+    """LBBNN-GP-MF.py:236-251 under autograd (VERDICT r02 missing #2): the medimean / joint-mean branch with
+    calculate_log_probs=True gives the values of the HIP no-grad pass on the same tau draws, and gradients equal to fp64
+    autograd of the reference formulas on the CPU."""
+    c = golden("base.npz").case("c1")
+    B, I, O = [int(v) for v in c["shape"]]
+    layer = _load_layer(bnn.base.BayesianLinear(I, O, 1), sub(c, "p."), dev).eval()
+    x, cg = c["x"].to(dev), c["cgamma"].to(dev)
+    layer.alpha = c["alpha_attr"].to(dev)
+    layer.gamma.alpha = (1 / (1 + torch.exp(-layer.lambdal))).detach()
+    layer.noise = {"tau_w": c["tau_w"].to(dev), "tau_b": c["tau_b"].to(dev)}
+    with torch.no_grad():
+        out0 = layer(x, cg, sample=False, medimean=medimean, calculate_log_probs=True)
+        lp0, lq0 = layer.log_prior.clone(), layer.log_variational_posterior.clone()
+    out = layer(x, cg, sample=False, medimean=medimean, calculate_log_probs=True)
+    lp, lq = layer.log_prior, layer.log_variational_posterior
+    assert out.requires_grad and lp.requires_grad and lq.requires_grad
+    assert rel_err(out, out0) < 1e-5 and rel_err(lp, lp0) < 2e-5 and rel_err(lq, lq0) < 2e-5
+    (out.sum() + 0.01 * (lq - lp)).backward()
+    # fp64 autograd of the same formulas (the oracle's densities)
+    P = {k: v.detach().cpu().double().requires_grad_(True) for k, v in layer.named_parameters()}
+    x64, cg64 = x.cpu().double(), cg.cpu().double()
+    w = (cg64 if medimean else c["alpha_attr"].double()) * P["weight_mu"]
+    b = P["bias_mu"]
+    lp64 = (orc.gaussgamma_log_prob(w, cg64, P["weight_a"], P["weight_b"], c["tau_w"].double(), False)
+            + orc.gaussgamma_log_prob(b, torch.ones_like(b), P["bias_a"], P["bias_b"], c["tau_b"].double(), False)
+            + orc.betabinomial_log_prob(cg64, P["pa"], P["pb"], False))
+    ga = layer.gamma.alpha.detach().cpu().double()
+    lq64 = (orc.gaussian_full_log_prob(w, cg64, P["weight_mu"], P["weight_rho"]) + orc.bernoulli_log_prob(cg64, ga, False)
+            + orc.gaussian_log_prob(b, P["bias_mu"], P["bias_rho"]))
+    out64 = torch.nn.functional.linear(x64, w, b)
+    (out64.sum() + 0.01 * (lq64 - lp64)).backward()
+    for k, p in layer.named_parameters():
+        if P[k].grad is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        assert p.grad is not None, k
+        assert rel_err(p.grad, P[k].grad) < 1e-4, (k, rel_err(p.grad, P[k].grad))
