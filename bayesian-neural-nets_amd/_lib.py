@@ -58,7 +58,10 @@ class GemmDesc(ctypes.Structure):
                 ("out", c_p), ("ldo", c_i), ("out_planes", c_p), ("ldp", c_i), ("std_out", c_p),
                 ("B", c_i), ("I", c_i), ("O", c_i), ("flags", c_i),
                 ("layers", ctypes.POINTER(LayerDesc)), ("n_layers", c_i), ("fin_rng", c_p), ("kl_total", c_p),
-                ("rng_live", c_p), ("advance", c_u64)]
+                ("rng_live", c_p), ("advance", c_u64),
+                ("head_e", c_p), ("head_v", c_p), ("head_ld", c_i), ("head_classes", c_i),
+                ("head_bias_mean", c_p), ("head_bias_var", c_p), ("head_eps", c_p), ("head_rng_stream", c_u32),
+                ("head_out", c_p), ("head_ldo", c_i), ("head_slab", c_p), ("head_flags", c_i)]
 
 
 class DenseTransform(ctypes.Structure):
@@ -176,6 +179,7 @@ SIGNATURES = {
     "lbbnn_weight_pass_f16": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.POINTER(Priors),
                                     c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "lbbnn_lrt_gemm_ex": (c_i, [ctypes.POINTER(GemmDesc), c_p]),
+    "lbbnn_head_slab_floats": (c_i64, [c_i, c_i]),
     "lbbnn_format_x": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_p]),
     "lbbnn_lrt_gemm": (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_u32, c_i64,
                              c_p, c_i, c_i, c_i, c_i, c_i, c_p]),

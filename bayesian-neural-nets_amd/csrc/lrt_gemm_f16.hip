@@ -57,8 +57,15 @@ struct G16Args {
     int ldx, ld, ldo, ldp, B, I, O;
     uint32_t rng_stream;
     int relu;
+    // head fold (lbbnn_gemm_desc_t::head_*): h_slab != NULL => the epilogue also contracts this tile's 80 output features
+    // with the <= 16 rows of the NEXT layer's fp32 operands and writes partial moments to h_slab[o tile][b][2][16]
+    const float* h_e; const float* h_v; float* h_slab;
+    int h_ld, h_C;
     FinalizePiggy fin;
 };
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+constexpr float kHeadES = 256.f, kHeadVS = 16384.f;       // fixed power-of-two scales of the head's e_w / var_w fp16 parts
 
 __device__ __forceinline__ uint32_t cvt_pk_h(float a, float b) {
     const floatx2 v = {a, b};
@@ -85,8 +92,14 @@ __device__ __forceinline__ void ld4f(const float* p, int o, int O, float fill, f
 //   fp32 `out` (float4 per lane), sqrt(var) for the backward pass, and the fp16 hi | lo PLANES of the next layer's x: the
 //   lane pair (q, q ^ 1) holds the 8 consecutive k of one 16-B unit pair, v_permlane16_swap_b32 moves the halves so that
 //   the even lane stores the hi unit and the odd lane the lo unit (16 B each, 64 B contiguous per row and tile).
-template <int TO, int TB>
-__device__ __forceinline__ void epilogue16(const G16Args& a, int o0, int q, int brow0,
+//   Head fold (a.h_slab): the NEXT layer is a <= 16-class head (LBBNN-GP-MF-MNF.py:256: l3 on relu(l2)).  Its two moment
+//   products over THIS workgroup's 80 features are formed here, on the matrix cores: the accumulator layout of a 16 x 16
+//   tile (lane (b, q): features 4q..4q+3 of row b) IS the B-operand layout of v_mfma_f32_16x16x16_f16 (k = 4q + r), the A
+//   operand is the head's weight tile (lane (class, q)), both as fp16 hi + lo with 3 + 1 (3) products like the main loop.
+//   Each wave owns its 32 rows, so nothing is reduced across waves: per o tile a slab row of 2 x 16 floats per batch row;
+//   head_finalize_kernel adds the slabs in o-tile order.  Saves the h2 store + re-read and the head's own launch.
+template <int TO, int TB, int NPV>
+__device__ __forceinline__ void epilogue16(const G16Args& a, int o0, int q, int lr, int brow0,
                                            const floatx4 (&accm)[TO][TB], const floatx4 (&accv)[TO][TB]) {
     const bool ovec = ((a.O & 3) == 0) && (!a.out || (((a.ldo & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0))) &&
                       (!a.eps || (reinterpret_cast<uintptr_t>(a.eps) & 15u) == 0) &&
@@ -126,12 +139,43 @@ __device__ __forceinline__ void epilogue16(const G16Args& a, int o0, int q, int 
             }
         }
     }
+    const bool head = a.h_slab != nullptr;
+    float4 he4[TO], hv4[TO];                              // head fold: this lane's A fragments (class lr, features o .. o+3)
+    if (head) {
+#pragma unroll
+        for (int i = 0; i < TO; ++i) {
+            const int o = o0 + i * 16 + 4 * q;
+            he4[i] = make_float4(0.f, 0.f, 0.f, 0.f); hv4[i] = he4[i];
+            if (lr < a.h_C && o < a.O) {
+                he4[i] = *reinterpret_cast<const float4*>(a.h_e + (size_t)lr * a.h_ld + o);
+                hv4[i] = *reinterpret_cast<const float4*>(a.h_v + (size_t)lr * a.h_ld + o);
+            }
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);
     const bool odd = q & 1;
+    floatx4 hm[TB], hv[TB];
+#pragma unroll
+    for (int j = 0; j < TB; ++j) { hm[j] = floatx4{0.f, 0.f, 0.f, 0.f}; hv[j] = floatx4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int i = 0; i < TO; ++i) {
         const int o = o0 + i * 16 + 4 * q;
         const bool oin = o < a.O;
+        f16x4 ehd = {0, 0, 0, 0}, eld = {0, 0, 0, 0}, vhd = {0, 0, 0, 0}, vld = {0, 0, 0, 0};
+        if (head) {
+            const float4 e4 = he4[i], v4 = hv4[i];
+            const uint32_t eh0 = cvt_pk_h(e4.x * kHeadES, e4.y * kHeadES), eh1 = cvt_pk_h(e4.z * kHeadES, e4.w * kHeadES);
+            const uint32_t el0 = cvt_pk_h(e4.x * kHeadES - h_lo(eh0), e4.y * kHeadES - h_hi(eh0));
+            const uint32_t el1 = cvt_pk_h(e4.z * kHeadES - h_lo(eh1), e4.w * kHeadES - h_hi(eh1));
+            const uint32_t vh0 = cvt_pk_h(v4.x * kHeadVS, v4.y * kHeadVS), vh1 = cvt_pk_h(v4.z * kHeadVS, v4.w * kHeadVS);
+            ehd = __builtin_bit_cast(f16x4, make_uint2(eh0, eh1)); eld = __builtin_bit_cast(f16x4, make_uint2(el0, el1));
+            vhd = __builtin_bit_cast(f16x4, make_uint2(vh0, vh1));
+            if (NPV == 3) {
+                const uint32_t vl0 = cvt_pk_h(v4.x * kHeadVS - h_lo(vh0), v4.y * kHeadVS - h_hi(vh0));
+                const uint32_t vl1 = cvt_pk_h(v4.z * kHeadVS - h_lo(vh1), v4.w * kHeadVS - h_hi(vh1));
+                vld = __builtin_bit_cast(f16x4, make_uint2(vl0, vl1));
+            }
+        }
 #pragma unroll
         for (int j = 0; j < TB; ++j) {
             const int b = brow0 + j * 16;
@@ -166,6 +210,27 @@ __device__ __forceinline__ void epilogue16(const G16Args& a, int o0, int q, int 
                     for (int r = 0; r < 4; ++r) if (o + r < a.O) p[r] = sd[r];
                 }
             }
+            if (head) {                                           // wave-uniform; dead lanes contribute zeros
+                float hx[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hx[r] = (live && o + r < a.O) ? res[r] : 0.f;
+                const uint32_t h01 = cvt_pk_h(hx[0], hx[1]), h23 = cvt_pk_h(hx[2], hx[3]);
+                const uint32_t l01 = cvt_pk_h(hx[0] - h_lo(h01), hx[1] - h_hi(h01)), l23 = cvt_pk_h(hx[2] - h_lo(h23), hx[3] - h_hi(h23));
+                const f16x4 xh = __builtin_bit_cast(f16x4, make_uint2(h01, h23)), xl = __builtin_bit_cast(f16x4, make_uint2(l01, l23));
+                const float s0 = hx[0] * hx[0] * kS2, s1 = hx[1] * hx[1] * kS2, s2 = hx[2] * hx[2] * kS2, s3 = hx[3] * hx[3] * kS2;
+                const uint32_t q01 = cvt_pk_h(s0, s1), q23 = cvt_pk_h(s2, s3);
+                const f16x4 sh = __builtin_bit_cast(f16x4, make_uint2(q01, q23));
+                hm[j] = __builtin_amdgcn_mfma_f32_16x16x16f16(ehd, xh, hm[j], 0, 0, 0);
+                hm[j] = __builtin_amdgcn_mfma_f32_16x16x16f16(eld, xh, hm[j], 0, 0, 0);
+                hm[j] = __builtin_amdgcn_mfma_f32_16x16x16f16(ehd, xl, hm[j], 0, 0, 0);
+                hv[j] = __builtin_amdgcn_mfma_f32_16x16x16f16(vhd, sh, hv[j], 0, 0, 0);
+                if (NPV == 3) {
+                    const uint32_t r01 = cvt_pk_h(s0 - h_lo(q01), s1 - h_hi(q01)), r23 = cvt_pk_h(s2 - h_lo(q23), s3 - h_hi(q23));
+                    const f16x4 sl = __builtin_bit_cast(f16x4, make_uint2(r01, r23));
+                    hv[j] = __builtin_amdgcn_mfma_f32_16x16x16f16(vld, sh, hv[j], 0, 0, 0);
+                    hv[j] = __builtin_amdgcn_mfma_f32_16x16x16f16(vhd, sl, hv[j], 0, 0, 0);
+                }
+            }
             if (a.out_planes) {                                   // wave-uniform; every lane takes part in the swaps
                 const uint32_t h01 = cvt_pk_h(res[0], res[1]), h23 = cvt_pk_h(res[2], res[3]);
                 const uint32_t l01 = cvt_pk_h(res[0] - h_lo(h01), res[1] - h_hi(h01));
@@ -179,6 +244,19 @@ __device__ __forceinline__ void epilogue16(const G16Args& a, int o0, int q, int 
                     char* p = a.out_planes + (size_t)b * a.ldp * 4 + (size_t)(kk >> 5) * 128 + ((kk >> 3) & 3) * 32 + (odd ? 16 : 0);
                     *reinterpret_cast<uint4*>(p) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
                 }
+            }
+        }
+    }
+    if (head) {
+        // lane (b = lr, q): classes 4q .. 4q+3 of row brow0 + 16 j; slab row = [mean 16 | var 16] floats of one batch row
+        const int ot = o0 / (TO * 16);
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            const int b = brow0 + j * 16;
+            if (b < a.B) {
+                float* p = a.h_slab + ((size_t)ot * a.B + b) * 32 + 4 * q;
+                *reinterpret_cast<float4*>(p) = make_float4(hm[j][0], hm[j][1], hm[j][2], hm[j][3]);
+                *reinterpret_cast<float4*>(p + 16) = make_float4(hv[j][0], hv[j][1], hv[j][2], hv[j][3]);
             }
         }
     }
@@ -373,7 +451,7 @@ __device__ __forceinline__ void gemm_f16s_body(const G16Args& a) {
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
     }
-    epilogue16<TO, TB>(a, o0, q, b0 + wv * TB * 16 + lr, accm, accv);
+    epilogue16<TO, TB, NPV>(a, o0, q, lr, b0 + wv * TB * 16 + lr, accm, accv);
 }
 
 template <int TO, int TB, int WB, int NPV, bool XPL>
@@ -408,7 +486,95 @@ __global__ __launch_bounds__(256) void format_x_kernel(const FormatJob j) {
     format_x_items(j, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
 }
 
+// Second half of the head fold: out[b][c] = log_softmax_c( sum_ot mean[ot][b][c] / 2^8 + bias_mean[c]
+//                                                        + sqrt(sum_ot var[ot][b][c] 2^8 / 2^14 + bias_var[c]) eps[b][c] )
+// (LBBNN-GP-MF-MNF.py:197-200 for the last layer, :256 log_softmax); deterministic: every sum has a fixed order.
+struct HeadFinArgs {
+    const float* slab; const float* bias_mean; const float* bias_var; const float* eps; const uint64_t* rng;
+    float* out; long long row_offset;
+    int n_ot, B, C, ldo, log_softmax; uint32_t rng_stream;
+};
+
+// Sixteen lanes (one DPP row) per batch row: lane = 4 q + g owns classes 4q .. 4q+3 and the o tiles g, g + 4, g + 8, ... --
+// at most four pairs of 16-B loads per lane, all in flight together (a thread per (row, q) that walked all 15 tiles made
+// the launch latency-bound on 64 workgroups: 7.1 us for 7.9 MB); the partial sums are combined in a fixed order by DPP.
+__global__ __launch_bounds__(256) void head_finalize_kernel(const HeadFinArgs a) {
+    const int t = blockIdx.x * 256 + threadIdx.x, b = t >> 4, q = (t >> 2) & 3, g = t & 3;
+    const bool rowok = b < a.B;
+    float m[4] = {0.f, 0.f, 0.f, 0.f}, v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (rowok) {
+        float4 pm[4], pv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ot = g + 4 * k;
+            pm[k] = make_float4(0.f, 0.f, 0.f, 0.f); pv[k] = pm[k];
+            if (ot < a.n_ot) {
+                const float* p = a.slab + ((size_t)ot * a.B + b) * 32 + 4 * q;
+                pm[k] = *reinterpret_cast<const float4*>(p); pv[k] = *reinterpret_cast<const float4*>(p + 16);
+            }
+        }
+        for (int ot = g + 16; ot < a.n_ot; ot += 4) {              // more than 16 o tiles (O > 1280): the rest, sequentially
+            const float* p = a.slab + ((size_t)ot * a.B + b) * 32 + 4 * q;
+            const float4 xm = *reinterpret_cast<const float4*>(p), xv = *reinterpret_cast<const float4*>(p + 16);
+            pm[0].x += xm.x; pm[0].y += xm.y; pm[0].z += xm.z; pm[0].w += xm.w;
+            pv[0].x += xv.x; pv[0].y += xv.y; pv[0].z += xv.z; pv[0].w += xv.w;
+        }
+        m[0] = (pm[0].x + pm[1].x) + (pm[2].x + pm[3].x); m[1] = (pm[0].y + pm[1].y) + (pm[2].y + pm[3].y);
+        m[2] = (pm[0].z + pm[1].z) + (pm[2].z + pm[3].z); m[3] = (pm[0].w + pm[1].w) + (pm[2].w + pm[3].w);
+        v[0] = (pv[0].x + pv[1].x) + (pv[2].x + pv[3].x); v[1] = (pv[0].y + pv[1].y) + (pv[2].y + pv[3].y);
+        v[2] = (pv[0].z + pv[1].z) + (pv[2].z + pv[3].z); v[3] = (pv[0].w + pv[1].w) + (pv[2].w + pv[3].w);
+    }
+    // the four o-tile groups of a (row, q) sit in one quad: lane ^ 1, lane ^ 2 -- every lane of the quad ends with the sum
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        m[r] += dpp_get<0xB1>(m[r]); m[r] += dpp_get<0x4E>(m[r]);
+        v[r] += dpp_get<0xB1>(v[r]); v[r] += dpp_get<0x4E>(v[r]);
+    }
+    float e[4] = {0.f, 0.f, 0.f, 0.f};
+    const int c0 = 4 * q;
+    if (rowok && c0 < a.C) {
+        if (a.eps) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (c0 + r < a.C) e[r] = a.eps[(size_t)b * a.C + c0 + r];
+        } else {
+            philox_normal4(a.rng[0], a.rng[1], a.rng_stream, (uint64_t)(a.row_offset + b), (uint32_t)q, e);
+        }
+    }
+    float res[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int c = c0 + r;
+        const bool in = rowok && c < a.C;
+        const float bm = (in && a.bias_mean) ? a.bias_mean[c] : 0.f, bv = (in && a.bias_var) ? a.bias_var[c] : 0.f;
+        const float sd = sqrtf(v[r] * (kS2inv / kHeadVS) + bv);
+        res[r] = m[r] * (1.f / kHeadES) + bm + sd * e[r];
+        if (in) mx = fmaxf(mx, res[r]);
+    }
+    if (a.log_softmax) {
+        // over the row's four q groups: quads of one 16-lane DPP row (all four lanes of a quad hold the same values)
+        mx = fmaxf(mx, dpp_get<0x141>(mx));
+        mx = fmaxf(mx, dpp_get<0x140>(mx));
+        float se = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (rowok && c0 + r < a.C) se += expf(res[r] - mx);
+        se += dpp_get<0x141>(se);
+        se += dpp_get<0x140>(se);
+        const float lse = mx + logf(se);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) res[r] -= lse;
+    }
+    if (rowok && g == 0)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (c0 + r < a.C) a.out[(size_t)b * a.ldo + c0 + r] = res[r];
+}
+
 }  // namespace
+
+extern "C" int64_t lbbnn_head_slab_floats(int B, int O) {
+    if (B <= 0 || O <= 0) return 0;
+    return (int64_t)((O + 79) / 80) * B * 32;
+}
 
 extern "C" int lbbnn_format_x(const float* x, int ldx, void* planes, int ldp, int B, int I, void* stream) {
     if (B == 0) return 0;
@@ -429,7 +595,7 @@ extern "C" int lbbnn_lrt_gemm_ex(const lbbnn_gemm_desc_t* d, void* stream) {
     if (flags & ~(LBBNN_F_RELU | LBBNN_F_F16S | LBBNN_F_VAR1 | LBBNN_F_XPLANES)) return LBBNN_E_FLAGS;
     if (!(flags & LBBNN_F_F16S)) return LBBNN_E_FLAGS;             // the descriptor form serves the fp16 format (the others: lbbnn_lrt_gemm*)
     if (B == 0 && I > 0 && O > 0 && d->n_layers == 0 && !d->advance) return 0;
-    if (!d->x || !d->e_w || !d->var_w || !d->mean_scale || !d->wvar_scale || (!d->out && !d->out_planes)) return LBBNN_E_NULL;
+    if (!d->x || !d->e_w || !d->var_w || !d->mean_scale || !d->wvar_scale) return LBBNN_E_NULL;
     if (!d->eps && !d->rng) return LBBNN_E_NOISE;
     if (B <= 0 || I <= 0 || O <= 16 || d->ldx < I || (d->out && d->ldo < O)) return LBBNN_E_SHAPE;
     const bool xpl = (flags & LBBNN_F_XPLANES) != 0;
@@ -440,6 +606,14 @@ extern "C" int lbbnn_lrt_gemm_ex(const lbbnn_gemm_desc_t* d, void* stream) {
     if (d->out_planes && ((O & 7) || (d->ldp & 31) || d->ldp < O || (reinterpret_cast<uintptr_t>(d->out_planes) & 15u))) return LBBNN_E_ALIGN;
     if ((size_t)B * d->ldx * 4 >= 0x7FFFFFF0u || (size_t)O * d->ld * 4 >= 0x7FFFFFF0u) return LBBNN_E_SHAPE;   // 32-bit buffer offsets
     if (d->n_layers < 0 || (d->n_layers > 0 && !d->layers) || (d->advance && !d->rng_live)) return LBBNN_E_NULL;
+    const bool head = d->head_out != nullptr;
+    if (head) {
+        if (!d->head_e || !d->head_v || !d->head_slab) return LBBNN_E_NULL;
+        if (d->head_classes <= 0 || d->head_classes > 16 || d->head_ld < O || (d->head_ld & 3) || d->head_ldo < d->head_classes) return LBBNN_E_SHAPE;
+        if ((O & 3) || ((reinterpret_cast<uintptr_t>(d->head_e) | reinterpret_cast<uintptr_t>(d->head_v) | reinterpret_cast<uintptr_t>(d->head_slab)) & 15u)) return LBBNN_E_ALIGN;
+        if (!d->head_eps && !d->rng) return LBBNN_E_NOISE;
+        if (!(flags & LBBNN_F_RELU)) return LBBNN_E_FLAGS;        // the head reads relu(this layer) (LBBNN-GP-MF-MNF.py:255-256)
+    } else if (!d->out && !d->out_planes) return LBBNN_E_NULL;
 
     G16Args a;
     a.x = static_cast<const char*>(d->x); a.e_w = static_cast<const char*>(d->e_w); a.var_w = static_cast<const char*>(d->var_w);
@@ -448,6 +622,8 @@ extern "C" int lbbnn_lrt_gemm_ex(const lbbnn_gemm_desc_t* d, void* stream) {
     a.eps = d->eps; a.rng = d->rng; a.out = d->out; a.out_planes = static_cast<char*>(d->out_planes); a.std_out = d->std_out;
     a.row_offset = d->row_offset; a.ldx = d->ldx; a.ld = d->ld; a.ldo = d->ldo; a.ldp = d->ldp; a.B = B; a.I = I; a.O = O;
     a.rng_stream = d->rng_stream; a.relu = (flags & LBBNN_F_RELU) ? 1 : 0;
+    a.h_e = head ? d->head_e : nullptr; a.h_v = head ? d->head_v : nullptr; a.h_slab = head ? d->head_slab : nullptr;
+    a.h_ld = d->head_ld; a.h_C = d->head_classes;
     a.fin = FinalizePiggy{};
     const bool want_fin = d->n_layers > 0 || d->advance;
     if (d->n_layers > 0) {
@@ -467,7 +643,17 @@ extern "C" int lbbnn_lrt_gemm_ex(const lbbnn_gemm_desc_t* d, void* stream) {
     // of 16 rows at four waves per SIMD (<5,1,8>) does not fit 128 VGPRs (61-96 spilled).
     if (blocks_big >= 256 && B >= 96) rc = launch16<5, 2, 4>(a, npv, xpl, s, &hosted);
     else rc = launch16<5, 1, 2>(a, npv, xpl, s, &hosted);
-    if (rc || !want_fin || hosted) return rc;
+    if (rc) return rc;
+    if (head) {
+        HeadFinArgs h;
+        h.slab = d->head_slab; h.bias_mean = d->head_bias_mean; h.bias_var = d->head_bias_var; h.eps = d->head_eps; h.rng = d->rng;
+        h.out = d->head_out; h.row_offset = d->row_offset; h.n_ot = (O + 79) / 80; h.B = B; h.C = d->head_classes; h.ldo = d->head_ldo;
+        h.log_softmax = (d->head_flags & LBBNN_F_LOG_SOFTMAX) ? 1 : 0; h.rng_stream = d->head_rng_stream;
+        hipLaunchKernelGGL(head_finalize_kernel, dim3((16 * (size_t)B + 255) / 256), dim3(256), 0, s, h);
+        rc = (int)hipGetLastError();
+        if (rc) return rc;
+    }
+    if (!want_fin || hosted) return rc;
     if (d->n_layers > 0)
         return launch_kl_finalize_all(a.fin.l, a.fin.active, d->n_layers, d->advance ? d->rng_live : nullptr, d->advance,
                                       d->kl_total, s);

@@ -48,6 +48,8 @@ _DENSE_DEFER = {"0": False, "always": "always"}.get(_os.environ.get("LBBNN_DENSE
 # split costs the first GEMM's K loop 1.33 us per step instead of 1.08 (~6 us); the format pass costs 6.9 us as a launch of its
 # own (0.1543 against 0.1487 ms per forward) and as much as it saves when it rides in the flow launch (0.1401 against
 # 0.1392 ms): no form of the pre-pass beats the in-register split, so the simpler one is the default.
+# LBBNN_HEAD_FOLD=0: keep the 10-class head a GEMM launch of its own (the skinny kernel) in the fused fp16 forward
+_HEAD_FOLD = _os.environ.get("LBBNN_HEAD_FOLD", "1") != "0"
 _F16_FIRST_PLANES = _os.environ.get("LBBNN_F16_FIRST", "f32") != "f32"
 _SIDE = {}
 
@@ -514,7 +516,7 @@ class _BayesLinearBase(nn.Module):
         return ws, noise
 
     def _gemm(self, x, cfg, rng, log_softmax=False, std_out=None, finalize=None, out=None, x_planes=False,
-              out_planes=None, want_out=True):
+              out_planes=None, want_out=True, head=None):
         """The layer's GEMM launch on the operands ``_prep`` (or the network's batched prepare) left in the workspace.
         Format 2 (row-scaled fp16): lbbnn_lrt_gemm_ex -- ``x`` may be the plane buffer the previous layer wrote
         (``x_planes``), and the call may write planes for the next layer (``out_planes``) instead of / beside fp32 ``out``
@@ -528,7 +530,7 @@ class _BayesLinearBase(nn.Module):
             o, _ = ops.lrt_gemm16(x, ws.e_w, ws.var_w, ws.e_scale, ws.v_scale, I=self.in_features, O=self.out_features,
                                   bias_mean=self.bias_mu, bias_var=ws.bias_var, eps=eps, rng=rng, rng_stream=stream_id,
                                   row_offset=self.row_offset, relu=relu, var1=(self._split_now == 3), x_planes=x_planes, out=out,
-                                  want_out=want_out, out_planes=out_planes, std_out=std_out, finalize=finalize)
+                                  want_out=want_out, out_planes=out_planes, std_out=std_out, finalize=finalize, head=head)
             return o
         return ops.lrt_gemm(x, ws.e_w, ws.var_w, I=self.in_features, O=self.out_features,
                             bias_mean=self.bias_mu, bias_var=ws.bias_var, eps=eps, rng=rng,
@@ -1259,6 +1261,7 @@ class _NetworkBase(nn.Module):
             defer_ev.record(side)
         all_kl = want_kl and all(c[1] for c in cfgs)
         fin_at = 1 if defer_ev is not None else 0
+        head_done = False
         for i, (l, c) in enumerate(zip(layers, cfgs)):
             # the KL finalize of all layers (parameters only) rides in the first GEMM's launch as one extra workgroup (in the
             # second's when part of the dense flows was deferred: it waits for the side stream first)
@@ -1272,14 +1275,36 @@ class _NetworkBase(nn.Module):
             # row-scaled fp16 layers hand their activations on as fp16 hi | lo PLANES (written by the GEMM epilogue, read by
             # the next GEMM's LDS-DMA as they lie): no fp32 copy of a hidden activation is stored in this no-grad forward
             fmt = l._split_now
+            if head_done:
+                break                                     # the last layer's GEMM ran inside the previous launch (head fold)
             give_planes = (fmt >= 2 and i + 1 < n and layers[i + 1]._split_now >= 2 and l.out_features % 8 == 0)
+            # HEAD FOLD: a row-scaled fp16 layer followed by the <= 16-class head computes the head's two moment products in
+            # its own epilogue (lbbnn_gemm_desc_t::head_*): the hidden activation is never stored, the head has no GEMM launch
+            head = None
+            nxt = layers[i + 1] if i + 1 < n else None
+            if (_HEAD_FOLD and fmt >= 2 and nxt is not None and i + 2 == n and nxt.out_features <= 16 and nxt._split_now == 0
+                    and cfgs[i + 1][0] and c[2] and l.out_features % 4 == 0 and fin is None):
+                wsn = nxt._workspace()
+                hout = (plan.setdefault("out%d" % (i + 1), torch.empty(B, nxt.out_features, dtype=torch.float32, device=dev))
+                        if plan is not None else torch.empty(B, nxt.out_features, dtype=torch.float32, device=dev))
+                key = ("slab", i, B, str(dev))
+                store = plan if plan is not None else self._plane_cache
+                slab = store.get(key)
+                if slab is None:
+                    slab = store[key] = torch.empty(ops.head_slab_floats(B, l.out_features), dtype=torch.float32, device=dev)
+                head = {"e_w": wsn.e_w, "var_w": wsn.var_w, "bias_mean": nxt.bias_mu, "bias_var": wsn.bias_var,
+                        "eps": (nxt.noise or {}).get("eps_out"), "rng_stream": ops.STREAM_EPS_OUT * 64 + nxt._layer_id,
+                        "out": hout, "slab": slab, "log_softmax": True}
             obuf = None
-            if plan is not None and not give_planes:
+            if plan is not None and not give_planes and head is None:
                 obuf = plan.setdefault("out%d" % i, torch.empty(B, l.out_features, dtype=torch.float32, device=dev))
             pbuf = self._planes(i, B, l.out_features, dev, plan) if give_planes else None
             y = l._gemm(x, c, snap, log_softmax=(i == n - 1 and l.out_features <= 16), finalize=fin, out=obuf,
-                        x_planes=x_planes, out_planes=pbuf, want_out=not give_planes)
-            x, x_planes = (pbuf, True) if give_planes else (y, False)
+                        x_planes=x_planes, out_planes=pbuf, want_out=(not give_planes and head is None), head=head)
+            if head is not None:
+                x, x_planes, head_done = head["out"], False, True
+            else:
+                x, x_planes = (pbuf, True) if give_planes else (y, False)
         if layers[-1].out_features > 16:
             x = F.log_softmax(x, dim=1)
         for i, (l, c) in enumerate(zip(layers, cfgs)):

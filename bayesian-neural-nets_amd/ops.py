@@ -377,6 +377,10 @@ def plane_ld(n: int) -> int:
     return operand_ld(n)
 
 
+def head_slab_floats(B: int, O: int) -> int:
+    return int(_lib.lib().lbbnn_head_slab_floats(B, O))
+
+
 def format_x(x, planes=None):
     """lbbnn_format_x: fp32 rows (B, I) -> fp16 hi | lo planes, a (B, plane_ld(I)) fp32-sized buffer (tail zero)."""
     B, I = x.shape
@@ -392,11 +396,14 @@ def format_x(x, planes=None):
 def lrt_gemm16(x, e_w, var_w, e_scale, v_scale, *, I: int, O: int, bias_mean=None, bias_var=None, var_scale=None,
                eps=None, rng: Optional[torch.Tensor] = None, rng_stream: int = 0, row_offset: int = 0, relu: bool = False,
                var1: bool = False, x_planes: bool = False, out: Optional[torch.Tensor] = None, want_out: bool = True,
-               out_planes: Optional[torch.Tensor] = None, std_out: Optional[torch.Tensor] = None, finalize=None):
+               out_planes: Optional[torch.Tensor] = None, std_out: Optional[torch.Tensor] = None, finalize=None,
+               head=None):
     """lbbnn_lrt_gemm_ex on LBBNN_F_F16S operands: the dual-moment GEMM + sampling epilogue of lrt_gemm in the row-scaled fp16
     format.  x: fp32 rows (B, I), or with ``x_planes`` the (B, plane_ld(I)) plane buffer a previous call / format_x wrote.
     Outputs: fp32 ``out`` (allocated unless ``want_out`` is False) and / or ``out_planes`` (B, plane_ld(O)) for the next layer.
-    ``finalize`` as in lrt_gemm.  Returns (out or None, out_planes or None)."""
+    ``finalize`` as in lrt_gemm.  ``head``: dict(e_w, var_w (C, operand_ld(O)) fp32 operands of the <= 16-class layer that follows,
+    bias_mean, bias_var, eps (or None), rng_stream, out (B, C), slab (head_slab_floats(B, O)), log_softmax) -- the head's GEMM
+    is folded into this launch's epilogue + a small finalize launch.  Returns (out or None, out_planes or None)."""
     B = x.shape[0]
     if x_planes:
         if x.dim() != 2 or x.shape[1] != plane_ld(I) or x.stride(1) != 1:
@@ -423,6 +430,13 @@ def lrt_gemm16(x, e_w, var_w, e_scale, v_scale, *, I: int, O: int, bias_mean=Non
     d.std_out = _ptr(std_out, "std_out")
     d.B, d.I, d.O = B, I, O
     d.flags = F_F16S | (F_RELU if relu else 0) | (F_VAR1 if var1 else 0) | (F_XPLANES if x_planes else 0)
+    if head is not None:
+        C = head["out"].shape[1]
+        d.head_e, d.head_v, d.head_ld, d.head_classes = _ptr(head["e_w"]), _ptr(head["var_w"]), head["e_w"].stride(0), C
+        d.head_bias_mean, d.head_bias_var, d.head_eps = _ptr(head.get("bias_mean")), _ptr(head.get("bias_var")), _ptr(head.get("eps"), "eps")
+        d.head_rng_stream = head.get("rng_stream", 0)
+        d.head_out, d.head_ldo, d.head_slab = head["out"].data_ptr(), head["out"].stride(0), _ptr(head["slab"])
+        d.head_flags = F_LOG_SOFTMAX if head.get("log_softmax") else 0
     if finalize is not None:
         live, adv = (finalize[4], finalize[5]) if len(finalize) > 4 else (None, 0)
         d.layers = finalize[0] if finalize[0] is not None else None

@@ -341,6 +341,7 @@ def roofline_pass(ops, run_step, sync, n_steps, launches_per_step):
     sync()
     fl = sorted(s.elapsed_time(e) for s, e in evs)
     log.bracket_floor_us = fl[len(fl) // 2] * 1e3
+    log.n_steps = n_steps          # (2 GEMM launches per step when the 10-class head is folded into the second one, else 3)
     return log
 
 
@@ -351,7 +352,7 @@ def roofline_object(events, precision, ms_per_step, sampled_in):
     big = [(b, i, o, s.elapsed_time(e)) for (b, i, o, s, e) in events if o > 16]
     if not big:
         return None, "no GEMM launch was bracketed"
-    n_steps = max(len(events) // 3, 1)
+    n_steps = getattr(events, "n_steps", None) or max(len(events) // 3, 1)
     flops = sum(4.0 * b * i * o for (b, i, o, _) in big) / len(big)
     avg_ms = sum(ms for (_, _, _, ms) in big) / len(big)
     med_ms = sorted(ms for (_, _, _, ms) in big)[len(big) // 2]

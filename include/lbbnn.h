@@ -777,9 +777,20 @@ typedef struct lbbnn_gemm_desc {
     /* optional KL finalize of a network carried by one extra workgroup (as lbbnn_lrt_gemm_finalize_adv) */
     const lbbnn_layer_desc_t* layers; int n_layers; const uint64_t* fin_rng; float* kl_total;
     uint64_t* rng_live; uint64_t advance;
+    /* optional HEAD FOLD (head_out != NULL; needs LBBNN_F_RELU): the layer that FOLLOWS this one has head_classes <= 16 outputs
+     * (the 10-class head of BayesianNetwork, LBBNN-GP-MF-MNF.py:255-256).  Its two moment products are formed in this launch's
+     * epilogue from the accumulators (fp16 hi + lo on v_mfma_f32_16x16x16_f16, per-o-tile partials in head_slab), a second small
+     * launch adds the partials, the head's bias / variance bias / noise (head_eps or Philox(rng, head_rng_stream)) and, with
+     * LBBNN_F_LOG_SOFTMAX in head_flags, log_softmax: head_out (B, head_classes).  head_e / head_v: the head's fp32 operands
+     * [head_classes][head_ld] (lbbnn_layers_operands, split == 0).  `out` / `out_planes` may then both be NULL: the hidden
+     * activation of this layer is never stored.  head_slab: lbbnn_head_slab_floats(B, O) floats. */
+    const float* head_e; const float* head_v; int head_ld; int head_classes;
+    const float* head_bias_mean; const float* head_bias_var; const float* head_eps; uint32_t head_rng_stream;
+    float* head_out; int head_ldo; float* head_slab; int head_flags;
 } lbbnn_gemm_desc_t;
 
 int lbbnn_lrt_gemm_ex(const lbbnn_gemm_desc_t* d, void* stream);
+int64_t lbbnn_head_slab_floats(int B, int O);
 
 /* fp32 rows -> fp16 hi | lo planes (the x format above); I % 8 == 0, x 16-B aligned rows, ldp % 32 == 0, ldp >= I.
  * Writes the whole row of planes (tail slots zero). */

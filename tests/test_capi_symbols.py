@@ -69,7 +69,7 @@ def test_ctypes_struct_layouts_match_the_header(tmp_path):
     import subprocess
     from bnn_amd import _lib
     pairs = [("lbbnn_priors_t", _lib.Priors, "bias_sigma_prior"), ("lbbnn_planar_flow_t", _lib.PlanarFlow, "T"),
-             ("lbbnn_layer_desc_t", _lib.LayerDesc, "v_scale"), ("lbbnn_gemm_desc_t", _lib.GemmDesc, "advance"),
+             ("lbbnn_layer_desc_t", _lib.LayerDesc, "v_scale"), ("lbbnn_gemm_desc_t", _lib.GemmDesc, "head_flags"),
              ("lbbnn_dense_transform_t", _lib.DenseTransform, "mask_kl"),
              ("lbbnn_gate_args_t", _lib.GateArgs, None), ("lbbnn_wpb_args_t", _lib.WpbArgs, None),
              ("lbbnn_adam_list_t", _lib.AdamList, None), ("lbbnn_copy_list_t", _lib.CopyList, None),

@@ -327,3 +327,31 @@ def test_f16_falls_back_where_the_format_does_not_apply(bnn, dev):
     with torch.no_grad():
         wide(x, sample=True)
     assert wide.l1._split_now == 1 and wide.l2._split_now == 1             # l3 rows of 1600 weights: the whole net keeps bf16x3
+
+
+@pytest.mark.parametrize("prec", ["fp16x3", "fp16x3f"])
+@pytest.mark.parametrize("dims,B", [((784, 1200, 1200, 10), 4096), ((64, 96, 40, 7), 100), ((784, 400, 88, 16), 33)])
+def test_head_fold_equals_the_unfolded_forward(bnn, dev, prec, dims, B, monkeypatch):
+    """The 10-class head folded into the previous GEMM's epilogue (lbbnn_gemm_desc_t::head_*, layers._HEAD_FOLD) against the
+    same forward with the head as its own launch (the exact-fp32 skinny kernel on the stored activations): same draws
+    (in-kernel Philox, same counters), outputs within the format's bar of each other, KL bit-identical; and the folded path
+    never stores the last hidden activation.  Odd sizes: O not a multiple of 80, 7 and 16 classes, ragged batch."""
+    from bnn_amd import layers as L
+    torch.manual_seed(3)
+    net = bnn.mnf.BayesianNetwork(dims, 2, z_flow_type="Planar", r_flow_type="Planar").to(dev).train()
+    net.set_precision(prec)
+    x = torch.rand(B, dims[0], device=dev)
+    res = {}
+    for fold in (True, False):
+        monkeypatch.setattr(L, "_HEAD_FOLD", fold)
+        with torch.no_grad():
+            bnn.manual_seed(7, 5)
+            out = net(x, sample=True).clone()
+            res[fold] = (out, net.kl().clone())
+        assert net.l2._split_now >= 2 and net.l3._split_now == 0
+    bar, atol = BARS[prec]
+    assert torch.isfinite(res[True][0]).all()
+    assert rel_err(res[True][0], res[False][0]) < bar, rel_err(res[True][0], res[False][0])
+    assert elementwise_violation(res[True][0], res[False][0].double(), rtol=1e-4, atol_frac=atol) <= 1.0
+    assert torch.equal(res[True][1], res[False][1])
+    assert float((res[True][0].exp().sum(dim=1) - 1).abs().max()) < 1e-5            # rows are log-probabilities
