@@ -8,6 +8,7 @@ from ._lib import LIB_PATH, Priors  # noqa: F401
 from .layers import (LRTBayesianLinear, LRTBayesianNetwork, MNFBayesianLinear,  # noqa: F401
                      MNFBayesianNetwork)
 from .ops import get_precision, manual_seed, set_precision  # noqa: F401
-from . import base, evaluate, flows, graphs, lrt, mnf, optim, parallel, vd  # noqa: F401
+from . import base, evaluate, flows, graphs, losses, lrt, mnf, optim, parallel, vd  # noqa: F401
+from .losses import elbo_loss  # noqa: F401
 
 __version__ = "0.1.0"

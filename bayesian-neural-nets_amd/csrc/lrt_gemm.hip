@@ -1020,7 +1020,7 @@ extern "C" int lbbnn_lrt_gemm_train(const float* x, int ldx, const void* e_w, co
                                     const float* eps, const uint64_t* rng, uint32_t rng_stream, int64_t row_offset,
                                     float* out, int ldo, float* std_out, int B, int I, int O, int flags, void* stream) {
     if ((flags & LBBNN_F_MEAN_ONLY) && std_out) return LBBNN_E_FLAGS;
-    if ((flags & LBBNN_F_LOG_SOFTMAX) && std_out) return LBBNN_E_FLAGS;
+    // (log_softmax + std_out is the training forward of the 10-class head: the backward needs sqrt(var), not the logits)
     return lrt_gemm_impl(x, ldx, e_w, var_w, ld, bias_mean, bias_var, var_scale, eps, rng, rng_stream, row_offset,
                          out, ldo, std_out, B, I, O, flags, stream);
 }
@@ -1032,7 +1032,7 @@ static int gemm_finalize_impl(const float* x, int ldx, const void* e_w, const vo
                               float* out, int ldo, float* std_out, int B, int I, int O, int flags,
                               const lbbnn_layer_desc_t* layers, int n, const uint64_t* fin_rng, float* kl_total,
                               uint64_t* rng_live, uint64_t advance, void* stream) {
-    if (((flags & LBBNN_F_MEAN_ONLY) || (flags & LBBNN_F_LOG_SOFTMAX)) && std_out) return LBBNN_E_FLAGS;
+    if ((flags & LBBNN_F_MEAN_ONLY) && std_out) return LBBNN_E_FLAGS;
     if (n == 0) {
         // nothing to finalize (a forward without KL): the plain GEMM, then the advance as the tiny launch it is
         const int rc = lrt_gemm_impl(x, ldx, e_w, var_w, ld, bias_mean, bias_var, var_scale, eps, rng, rng_stream, row_offset,

@@ -150,12 +150,17 @@ def make_graphed_train_step(net, optimizer, loss_fn, example_x, example_y, warmu
         _quiet(True)
 
     def step(x, y):
-        static_x.copy_(x)
-        static_y.copy_(y)
+        # a batch that already lies in the graph's input buffers (step.inputs: a loader that writes its host-to-device copy
+        # straight into them) costs no device-to-device copy: 2 x ~4.7 us ahead of every replay otherwise
+        if x.data_ptr() != static_x.data_ptr():
+            static_x.copy_(x)
+        if y.data_ptr() != static_y.data_ptr():
+            static_y.copy_(y)
         graph.replay()
         return static_loss
 
     step.graph = graph
+    step.inputs = (static_x, static_y)
     return step
 
 

@@ -232,6 +232,8 @@ class _BayesLinearFn(torch.autograd.Function):
         # ---- (B,O) head: mask, G_v, transposes and column sums in one HIP pass; eps_out is re-created from the
         # forward's Philox state inside the kernel unless explicit draws were given
         explicit = ctx.saved.get("noise") or {}
+        if ctx.saved.get("lsm"):
+            g_out = ops.log_softmax_backward(g_out, out)              # grad wrt log-probabilities -> grad wrt the logits
         g, g_v, gT, g_vT, g_sum, gv_sum = ops.output_grad(
             g_out, out=out if relu else None, std=std if stochastic else None, eps=explicit.get("eps_out"),
             rng=ctx.saved.get("rng"), rng_stream=ops.STREAM_EPS_OUT * 64 + layer._layer_id, row_offset=layer.row_offset,
@@ -442,6 +444,7 @@ class _BayesLinearBase(nn.Module):
         self._last_flow_rng = None
         self._mask_pool = None         # Bernoulli masks pre-drawn by the network for this call (one launch for all layers)
         self._preprep = None           # K3 / K1 of this call already run by the network (one launch per kind for all layers)
+        self._lsm_now = False          # set by the network around the head's training forward: log_softmax in the GEMM epilogue
         self._last_masks = None
 
     # reference keeps the prior tensors as attributes; expose them lazily with the same names
@@ -579,7 +582,10 @@ class _BayesLinearBase(nn.Module):
             fin = (desc, 1, rng.data_ptr() if rng is not None else None, None)
         saved["masks"] = self._last_masks
         std = torch.empty((x.shape[0], self.out_features), dtype=torch.float32, device=x.device) if want_std else None
-        out = self._gemm(x, cfg, rng, std_out=std, finalize=fin)
+        out = self._gemm(x, cfg, rng, std_out=std, finalize=fin, log_softmax=bool(self._lsm_now and self._split_now == 0))
+        saved["lsm"] = bool(self._lsm_now and self._split_now == 0)
+        if self._lsm_now and not saved["lsm"]:
+            out = F.log_softmax(out, dim=1)               # (a head the skinny kernel does not take: > 16 classes never get here)
         if std is not None:
             saved["std"] = std
         if st is not None and advance:
@@ -998,6 +1004,8 @@ class _NetworkBase(nn.Module):
     With autograd each layer goes through ``_BayesLinearFn`` (HIP forward + HIP backward).
     """
     _kl_total = None
+    _train_kl_total = None        # training forward: the network KL as summed on the device by the KL finalize (else None)
+    _pre_shared = None
 
     def _layers(self):
         return [self.l1, self.l2, self.l3]
@@ -1040,6 +1048,7 @@ class _NetworkBase(nn.Module):
         x = x.view(-1, self.dims[0])                                  # …LRT.py:207
         layers = self._layers()
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        self._train_kl_total = None
         if needs_grad or not x.is_cuda or not all(l._fusable() for l in layers):
             self._kl_total = None
             shared = needs_grad and x.is_cuda
@@ -1049,16 +1058,25 @@ class _NetworkBase(nn.Module):
                 self._predraw_masks([l for l in layers if l._mnf and l._check_flows() == "dense"])
                 self._preflow_dense(layers, sample)
                 self._preprep_all(layers, sample, x)
+            fused_lsm = False
             try:
                 for i, l in enumerate(layers):
                     l._advance_rng = not shared
+                    # the head's F.log_softmax (…LRT.py:210) runs in its GEMM's epilogue in the training forward too: the layer's
+                    # autograd node then returns log-probabilities and its backward starts with lbbnn_log_softmax_backward
+                    l._lsm_now = bool(shared and i == len(layers) - 1 and l.out_features <= 16 and (l.training or sample))
+                    fused_lsm = l._lsm_now
                     x = l.forward(x, sample, _relu=(i < 2))           # F.relu fused into the GEMM epilogue
             finally:
                 for l in layers:
                     l._advance_rng = True
+                    l._lsm_now = False
             if shared:
                 ops.RngState.get(x.device).advance(1)
-            return F.log_softmax(x, dim=1)                            # …LRT.py:210
+                sh = self._pre_shared
+                self._train_kl_total = sh["kl_total"] if (sh is not None and sh.get("hosted") and sh.get("kl_total") is not None) else None
+                self._pre_shared = None
+            return x if fused_lsm else F.log_softmax(x, dim=1)       # …LRT.py:210
         return self._forward_streams(x.float(), sample)
 
     @staticmethod
@@ -1146,8 +1164,11 @@ class _NetworkBase(nn.Module):
                                                          (rng.data_ptr() + 16 if rng is not None else None), 0,
                                                          torch.cuda.current_stream(dev).cuda_stream), "lbbnn_layers_operands_snap")
         all_kl = all(c[1] for c in cfgs)
-        shared = {"hosted": False, "keep": keep,
-                  "fin_all": (descs, len(layers), rng.data_ptr() if rng is not None else None, None) if all_kl else None}
+        kl_total = torch.empty((), dtype=torch.float32, device=dev) if all_kl else None
+        shared = {"hosted": False, "keep": keep, "kl_total": kl_total,
+                  "fin_all": (descs, len(layers), rng.data_ptr() if rng is not None else None,
+                              kl_total.data_ptr()) if all_kl else None}
+        self._pre_shared = shared
         for i, (l, c) in enumerate(zip(layers, cfgs)):
             l._preprep = {"cfg": c, "split": l._split_now, "kl": kls[i], "first": i == 0, "shared": shared, "snap": snap}
 
@@ -1315,6 +1336,9 @@ class _NetworkBase(nn.Module):
     def kl(self):
         if self._kl_total is not None:
             return self._kl_total                                     # summed on the device by K5
+        if self._train_kl_total is not None and all(torch.is_tensor(l.kl) and l.kl.grad_fn is not None for l in self._layers()):
+            from .losses import _SumKLFn                              # ... also in the training forward: no add kernels
+            return _SumKLFn.apply(self._train_kl_total, *[l.kl for l in self._layers()])
         return self.l1.kl + self.l2.kl + self.l3.kl                   # …LRT.py:213-214
 
     def set_row_offset(self, off: int):

@@ -1,0 +1,64 @@
+"""The scalar head of a training step as fused HIP launches (include/lbbnn.h: lbbnn_elbo_loss*).
+
+``elbo_loss(log_probs, target, kl, num_batches)`` is ``F.nll_loss(log_probs, target, reduction='sum') + kl / num_batches`` --
+what the reference's ``train()`` writes out (LBBNN-GP-MF-MNF.py:268-271; ...LRT.py:222-225) -- as ONE forward launch and ONE
+backward launch instead of torch's nll_loss / mul / add kernels (13 + 4 + 4 us forward, 6 us + fills backward for a
+4096 x 10 batch: the reduce kernel of nll_loss runs on a single workgroup).  The reference's own spelling keeps working; this
+is the faster one for callers that want it (``bnn_amd.parallel.DataParallelELBO.loss`` uses it on HIP tensors).
+"""
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+
+
+class _ElboLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, log_probs, target, kl, scale):
+        B, C = log_probs.shape
+        lp = log_probs if log_probs.stride(1) == 1 else log_probs.contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=lp.device)
+        stream = torch.cuda.current_stream(lp.device).cuda_stream
+        _lib.check(_lib.lib().lbbnn_elbo_loss(lp.data_ptr(), lp.stride(0), target.data_ptr(), B, C,
+                                              kl.data_ptr() if kl is not None else None, float(scale), loss.data_ptr(), stream),
+                   "lbbnn_elbo_loss")
+        ctx.save_for_backward(target)
+        ctx.meta = (B, C, float(scale), kl is not None)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (target,) = ctx.saved_tensors
+        B, C, scale, has_kl = ctx.meta
+        g = g.contiguous()
+        g_logp = torch.empty((B, C), dtype=torch.float32, device=g.device)
+        g_kl = torch.empty((), dtype=torch.float32, device=g.device) if has_kl else None
+        stream = torch.cuda.current_stream(g.device).cuda_stream
+        _lib.check(_lib.lib().lbbnn_elbo_loss_backward(g.data_ptr(), target.data_ptr(), B, C, scale, g_logp.data_ptr(),
+                                                       g_kl.data_ptr() if has_kl else None, stream), "lbbnn_elbo_loss_backward")
+        return g_logp, None, g_kl, None
+
+
+def elbo_loss(log_probs, target, kl=None, num_batches=1.0):
+    """nll_loss(log_probs, target, reduction='sum') + kl / num_batches.  HIP tensors: the fused launches; anything else (the
+    CPU host-logic tests of bnn_amd.parallel run on oracle tensors): the same expression in torch ops."""
+    if (log_probs.is_cuda and log_probs.dtype == torch.float32 and log_probs.dim() == 2 and target.dtype == torch.int64
+            and target.is_contiguous() and (kl is None or (torch.is_tensor(kl) and kl.is_cuda and kl.dtype == torch.float32
+                                                           and kl.numel() == 1))):
+        return _ElboLossFn.apply(log_probs, target, kl if kl is None else kl.reshape(()), 1.0 / float(num_batches))
+    nll = F.nll_loss(log_probs, target, reduction="sum")
+    return nll if kl is None else nll + kl / num_batches
+
+
+class _SumKLFn(torch.autograd.Function):
+    """kl_total of a network whose layers' KL tails ran in ONE finalize (kl_piggy.h): the total was added on the device in
+    layer order by that launch; this node only tells autograd that it is the sum of the per-layer values."""
+
+    @staticmethod
+    def forward(ctx, total, *kls):
+        ctx.n = len(kls)
+        return total.detach().view_as(total)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None,) + (g,) * ctx.n

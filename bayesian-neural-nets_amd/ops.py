@@ -795,6 +795,18 @@ def format_operand(src: torch.Tensor, *, square: bool = False, split: bool = Fal
     return out
 
 
+def log_softmax_backward(g: torch.Tensor, logp: torch.Tensor) -> torch.Tensor:
+    """lbbnn_log_softmax_backward: g - exp(logp) * rowsum(g) for (B, C <= 64) tensors."""
+    B, C = g.shape
+    if g.stride(1) != 1:
+        g = g.contiguous()
+    out = torch.empty((B, C), dtype=torch.float32, device=g.device)
+    rc = _lib.lib().lbbnn_log_softmax_backward(_ptr_rows(g, "g"), g.stride(0), _ptr_rows(logp, "logp"), logp.stride(0),
+                                               out.data_ptr(), C, B, C, _stream())
+    _lib.check(rc, "lbbnn_log_softmax_backward")
+    return out
+
+
 def log_softmax_rows(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     B, O = x.shape
     if out is None:

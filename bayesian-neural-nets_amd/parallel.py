@@ -224,14 +224,17 @@ class DataParallelELBO:
             self.bucket.last += " between two HIP graphs"
 
         def step(x, y):
-            static_x.copy_(x)
-            static_y.copy_(y)
+            if x.data_ptr() != static_x.data_ptr():       # (a batch written straight into step.inputs needs no copy)
+                static_x.copy_(x)
+            if y.data_ptr() != static_y.data_ptr():
+                static_y.copy_(y)
             g_a.replay()
             self.bucket.collective(self.group)
             g_b.replay()
             return static_loss
 
         step.graphs = (g_a, g_b)
+        step.inputs = (static_x, static_y)
         return step
 
     def describe_collective(self) -> str:
@@ -248,8 +251,9 @@ class DataParallelELBO:
         return out if len(out) > 1 else out[0]
 
     def loss(self, log_probs, target, num_batches):
-        nll = torch.nn.functional.nll_loss(log_probs, target, reduction="sum")
-        return nll + self.net.kl() / (num_batches * self.world)
+        """nll_r + kl / (num_batches * world) (module docstring); on HIP tensors one fused launch (bnn_amd.losses.elbo_loss)."""
+        from .losses import elbo_loss
+        return elbo_loss(log_probs, target, self.net.kl(), num_batches * self.world)
 
     def all_reduce_grads(self, unpack: bool = True):
         self.bucket.all_reduce(self.group, unpack=unpack)

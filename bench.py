@@ -469,7 +469,9 @@ def train_leg(args, bnn_amd, net, x, sync, world, rank):
     mode, why = "two HIP graphs around the collective", None
     try:
         gstep = dp.make_graphed_step(opt, x, y, 600)
-        step = lambda: gstep(x, y)
+        gx, gy = gstep.inputs                    # the batch is resident in the graph's own input buffers (as x is for the forward legs)
+        gx.copy_(x.view_as(gx)); gy.copy_(y)
+        step = lambda: gstep(gx, gy)
     except Exception as e:                                   # noqa: BLE001 -- report, fall back, keep the bench alive
         mode, why = "eager", "%s: %s" % (type(e).__name__, str(e)[:200])
         step = eager_step

@@ -796,6 +796,18 @@ int64_t lbbnn_head_slab_floats(int B, int O);
  * Writes the whole row of planes (tail slots zero). */
 int lbbnn_format_x(const float* x, int ldx, void* planes, int ldp, int B, int I, void* stream);
 
+/* The scalar head of the training step (train(), LBBNN-GP-MF-MNF.py:268-271), one launch each, deterministic:
+ *   lbbnn_elbo_loss:            *loss = -sum_b logp[b][target[b]] + (kl ? *kl * kl_scale : 0)   (F.nll_loss(reduction='sum') + kl / N)
+ *   lbbnn_elbo_loss_backward:   g_logp[b][c] = -(*g) (c == target[b]);  *g_kl = (*g) * kl_scale (g_kl may be NULL)
+ *   lbbnn_log_softmax_backward: out = g - exp(logp) * rowsum(g)   (backward of F.log_softmax(dim=1), C <= 64)
+ * target: int64 class indices (entries outside [0, C) contribute nothing, as ignore_index does). */
+int lbbnn_elbo_loss(const float* logp, int ldp, const int64_t* target, int B, int C, const float* kl, float kl_scale,
+                    float* loss, void* stream);
+int lbbnn_elbo_loss_backward(const float* g, const int64_t* target, int B, int C, float kl_scale, float* g_logp, float* g_kl,
+                             void* stream);
+int lbbnn_log_softmax_backward(const float* g, int ldg, const float* logp, int ldp, float* out, int ldo, int B, int C,
+                               void* stream);
+
 /* lbbnn_layers_operands_snap + lbbnn_format_x of the network input in the SAME launches: the planar flows of a network are two
  * latency-bound workgroups per layer, and the format job (one pass over x) runs as extra workgroups of that launch on the CUs
  * it leaves idle -- no launch of its own, nothing added to the critical path.  Falls back to a separate lbbnn_format_x launch

@@ -2351,7 +2351,9 @@ def test_gemm_combine_epilogue(bnn, dev, M, K, N, split):
 @pytest.mark.parametrize("family", ["lrt", "Planar"])
 def test_network_training_path_equals_per_layer_path(bnn, dev, family):
     """The training forward of a network (K3 / K1 of all layers in one launch per kind, every KL tail in the first GEMM's
-    launch, one shared RNG offset) against driving the same layers one by one: loss and every gradient bitwise equal."""
+    launch, one shared RNG offset, log_softmax in the head's GEMM epilogue, the KL total from the device-side finalize)
+    against driving the same layers one by one (the head with the same fused log_softmax, the KL as the three-term torch
+    sum): loss and every gradient bitwise equal."""
     for prec in ("fp32", "bf16x3"):
         bnn.set_precision(prec)
         torch.manual_seed(0)
@@ -2371,9 +2373,11 @@ def test_network_training_path_equals_per_layer_path(bnn, dev, family):
                 h = x
                 for i, l in enumerate((net.l1, net.l2, net.l3)):
                     l._advance_rng = False
+                    l._lsm_now = i == 2                   # the head returns log-probabilities from its GEMM epilogue
                     h = l.forward(h, True, _relu=(i < 2))
                     l._advance_rng = True
-                out = torch.nn.functional.log_softmax(h, dim=1)
+                    l._lsm_now = False
+                out = h
                 kl = net.l1.kl + net.l2.kl + net.l3.kl
             loss = torch.nn.functional.nll_loss(out, y, reduction="sum") + kl / 10
             loss.backward()
@@ -2500,3 +2504,64 @@ def test_planar_backward_tiny_shape_of_the_round2_fuzz_outlier(bnn, dev, seed):
         if ref is not None and float(ref.abs().max()) > 0:
             e = rel_err(prm.grad, ref)
             assert e < (5e-5 if name == "r0_c" else 1e-4), (name, e)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C", [(4096, 10), (33, 7), (1, 16)])
+def test_fused_elbo_loss_and_log_softmax_backward_vs_torch(bnn, dev, B, C):
+    """bnn_amd.elbo_loss == F.nll_loss(reduction='sum') + kl / num_batches (train(), LBBNN-GP-MF-MNF.py:268-271) in value and
+    in both gradients; ops.log_softmax_backward == autograd of F.log_softmax."""
+    g = torch.Generator().manual_seed(B + C)
+    logits = torch.randn(B, C, generator=g).to(dev).requires_grad_(True)
+    y = torch.randint(0, C, (B,), generator=g).to(dev)
+    kl = torch.tensor(1234.5, device=dev, requires_grad=True)
+    lp = torch.log_softmax(logits, dim=1)
+    loss = bnn.elbo_loss(lp, y, kl, 600)
+    loss.backward()
+    g_fused, gk_fused = logits.grad.clone(), kl.grad.clone()
+    logits.grad = None; kl.grad = None
+    ref = torch.nn.functional.nll_loss(torch.log_softmax(logits.double(), dim=1), y, reduction="sum") + kl.double() / 600
+    ref.backward()
+    assert rel_err(loss, ref) < 1e-6
+    assert rel_err(g_fused, logits.grad) < 1e-6 and rel_err(gk_fused, kl.grad) < 1e-6
+    assert rel_err(bnn.elbo_loss(lp.detach(), y), torch.nn.functional.nll_loss(lp.detach().double(), y, reduction="sum")) < 1e-6
+    gout = torch.randn(B, C, generator=g).to(dev)
+    lpd = lp.detach()
+    l2 = logits.detach().double().requires_grad_(True)
+    (torch.log_softmax(l2, dim=1) * gout.double()).sum().backward()
+    assert rel_err(bnn.ops.log_softmax_backward(gout, lpd), l2.grad) < 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["fp32", "fp16x3f"])
+def test_training_forward_fuses_log_softmax_and_sums_kl_on_device(bnn, dev, prec):
+    """The network's training forward returns log-probabilities straight from the head's GEMM epilogue (no torch softmax
+    kernels) and net.kl() is the device-side total of the KL finalize: values and gradients equal those of the same network
+    run layer by layer with torch's log_softmax and the three-term KL sum (same explicit draws)."""
+    dims, B = (784, 96, 64, 10), 48
+    torch.manual_seed(4)
+    net = bnn.mnf.BayesianNetwork(dims, 2, z_flow_type="Planar", r_flow_type="Planar").to(dev).train()
+    net.set_precision(prec)
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(B, 784, generator=g).to(dev)
+    y = torch.randint(0, 10, (B,), generator=g).to(dev)
+    for l in net._layers():
+        l.noise = {"eps_z": torch.randn(1, l.in_features, generator=g).to(dev), "eps_out": torch.randn(B, l.out_features, generator=g).to(dev),
+                   "eps_z2": torch.randn(1, l.in_features, generator=g).to(dev), "eps_act": torch.randn(l.out_features, generator=g).to(dev)}
+    out = net(x, sample=True)
+    kl = net.kl()
+    assert type(kl.grad_fn).__name__.startswith("_SumKLFn") and float((out.exp().sum(1) - 1).abs().max()) < 1e-5
+    loss = bnn.elbo_loss(out, y, kl, 100)
+    loss.backward()
+    got = {k: p.grad.clone() for k, p in net.named_parameters()}
+    net.zero_grad(set_to_none=True)
+    h = x
+    for i, l in enumerate(net._layers()):
+        h = l(h, sample=True, _relu=(i < 2))
+    out2 = torch.log_softmax(h, dim=1)
+    kl2 = net.l1.kl + net.l2.kl + net.l3.kl
+    loss2 = torch.nn.functional.nll_loss(out2, y, reduction="sum") + kl2 / 100
+    loss2.backward()
+    assert rel_err(out, out2) < 1e-6 and rel_err(kl, kl2) < 1e-6 and rel_err(loss, loss2) < 1e-6
+    for k, p in net.named_parameters():
+        assert rel_err(got[k], p.grad) < 2e-5, (k, rel_err(got[k], p.grad))
