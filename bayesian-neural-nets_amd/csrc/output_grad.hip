@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void output_grad_kernel(const lbbnn_outgrad_ar
     const bool vec = ((a.O & 3) == 0) && ((a.ldg & 3) == 0) && ((a.ldo & 3) == 0) &&
                      ((reinterpret_cast<uintptr_t>(a.g_out) & 15u) == 0) && (!a.out || (reinterpret_cast<uintptr_t>(a.out) & 15u) == 0) &&
                      (!stoch || (reinterpret_cast<uintptr_t>(a.std) & 15u) == 0) && (!a.eps || (reinterpret_cast<uintptr_t>(a.eps) & 15u) == 0) &&
-                     ((reinterpret_cast<uintptr_t>(a.gm) & 15u) == 0) && (!stoch || (reinterpret_cast<uintptr_t>(a.gv) & 15u) == 0);
+                     (!a.gm || (reinterpret_cast<uintptr_t>(a.gm) & 15u) == 0) && (!stoch || !a.gv || (reinterpret_cast<uintptr_t>(a.gv) & 15u) == 0);
     // ---- row-major pass: thread -> (row r = idx / 16, 4 consecutive o)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -53,13 +53,17 @@ __global__ __launch_bounds__(256) void output_grad_kernel(const lbbnn_outgrad_ar
                 if (o + q >= a.O) { gm[q] = 0.f; gv[q] = 0.f; }
                 else if (stoch && a.gv_scale) gv[q] *= a.gv_scale[o + q];
             }
+            // (gm / gv NULL: a first layer, whose input needs no gradient, uses the transposes and the sums only -- a quarter of
+            // this pass's traffic is not written)
             const size_t id = (size_t)b * a.O + o;
-            if (vec) {
-                *reinterpret_cast<float4*>(a.gm + id) = make_float4(gm[0], gm[1], gm[2], gm[3]);
-                if (stoch) *reinterpret_cast<float4*>(a.gv + id) = make_float4(gv[0], gv[1], gv[2], gv[3]);
-            } else {
+            if (a.gm) {
+                if (vec) {
+                    *reinterpret_cast<float4*>(a.gm + id) = make_float4(gm[0], gm[1], gm[2], gm[3]);
+                    if (stoch && a.gv) *reinterpret_cast<float4*>(a.gv + id) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+                } else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) if (o + q < a.O) { a.gm[id + q] = gm[q]; if (stoch) a.gv[id + q] = gv[q]; }
+                    for (int q = 0; q < 4; ++q) if (o + q < a.O) { a.gm[id + q] = gm[q]; if (stoch && a.gv) a.gv[id + q] = gv[q]; }
+                }
             }
         }
 #pragma unroll
@@ -116,7 +120,56 @@ __global__ __launch_bounds__(256) void dx_combine_kernel(float* __restrict__ gx,
         gx[(size_t)b * I + i] += 2.f * x[(size_t)b * ldx + i] * gxv[(size_t)b * I + i];
 }
 
+// dX of a <= 16-class head (LBBNN-GP-MF-MNF.py:197-198 differentiated; K = classes):
+//   dX[b][i] = sum_c G_m[b][c] W_m^T[i][c] + 2 x[b][i] sum_c G_v[b][c] W_v^T[i][c]
+// The GEMM kernels are built for K in the hundreds: K = 10 cost two 15.4 us launches of the generic fp32 kernel (a full tile
+// machinery around ten multiply-adds per output).  Here a workgroup owns 16 rows x 256 columns: thread = one column i, its
+// 2 x C operand values in registers, the 16 rows' gradients broadcast from LDS; x read and dX written coalesced, once.
+constexpr int HD_ROWS = 16, HD_COLS = 256, HD_MAXC = 16;
+
+__global__ __launch_bounds__(HD_COLS) void head_dx_kernel(const float* __restrict__ gm, const float* __restrict__ gv, int ldg,
+                                                          const float* __restrict__ wmT, const float* __restrict__ wvT, int ldw,
+                                                          const float* __restrict__ x, int ldx, float* __restrict__ out, int ldo,
+                                                          int B, int C, int I) {
+    __shared__ float sgm[HD_ROWS][HD_MAXC], sgv[HD_ROWS][HD_MAXC];
+    const int b0 = blockIdx.y * HD_ROWS, i = blockIdx.x * HD_COLS + threadIdx.x;
+    for (int t = threadIdx.x; t < HD_ROWS * HD_MAXC; t += HD_COLS) {
+        const int r = t / HD_MAXC, c = t % HD_MAXC;
+        const bool in = b0 + r < B && c < C;
+        sgm[r][c] = in ? gm[(size_t)(b0 + r) * ldg + c] : 0.f;
+        sgv[r][c] = (in && gv) ? gv[(size_t)(b0 + r) * ldg + c] : 0.f;
+    }
+    float wm[HD_MAXC], wv[HD_MAXC];
+#pragma unroll
+    for (int c = 0; c < HD_MAXC; ++c) {
+        const bool in = i < I && c < C;
+        wm[c] = in ? wmT[(size_t)i * ldw + c] : 0.f;
+        wv[c] = (in && wvT) ? wvT[(size_t)i * ldw + c] : 0.f;
+    }
+    __syncthreads();
+    if (i >= I) return;
+#pragma unroll 4
+    for (int r = 0; r < HD_ROWS; ++r) {
+        const int b = b0 + r;
+        if (b >= B) break;
+        float am = 0.f, av = 0.f;
+#pragma unroll
+        for (int c = 0; c < HD_MAXC; ++c) { am += sgm[r][c] * wm[c]; av += sgv[r][c] * wv[c]; }
+        out[(size_t)b * ldo + i] = gv ? am + 2.f * x[(size_t)b * ldx + i] * av : am;
+    }
+}
+
 }  // namespace
+
+extern "C" int lbbnn_head_dx(const float* gm, const float* gv, int ldg, const float* wmT, const float* wvT, int ldw,
+                             const float* x, int ldx, float* out, int ldo, int B, int C, int I, void* stream) {
+    if (!gm || !wmT || !out) return LBBNN_E_NULL;
+    if ((gv == nullptr) != (wvT == nullptr) || (gv && !x)) return LBBNN_E_NULL;
+    if (B <= 0 || C <= 0 || C > HD_MAXC || I <= 0 || ldg < C || ldw < C || ldo < I || (x && ldx < I)) return LBBNN_E_SHAPE;
+    hipLaunchKernelGGL(head_dx_kernel, dim3((I + HD_COLS - 1) / HD_COLS, (B + HD_ROWS - 1) / HD_ROWS), dim3(HD_COLS), 0,
+                       static_cast<hipStream_t>(stream), gm, gv, ldg, wmT, wvT, ldw, x, ldx, out, ldo, B, C, I);
+    return (int)hipGetLastError();
+}
 
 extern "C" int64_t lbbnn_output_grad_workspace(int B, int O) {
     if (B <= 0 || O <= 0) return 0;
@@ -126,9 +179,9 @@ extern "C" int64_t lbbnn_output_grad_workspace(int B, int O) {
 extern "C" int lbbnn_output_grad(const lbbnn_outgrad_args_t* p, void* stream) {
     if (!p) return LBBNN_E_NULL;
     const lbbnn_outgrad_args_t& a = *p;
-    if (!a.g_out || !a.gm || !a.gmT || !a.g_sum || !a.work) return LBBNN_E_NULL;
+    if (!a.g_out || !a.gmT || !a.g_sum || !a.work) return LBBNN_E_NULL;
     if (a.relu && !a.out) return LBBNN_E_NULL;
-    if (a.std && (!a.gv || !a.gvT || !a.gv_sum)) return LBBNN_E_NULL;
+    if (a.std && (!a.gvT || !a.gv_sum || ((a.gm == nullptr) != (a.gv == nullptr)))) return LBBNN_E_NULL;
     if (a.std && !a.eps && !a.rng) return LBBNN_E_NOISE;
     if (a.B <= 0 || a.O <= 0 || a.ldg < a.O || ((a.relu || a.std) && a.ldo < a.O)) return LBBNN_E_SHAPE;
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -237,7 +237,7 @@ class _BayesLinearFn(torch.autograd.Function):
         g, g_v, gT, g_vT, g_sum, gv_sum = ops.output_grad(
             g_out, out=out if relu else None, std=std if stochastic else None, eps=explicit.get("eps_out"),
             rng=ctx.saved.get("rng"), rng_stream=ops.STREAM_EPS_OUT * 64 + layer._layer_id, row_offset=layer.row_offset,
-            relu=relu)
+            relu=relu, want_g=bool(ctx.needs_input_grad[1]))
         planar = layer._mnf and layer._check_flows() == "planar"
         dense = layer._mnf and ctx.saved.get("dense_save") is not None
         # planar / dense MNF layers re-create their small draws inside V1 / V2; the torch-graph paths need them as tensors
@@ -287,8 +287,14 @@ class _BayesLinearFn(torch.autograd.Function):
                     e_t.data_ptr(), v_t.data_ptr() if v_t is not None else None, ld, O, I,
                     ops.F_SPLIT16 if split_m else 0, torch.cuda.current_stream(x.device).cuda_stream), "lbbnn_weight_operands_t")
                 w_shape = torch.empty((O, I), device="meta")       # shape carrier for _hip_matmul_nt
-                gx = _hip_matmul_nt(g, None, w_shape, op=e_t, module=layer)
-                if stochastic:
+                if O <= 16 and not split_m and x.stride(1) == 1 and g.stride(0) == (g_v.stride(0) if stochastic else g.stride(0)):
+                    # the 10-class head: ten multiply-adds per output are one elementwise-shaped launch, not two GEMMs
+                    gx = ops.head_dx(g, g_v if stochastic else None, e_t, v_t if stochastic else None, x, C=O, I=I)
+                    stochastic_done = True
+                else:
+                    stochastic_done = False
+                    gx = _hip_matmul_nt(g, None, w_shape, op=e_t, module=layer)
+                if stochastic and not stochastic_done:
                     if I > 16 and x.stride(1) == 1:
                         # dX = G_m.W_m + 2 x (.) (G_v.W_v): the combination is the second product's epilogue
                         gx = ops.lrt_gemm_combine(g_v, v_t, K=O, N=I, comb_x=x, comb_add=gx, split=split_v)

@@ -199,7 +199,7 @@ def weight_pass(mu, rho, lambdal, *, z_fwd=None, z_kl=None, r0_c=None, bias_rho=
 
 
 def output_grad(g_out, *, out=None, std=None, eps=None, rng=None, rng_stream: int = 0, row_offset: int = 0,
-                relu: bool = False, gv_scale=None):
+                relu: bool = False, gv_scale=None, want_g: bool = True):
     """lbbnn_output_grad.  Returns (gm, gv, gmT, gvT, g_sum, gv_sum); the gv* are None for a posterior-mean forward.
     gv_scale (O,): per-column factor on G_v (the variational-dropout alpha)."""
     B, O = g_out.shape
@@ -207,10 +207,11 @@ def output_grad(g_out, *, out=None, std=None, eps=None, rng=None, rng_stream: in
     if g_out.stride(1) != 1:
         g_out = g_out.contiguous()
     stoch = std is not None
-    gm, gmT, g_sum = torch.empty((B, O), **f), torch.empty((O, B), **f), torch.empty(O, **f)
+    # want_g=False: the caller needs no input gradient (a first layer): G_m / G_v themselves are not written, only G^T and sums
+    gm, gmT, g_sum = (torch.empty((B, O), **f) if want_g else None), torch.empty((O, B), **f), torch.empty(O, **f)
     gv = gvT = gv_sum = None
     if stoch:
-        gv, gvT, gv_sum = torch.empty((B, O), **f), torch.empty((O, B), **f), torch.empty(O, **f)
+        gv, gvT, gv_sum = (torch.empty((B, O), **f) if want_g else None), torch.empty((O, B), **f), torch.empty(O, **f)
     if B == 0:
         g_sum.zero_()
         if stoch:
@@ -226,14 +227,25 @@ def output_grad(g_out, *, out=None, std=None, eps=None, rng=None, rng_stream: in
     a.eps = _ptr(eps, "eps") if (stoch and eps is not None) else None
     a.rng = rng.data_ptr() if rng is not None else None
     work = torch.empty(_lib.lib().lbbnn_output_grad_workspace(B, O), **f)
-    a.gm, a.gmT, a.g_sum, a.work = gm.data_ptr(), gmT.data_ptr(), g_sum.data_ptr(), work.data_ptr()
+    a.gm, a.gmT, a.g_sum, a.work = (gm.data_ptr() if gm is not None else None), gmT.data_ptr(), g_sum.data_ptr(), work.data_ptr()
     if stoch:
-        a.gv, a.gvT, a.gv_sum = gv.data_ptr(), gvT.data_ptr(), gv_sum.data_ptr()
+        a.gv, a.gvT, a.gv_sum = (gv.data_ptr() if gv is not None else None), gvT.data_ptr(), gv_sum.data_ptr()
     a.row_offset, a.rng_stream = row_offset, rng_stream
     a.gv_scale = _ptr(gv_scale, "gv_scale") if (stoch and gv_scale is not None) else None
     a.B, a.O, a.ldg, a.ldo, a.relu = B, O, g_out.stride(0), ldo, 1 if relu else 0
     _lib.check(_lib.lib().lbbnn_output_grad(ctypes.byref(a), _stream()), "lbbnn_output_grad")
     return gm, gv, gmT, gvT, g_sum, gv_sum
+
+
+def head_dx(gm, gv, wmT, wvT, x, *, C: int, I: int):
+    """lbbnn_head_dx: dX (B, I) of a <= 16-class head from G_m / G_v (B, C) and the transposed fp32 operands [I][ld]."""
+    B = gm.shape[0]
+    out = torch.empty((B, I), dtype=torch.float32, device=gm.device)
+    rc = _lib.lib().lbbnn_head_dx(_ptr_rows(gm, "gm"), _ptr_rows(gv, "gv") if gv is not None else None, gm.stride(0),
+                                  _ptr(wmT), _ptr(wvT), wmT.stride(0), _ptr_rows(x, "x") if gv is not None else None,
+                                  x.stride(0) if gv is not None else 0, out.data_ptr(), I, B, C, I, _stream())
+    _lib.check(rc, "lbbnn_head_dx")
+    return out
 
 
 def matmul_splitk(a, w_op, *, K: int, N: int, kchunk: int):

@@ -600,7 +600,11 @@ typedef struct lbbnn_outgrad_args {
 } lbbnn_outgrad_args_t;
 
 int64_t lbbnn_output_grad_workspace(int B, int O);
-int lbbnn_output_grad(const lbbnn_outgrad_args_t* args, void* stream);
+int lbbnn_output_grad(const lbbnn_outgrad_args_t* args, void* stream);    /* gm == gv == NULL: only the transposes and the sums */
+/* Input gradient of a <= 16-class head in ONE launch: out[b][i] = sum_c gm[b][c] wmT[i][c] + 2 x[b][i] sum_c gv[b][c] wvT[i][c]
+ * (gv == wvT == NULL: the first sum alone).  wmT / wvT: [I][ldw] fp32, the (e_w z)^T / var_w^T operands of lbbnn_weight_operands_t. */
+int lbbnn_head_dx(const float* gm, const float* gv, int ldg, const float* wmT, const float* wvT, int ldw,
+                  const float* x, int ldx, float* out, int ldo, int B, int C, int I, void* stream);
 /* gx (B,I dense) += 2 * x (B,I; row stride ldx) * gxv (B,I dense): the input gradient of the variance GEMM folded
  * into dX = G_m.W_m + 2 x (.) (G_v.W_v)  (d/dx of (x^2).var_w^T, LBBNN-GP-MF-LRT.py:173). */
 /* out = comb_add + 2 * comb_x (.) (x . w_op^T): the mean-only product of lbbnn_lrt_gemm with lbbnn_dx_combine fused into
