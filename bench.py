@@ -12,6 +12,11 @@ activations, log_softmax, and net.kl() -- what the reference's train() runs befo
 in-kernel (Philox).  Data parallel: every rank holds the (replicated) parameters and its own
 4096 rows (weak scaling); the forward has no collective.
 
+Headline arithmetic since round 3: the row-scaled fp16 hi + lo operand format with 3 mean + 1 variance MFMA products
+(--precision fp16x3f; 1.4-1.8e-5 of max|out| against fp64, contract 1e-4); the strict 3 + 3 form (fp16x3, 3e-8), the exact
+fp32 MFMA path and the reduced single-product bf16 mode are timed in the same process as labelled secondary legs.
+`python bench.py --gpus N` with no launcher starts its own N ranks (spawn_ranks) and reports them ("ranks").
+
 How the number is taken (round 2; the round-1 line did not reproduce under the driver's command):
   1. W untimed warm-up steps (--warmup, honoured and reported), then warm-up CONTINUES to steady
      state: blocks of 25 steps run back to back (no synchronisation between them) until the last
@@ -31,13 +36,15 @@ How the number is taken (round 2; the round-1 line did not reproduce under the d
      -- 4 calls, 5 kernels -- recorded once after the warm-up and made again from a list; --graph:
      one HIP-graph replay; --eager: the launches issued from Python each step); the noise is fresh
      on every call -- the Philox offset lives on the device and is advanced by the forward's kernels.
-  4. the same three stages again with the exact-fp32 MFMA GEMM ("secondary": reference precision).
+  4. the same three stages again with the exact-fp32 MFMA GEMM ("secondary": reference precision) and with the strict
+     3 + 3 product fp16 form ("secondary_strict_fp16x3").
   4b. at N > 1: the strong-scaling form (the same 4096 rows split N ways) as "secondary_strong".
   5. with --train (default at N > 1): the full data-parallel training step (forward, backward,
      flat-bucket gradient all-reduce over RCCL, Adam) as "secondary_train".
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with the extra objects
-  roofline      dominant kernel (the 80x128-tile dual-moment GEMM) vs the MFMA peak of its dtype;
+  roofline      dominant kernel (the 80x128-tile dual-moment GEMM) vs the MFMA peak of its dtype; frac_rocprof = the same
+                fraction from the committed rocprofv3 summary of this command (profiles/r03_kernel_stats_bench_default.csv);
   cpu_baseline  the CPU oracle (port of the reference op sequence, as-written B-row z flow) timed
                 on this box's host cores on a bounded sample (rank 0, N=1 only).
 """
@@ -497,6 +504,18 @@ def train_leg(args, bnn_amd, net, x, sync, world, rank):
            "ms_per_step": elapsed / steps * 1e3, "settle": st, "timed_attempts": attempts,
            "bucket_bytes": dp.bucket_numel() * 4, "collective": dp.describe_collective()}
     step_stats(res, per_step)
+    # whole-step roofline: forward 4 B sum(IO) + backward 8 B sum(IO) algorithmic flop (dX and dW of both moment products; the
+    # first layer has no dX: 12 B sum(IO) - 4 B I1 O1) against the 16-bit MFMA peak -- the step also contains ~0.35 ms of
+    # HBM-bound passes (output gradients, weight-pass backward, operand transposes, Adam), so this is a floor on how far the
+    # step is from the matrix peak, not a kernel efficiency
+    sum_io = sum(DIMS[i] * DIMS[i + 1] for i in range(3))
+    flop = (12.0 * sum_io - 4.0 * DIMS[0] * DIMS[1]) * x.shape[0]
+    ach = flop / (elapsed / steps) / 1e12
+    res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / BF16_MFMA_PEAK_TFLOPS,
+                       "gflop_per_step_algorithmic": flop / 1e9,
+                       "note": "ALGORITHMIC flop of forward + backward of the three layers per rank / step time; forward GEMMs in the "
+                               "row-scaled fp16 format (2 executed products per algorithmic one), backward products bf16x3 (3 per one)",
+                       "kernel_summary": "profiles/r03_train_step_graph_planar_kernel_summary.txt"}
     return res
 
 

@@ -2,8 +2,8 @@
 """Per-kernel, per-launch averages of the counters in rocprofv3 p_counter_collection.csv files.
 Usage: python tools/pmc_summary.py gpurun_out/pmc_*/p_counter_collection.csv [--match substr]"""
 import collections, csv, sys
-files = [a for a in sys.argv[1:] if not a.startswith("--")]
 match = sys.argv[sys.argv.index("--match") + 1] if "--match" in sys.argv else "lrt_gemm"
+files = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and sys.argv[i - 1] != "--match"]
 for f in files:
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     disp = collections.defaultdict(set)
