@@ -26,7 +26,7 @@ def graphed(fn):
     return g.replay
 
 
-for prec in ("bf16x3", "fp32", "bf16", "fp16"):
+for prec in os.environ.get("PRECS", "fp16x3f,fp16x3,bf16x3,fp32,bf16,fp16").split(","):
     bnn_amd.set_precision(prec)
     torch.manual_seed(0)
     with torch.no_grad():
