@@ -265,6 +265,11 @@ constexpr int kInT = 4;                                  // in-kernel planar flo
 constexpr int kInNV = 3 * kInT + kInT * (kInT - 1) / 2 + kInT + 1;      // A_k | UW | X | A_f | LQ0 = 23 sums (19 used at T = 2 + 2)
 constexpr int kRowG = 8;                                 // float4 groups per lane: ld <= 64 * 4 * 8 = 2048
 constexpr int kRowB = 5;                                 // ... of which this many are loaded together
+#ifndef LBBNN_K1_ROWS_PER_WG
+#define LBBNN_K1_ROWS_PER_WG 4
+#endif
+constexpr int kRowsWG = LBBNN_K1_ROWS_PER_WG;            // rows (= waves) per workgroup of the row kernel
+constexpr int kRowNT = 64 * kRowsWG;
 
 struct WeightRowsBatch {
     WeightPassArgs l[LBBNN_MAX_LAYERS];
@@ -284,10 +289,10 @@ __device__ __forceinline__ float4 fma4(const float4 u, float s, const float4 z) 
 __device__ __forceinline__ uint32_t dpp_xor1(uint32_t v) { return (uint32_t)dpp_mov<0xB1>((int)v); }   // lane ^ 1
 
 template <bool F16S>
-__global__ __launch_bounds__(256, 3) void weight_rows_kernel(const WeightRowsBatch bt_) {
+__global__ __launch_bounds__(kRowNT, 3) void weight_rows_kernel(const WeightRowsBatch bt_) {
     const LBBNN_CONST_AS WeightRowsBatch* bt = kernarg_as<WeightRowsBatch>();
     extern __shared__ __attribute__((aligned(16))) float sm[];          // zf[P] | zk[P] | rc[P]
-    __shared__ double red[kInNV][4];
+    __shared__ double red[kInNV][kRowsWG];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (bt->rng_snap && blockIdx.x == 0 && tid == 0) {                   // see weight_pass_kernel
         const uint64_t sd = bt->rng[0], of = bt->rng[1];
@@ -307,7 +312,7 @@ __global__ __launch_bounds__(256, 3) void weight_rows_kernel(const WeightRowsBat
     const bool want_kl = a.kl_rows != nullptr, want_act = a.act_mu != nullptr;
     const float4 one4 = make_float4(1.f, 1.f, 1.f, 1.f), zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    const int o = 4 * ((int)blockIdx.x - wg0) + wv;
+    const int o = kRowsWG * ((int)blockIdx.x - wg0) + wv;
     const bool has_row = o < a.O;
     const int G = (nq + 63) >> 6;                                        // wave-uniform, <= kRowG
     const size_t rowoff = (size_t)o * I;
@@ -327,7 +332,7 @@ __global__ __launch_bounds__(256, 3) void weight_rows_kernel(const WeightRowsBat
         // reduction spilled at the 168-VGPR budget that three workgroups per CU need)
 #pragma unroll 1
         for (int h = 0; h < 2; ++h) {
-            const int j = tid + 256 * h;
+            const int j = tid + kRowNT * h;
             if (j < iq) {
                 const float4 qm = ld4(f.q0_mean, j), lv = ld4(f.q0_log_var, j);
                 float ef[4], ek[4] = {0.f, 0.f, 0.f, 0.f};
@@ -376,7 +381,12 @@ __global__ __launch_bounds__(256, 3) void weight_rows_kernel(const WeightRowsBat
             for (int k = 0; k < kInNV; ++k) red[k][wv] = acc[k];
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < kInNV; ++k) acc[k] = (red[k][0] + red[k][1]) + (red[k][2] + red[k][3]);
+        for (int k = 0; k < kInNV; ++k) {
+            double t2 = 0.0;
+#pragma unroll
+            for (int w2 = 0; w2 < kRowsWG; ++w2) t2 += red[k][w2];
+            acc[k] = t2;
+        }
         // the scalar chains (flows2.py:87-95), every thread redundantly: forward draw (z flow only), KL draw (z then r flow)
         float thf[kInT], thk[kInT], ldf = 0.f, ldq = 0.f, ldr = 0.f;
         {
@@ -403,7 +413,7 @@ __global__ __launch_bounds__(256, 3) void weight_rows_kernel(const WeightRowsBat
         }
 #pragma unroll 1
         for (int h = 0; h < 2; ++h) {
-            const int j = tid + 256 * h;
+            const int j = tid + kRowNT * h;
             if (j < nq) {
                 float4 zf = zero4, zk = zero4;
                 float ulast[kInT] = {0.f, 0.f, 0.f, 0.f};
@@ -445,7 +455,7 @@ __global__ __launch_bounds__(256, 3) void weight_rows_kernel(const WeightRowsBat
     } else {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int j = tid + 256 * h;
+            const int j = tid + kRowNT * h;
             if (j < nq) {
                 const bool in = j < iq;
                 float4 zf = one4, zk = one4, rc = one4;
@@ -682,7 +692,7 @@ int launch_weight_pass(const WeightPassArgs* a, int n, hipStream_t s, uint64_t* 
             bt.l[i] = a[i];
             if (flows) bt.f[i] = flows[i];
             if (bt.f[i].on && advance) return LBBNN_E_FLAGS;     // the in-kernel flows read the live offset in every workgroup
-            wgs += (a[i].O + 3) / 4; bt.wg_end[i] = wgs;
+            wgs += (a[i].O + kRowsWG - 1) / kRowsWG; bt.wg_end[i] = wgs;
             maxld = a[i].ld > maxld ? a[i].ld : maxld;
         }
         for (int i = n; i < LBBNN_MAX_LAYERS; ++i) bt.wg_end[i] = wgs;
@@ -690,9 +700,9 @@ int launch_weight_pass(const WeightPassArgs* a, int n, hipStream_t s, uint64_t* 
         bt.members = members;
         if (members > 1) for (int i = 0; i < n; ++i) if (bt.f[i].on || a[i].kl_rows || a[i].act_mu) return LBBNN_E_FLAGS;
         if (any_f16)
-            hipLaunchKernelGGL(weight_rows_kernel<true>, dim3(wgs, 1), dim3(256), (size_t)3 * maxld * sizeof(float), s, bt);
+            hipLaunchKernelGGL(weight_rows_kernel<true>, dim3(wgs, 1), dim3(kRowNT), (size_t)3 * maxld * sizeof(float), s, bt);
         else
-            hipLaunchKernelGGL(weight_rows_kernel<false>, dim3(wgs, members > 1 ? members : 1), dim3(256),
+            hipLaunchKernelGGL(weight_rows_kernel<false>, dim3(wgs, members > 1 ? members : 1), dim3(kRowNT),
                                (size_t)3 * maxld * sizeof(float), s, bt);
         return (int)hipGetLastError();
     }

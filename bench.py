@@ -33,7 +33,7 @@ How the number is taken (round 2; the round-1 line did not reproduce under the d
      that contradicts the timed region (share of step > 1, launch longer than a step) is not
      printed: "roofline_invalid" carries the reason instead.
      A step is one call of a RECORDED LAUNCH PLAN (bnn_amd.graphs.LaunchPlan: the forward's C calls
-     -- 4 calls, 5 kernels -- recorded once after the warm-up and made again from a list; --graph:
+     -- 3 calls, 5 kernels in the fp16 forward -- recorded once after the warm-up and made again from a list; --graph:
      one HIP-graph replay; --eager: the launches issued from Python each step); the noise is fresh
      on every call -- the Philox offset lives on the device and is advanced by the forward's kernels.
   4. the same three stages again with the exact-fp32 MFMA GEMM ("secondary": reference precision) and with the strict
@@ -88,7 +88,7 @@ def parse():
                     help="also time the data-parallel training step (default: only when N > 1)")
     ap.add_argument("--no-train", dest="train", action="store_false")
     ap.add_argument("--plan", dest="launch", action="store_const", const="plan", default="plan",
-                    help="(default) a step = bnn_amd.graphs.LaunchPlan: the forward's 4 C calls (5 kernels) recorded once after "
+                    help="(default) a step = bnn_amd.graphs.LaunchPlan: the forward's C calls (3 calls = 5 kernels in the fp16 forward) recorded once after "
                          "the warm-up and replayed from a list -- the eager launches without the Python between them (~30 us of "
                          "host time per step instead of ~100), fresh Philox noise on every call (the offset lives on the device)")
     ap.add_argument("--graph", dest="launch", action="store_const", const="graph",
@@ -720,7 +720,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE_OF[args.precision], "precision": args.precision,
             "data": "synthetic", "hip_graph": main_leg["launch"] == "graph",
-            "launch": {"plan": "recorded launch plan (bnn_amd.graphs.LaunchPlan: the forward's 4 C calls = 5 kernels, replayed from a list)",
+            "launch": {"plan": "recorded launch plan (bnn_amd.graphs.LaunchPlan: the forward's C calls -- flows + weight pass, GEMM 1 with the KL "
+                               "finalize riding, GEMM 2 with the head folded in + its finalize: 5 kernels -- replayed from a list)",
                        "graph": "one HIP-graph replay per step", "eager": "5 launches per step from Python"}[main_leg["launch"]],
             "launch_fallback_reason": main_leg["launch_fallback_reason"],
             "config": {"workload": "LBBNN-GP-MF-MNF 784-1200-1200-10, 2 planar flows/layer, batch %d per GPU, "
