@@ -271,9 +271,9 @@ __global__ __launch_bounds__(256) void weight_operands_t_kernel(const float* __r
         float e = 0.f, v = 0.f;
         if (o < O && i < I) {
             const size_t k = (size_t)o * I + i;
-            const float alpha = __frcp_rn(1.0f + __expf(-lam[k]));
+            const float alpha = k1_alpha(lam[k]);
             e = (mu[k] * alpha) * (z ? z[i] : 1.f);                                  // same association as the weight pass
-            if (v_t) { const float sg = softplus_fast(rho[k]); v = (sg * sg) * (alpha * alpha); }
+            if (v_t) { const float sg = k1_sigma(rho[k]); v = (sg * sg) * (alpha * alpha); }
         }
         te[ty + 8 * r][tx] = e; tv[ty + 8 * r][tx] = v;
     }

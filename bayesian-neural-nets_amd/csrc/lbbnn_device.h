@@ -149,6 +149,28 @@ __device__ __forceinline__ float softplus_fast(float rho) {
     if (y < 0.04f) return y * (1.f + y * (-0.5f + y * (0.33333334f + y * (-0.25f + y * 0.2f))));
     return log1pf(y);
 }
+// The weight pass's gate and scale (round 3), shared by every kernel that must reproduce its operands bit for bit (K1's
+// row / generic kernels, lbbnn_weight_operands_t).  Raw hardware forms: v_exp_f32 is 2^x, v_rcp_f32 ~1 ulp; the library
+// forms spend 4-5 more instructions per call on denormal scaling that these arguments cannot need (exp(-lambda) underflowing
+// to 0 / overflowing to inf gives alpha = 1 / 0, as the rounded reference value).  sigma's exp keeps the rounding of
+// rho * log2(e) (5e-7 relative at rho = -9, doubled in var_w = sigma^2 alpha^2) out through the product's exact residual.
+__device__ __forceinline__ float k1_exp_raw(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float k1_exp_acc(float x) {
+    const float th = x * 1.4426950408889634f;
+    float tl = __builtin_fmaf(x, 1.4426950408889634f, -th);
+    tl = __builtin_fmaf(x, 1.9259629911e-8f, tl);                            // log2(e) - fl32(log2(e))
+    const float e = __builtin_amdgcn_exp2f(th);
+    return __builtin_fmaf(e, tl * 0.6931471805599453f, e);
+}
+__device__ __forceinline__ float k1_alpha(float lam) { return __builtin_amdgcn_rcpf(1.0f + k1_exp_raw(-lam)); }
+// softplus from y = exp(rho): the 5-term log1p series while y < 0.04 (truncation < 1e-9 relative), libm beyond
+__device__ __forceinline__ float k1_sigma_of(float y) {
+    if (y < 0.04f)
+        return y * __builtin_fmaf(y, __builtin_fmaf(y, __builtin_fmaf(y, __builtin_fmaf(y, 0.2f, -0.25f), 0.33333334f), -0.5f), 1.f);
+    return log1pf(y);
+}
+__device__ __forceinline__ float k1_sigma(float rho) { return k1_sigma_of(k1_exp_acc(rho)); }
+
 __device__ __forceinline__ float tanh_fast(float x) {
     const float t = __expf(-2.f * fabsf(x));
     const float r = (1.f - t) * __frcp_rn(1.f + t);
@@ -184,17 +206,19 @@ __device__ __forceinline__ void philox_normal4(uint64_t seed, uint64_t offset, u
     const uint32_t k0 = (uint32_t)seed ^ ((uint32_t)offset * 0x9E3779B9u);
     const uint32_t k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(offset >> 32) ^ ((uint32_t)offset >> 7);
     const Philox4 r = philox4x32_10((uint32_t)ctr0, (uint32_t)(ctr0 >> 32), ctr1, stream, k0, k1);
-    // Box-Muller on two pairs; u in (0,1]: (x + 1) * 2^-32 avoids log(0).
+    // Box-Muller on two pairs; u in [2^-32, 1]: (x + 1) * 2^-32 avoids log(0) (and is never a denormal, never above 1: the
+    // largest x rounds to 2^32).  Round 3: the hardware forms taken directly -- v_log_f32 is log2, v_sin/v_cos take their
+    // argument in revolutions, v_sqrt_f32 at its native 1 ulp -- 24 VALU instructions after the Philox rounds where
+    // sqrtf / __logf / __sincosf (range checks, a Newton step, denormal scaling none of which these arguments can need)
+    // compiled to 82; every consumer draws through this one function, so explicit-noise == in-kernel-noise stays bitwise.
     const float u0 = ((float)r.x + 1.0f) * 2.3283064365386963e-10f;
     const float u1 = (float)r.y * 2.3283064365386963e-10f;
     const float u2 = ((float)r.z + 1.0f) * 2.3283064365386963e-10f;
     const float u3 = (float)r.w * 2.3283064365386963e-10f;
-    const float ra = sqrtf(-2.0f * __logf(fminf(u0, 1.0f)));
-    const float rb = sqrtf(-2.0f * __logf(fminf(u2, 1.0f)));
-    float sa, ca, sb, cb;
-    __sincosf(6.283185307179586f * u1, &sa, &ca);
-    __sincosf(6.283185307179586f * u3, &sb, &cb);
-    out[0] = ra * ca; out[1] = ra * sa; out[2] = rb * cb; out[3] = rb * sb;
+    const float ra = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));    // sqrt(-2 ln u0)
+    const float rb = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u2));
+    out[0] = ra * __builtin_amdgcn_cosf(u1); out[1] = ra * __builtin_amdgcn_sinf(u1);
+    out[2] = rb * __builtin_amdgcn_cosf(u3); out[3] = rb * __builtin_amdgcn_sinf(u3);
 }
 
 // 128 raw bits for counter (ctr0, ctr1) of stream `stream` (same keying as philox_normal4): Bernoulli(0.5) masks.

@@ -71,6 +71,15 @@ __device__ __forceinline__ void split4_h(const float4 w, uint2& hi, uint2& lo) {
     hi = make_uint2(h0, h1);
     lo = make_uint2(cvt_pk_h(w.x - (float)f0[0], w.y - (float)f0[1]), cvt_pk_h(w.z - (float)f1[0], w.w - (float)f1[1]));
 }
+// ... of w * scale (scale a power of two: exact), the products and residuals on packed pairs
+__device__ __forceinline__ void split4_hs(const float4 w, float scale, uint2& hi, uint2& lo) {
+    const k1_floatx2 a = k1_floatx2{w.x, w.y} * scale, b = k1_floatx2{w.z, w.w} * scale;
+    const k1_f16x2 f0 = __builtin_convertvector(a, k1_f16x2), f1 = __builtin_convertvector(b, k1_f16x2);
+    const k1_floatx2 ra = a - __builtin_convertvector(f0, k1_floatx2), rb = b - __builtin_convertvector(f1, k1_floatx2);
+    hi = make_uint2(__builtin_bit_cast(uint32_t, f0), __builtin_bit_cast(uint32_t, f1));
+    lo = make_uint2(__builtin_bit_cast(uint32_t, __builtin_convertvector(ra, k1_f16x2)),
+                    __builtin_bit_cast(uint32_t, __builtin_convertvector(rb, k1_f16x2)));
+}
 // max over the 64 lanes (every lane gets it); v >= 0
 __device__ __forceinline__ float wave_max(float v) {
     v = fmaxf(v, dpp_get<0xB1>(v));
@@ -104,8 +113,8 @@ __device__ __forceinline__ void pow2_scale(float m, float& scale, float& inv) {
 __device__ __forceinline__ Elem weight_elem(float mu, float rho, float lam, float zf, float zk, float rc,
                                             bool want_kl, bool want_act, const WeightPassArgs& a) {
     Elem e;
-    const float alpha = __frcp_rn(1.0f + __expf(-lam));
-    const float sigma = softplus_fast(rho);
+    const float alpha = k1_alpha(lam);
+    const float sigma = k1_sigma(rho);
     const float ea = mu * alpha;
     e.ew = ea * zf;
     e.vw = (sigma * sigma) * (alpha * alpha);
@@ -238,21 +247,65 @@ __global__ __launch_bounds__(256) void weight_pass_kernel(const WeightPassBatch 
 // ------------------------------------------------------------------------------------------------ round-2 row kernel
 struct ElemConst { float mu_prior, log_sp, log_ap, log_1map, inv_2sp2; };
 
-__device__ __forceinline__ Elem weight_elem_c(float mu, float rho, float lam, float zf, float zk, float rc,
-                                              bool want_kl, bool want_act, const ElemConst& c) {
-    Elem e;
-    const float alpha = __frcp_rn(1.0f + __expf(-lam));
-    const float sigma = softplus_fast(rho);
-    const float ea = mu * alpha;
-    e.ew = ea * zf;
-    e.vw = (sigma * sigma) * (alpha * alpha);
-    e.kl = 0.f; e.amu = 0.f; e.avar = 0.f;
+// Round 3: the same arithmetic on PAIRS of weights.  The row kernel is a single wave of workgroups (2410 rows on 3072 wave
+// slots) whose VALU work is not hidden behind anyone else's loads, so its instruction count is time: ~70 VALU per weight in
+// the scalar form above.  Here the non-transcendental part runs on float2 (v_pk_mul / v_pk_fma / v_pk_add_f32: two weights
+// per instruction), the transcendentals are the raw hardware forms (v_exp_f32 = 2^x, v_log_f32 = log2: the library forms
+// spend 4-5 instructions each on denormal scaling these arguments cannot need), log(1 - alpha) = log(alpha) - lambda costs
+// no logarithm (and no cancellation), and log(sigma) = rho + log1p-series while exp(rho) < 0.04 (the softplus series'
+// companion: log(softplus(rho)) - rho = -y/2 + 5y^2/24 - y^3/8 + 251y^4/2880, |next term| < 7e-9 there).
+typedef float k1_f2 __attribute__((ext_vector_type(2)));
+struct Elem2 { k1_f2 ew, vw, kl, amu, avar; };
+
+// (k1_exp_raw / k1_exp_acc / k1_alpha / k1_sigma_of of lbbnn_device.h on pairs: the same IEEE operations in the same order,
+// so a packed lane and the scalar form give the same bits -- lbbnn_weight_operands_t and the generic kernel rely on it)
+__device__ __forceinline__ k1_f2 exp_raw2(k1_f2 x) {
+    const k1_f2 t = x * 1.4426950408889634f;
+    return k1_f2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+}
+__device__ __forceinline__ k1_f2 exp_acc2(k1_f2 x) {
+    const k1_f2 l2e = {1.4426950408889634f, 1.4426950408889634f};
+    const k1_f2 th = x * l2e;
+    k1_f2 tl = __builtin_elementwise_fma(x, l2e, -th);
+    tl = __builtin_elementwise_fma(x, k1_f2{1.9259629911e-8f, 1.9259629911e-8f}, tl);      // log2(e) - fl32(log2(e))
+    const k1_f2 e = {__builtin_amdgcn_exp2f(th.x), __builtin_amdgcn_exp2f(th.y)};
+    return __builtin_elementwise_fma(e, tl * 0.6931471805599453f, e);
+}
+__device__ __forceinline__ k1_f2 ln_raw2(k1_f2 x) {
+    return k1_f2{__builtin_amdgcn_logf(x.x), __builtin_amdgcn_logf(x.y)} * 0.6931471805599453f;
+}
+__device__ __forceinline__ k1_f2 fma2(k1_f2 a, k1_f2 b, k1_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+__device__ __forceinline__ Elem2 weight_elem_p2(k1_f2 mu, k1_f2 rho, k1_f2 lam, k1_f2 zf, k1_f2 zk, k1_f2 rc,
+                                                bool want_kl, bool want_act, const ElemConst& c) {
+    Elem2 e;
+    const k1_f2 en = exp_raw2(-lam);                                    // exp(-lambda): 0 / inf at |lambda| > 87 -> alpha 1 / 0
+    const k1_f2 ope = en + 1.f;
+    const k1_f2 alpha = {__builtin_amdgcn_rcpf(ope.x), __builtin_amdgcn_rcpf(ope.y)};
+    const k1_f2 y = exp_acc2(rho);
+    k1_f2 sigma, lsig;
+    if (y.x < 0.04f && y.y < 0.04f) {
+        const k1_f2 p = fma2(y, fma2(y, fma2(y, fma2(y, k1_f2{0.2f, 0.2f}, k1_f2{-0.25f, -0.25f}), k1_f2{0.33333334f, 0.33333334f}),
+                                     k1_f2{-0.5f, -0.5f}), k1_f2{1.f, 1.f});
+        sigma = y * p;
+        if (want_kl)
+            lsig = fma2(y, fma2(y, fma2(y, fma2(y, k1_f2{0.08715278f, 0.08715278f}, k1_f2{-0.125f, -0.125f}),
+                                        k1_f2{0.20833333f, 0.20833333f}), k1_f2{-0.5f, -0.5f}), rho);
+    } else {
+        sigma = k1_f2{k1_sigma_of(y.x), k1_sigma_of(y.y)};
+        lsig = k1_f2{__logf(sigma.x), __logf(sigma.y)};
+    }
+    const k1_f2 s2 = sigma * sigma;
+    e.ew = (mu * alpha) * zf;
+    e.vw = s2 * (alpha * alpha);
+    e.kl = k1_f2{0.f, 0.f}; e.amu = e.kl; e.avar = e.kl;
     if (want_kl) {
-        const float d = mu * zk - c.mu_prior;
-        const float one_m = 1.f - alpha;
-        e.kl = alpha * ((c.log_sp - __logf(sigma)) - 0.5f + (__logf(alpha) - c.log_ap)
-                        + (sigma * sigma + d * d) * c.inv_2sp2)
-             + one_m * (__logf(one_m) - c.log_1map);
+        const k1_f2 d = fma2(mu, zk, k1_f2{-c.mu_prior, -c.mu_prior});
+        const k1_f2 la = -ln_raw2(ope);                                 // log(alpha) = -log(1 + exp(-lambda))
+        const k1_f2 l1m = la - lam;                                     // log(1 - alpha)
+        const k1_f2 one_m = 1.f - alpha;
+        const k1_f2 t = ((c.log_sp - lsig) - 0.5f) + (la - c.log_ap) + fma2(d, d, s2) * c.inv_2sp2;
+        e.kl = alpha * t + one_m * (l1m - c.log_1map);
     }
     if (want_act) {
         e.amu = rc * ((zk * mu) * alpha);
@@ -473,7 +526,7 @@ __global__ __launch_bounds__(kRowNT, 3) void weight_rows_kernel(const WeightRows
     // ---------------------------------------------------------------- one row per wave
     if (!has_row) return;
     const ElemConst ec = {a.mu_prior, a.log_sp, a.log_ap, a.log_1map, a.inv_2sp2};
-    float kl = 0.f, amu = 0.f, avar = 0.f;
+    k1_f2 kl2 = {0.f, 0.f}, amu2 = kl2, avar2 = kl2;          // per-lane partial row sums, two lanes of a packed register
     const bool split = a.split == 1;
     float* const ewp = a.e_w ? a.e_w + (size_t)mem * a.O * P : nullptr;
     float* const vwp = mem == 0 ? a.var_w : nullptr;
@@ -501,15 +554,15 @@ __global__ __launch_bounds__(kRowNT, 3) void weight_rows_kernel(const WeightRows
             if (j < iq) {
                 const float4 zf = reinterpret_cast<const float4*>(zf_s)[j], zk = reinterpret_cast<const float4*>(zk_s)[j];
                 const float4 rc = reinterpret_cast<const float4*>(rc_s)[j];
-                const Elem e0 = weight_elem_c(mu[g].x, rho[g].x, lam[g].x, zf.x, zk.x, rc.x, want_kl, want_act, ec);
-                const Elem e1 = weight_elem_c(mu[g].y, rho[g].y, lam[g].y, zf.y, zk.y, rc.y, want_kl, want_act, ec);
-                const Elem e2 = weight_elem_c(mu[g].z, rho[g].z, lam[g].z, zf.z, zk.z, rc.z, want_kl, want_act, ec);
-                const Elem e3 = weight_elem_c(mu[g].w, rho[g].w, lam[g].w, zf.w, zk.w, rc.w, want_kl, want_act, ec);
-                ew = make_float4(e0.ew, e1.ew, e2.ew, e3.ew);
-                vw = make_float4(e0.vw, e1.vw, e2.vw, e3.vw);
-                kl += (e0.kl + e1.kl) + (e2.kl + e3.kl);
-                amu += (e0.amu + e1.amu) + (e2.amu + e3.amu);
-                avar += (e0.avar + e1.avar) + (e2.avar + e3.avar);
+                const Elem2 ea = weight_elem_p2(k1_f2{mu[g].x, mu[g].y}, k1_f2{rho[g].x, rho[g].y}, k1_f2{lam[g].x, lam[g].y},
+                                                k1_f2{zf.x, zf.y}, k1_f2{zk.x, zk.y}, k1_f2{rc.x, rc.y}, want_kl, want_act, ec);
+                const Elem2 eb = weight_elem_p2(k1_f2{mu[g].z, mu[g].w}, k1_f2{rho[g].z, rho[g].w}, k1_f2{lam[g].z, lam[g].w},
+                                                k1_f2{zf.z, zf.w}, k1_f2{zk.z, zk.w}, k1_f2{rc.z, rc.w}, want_kl, want_act, ec);
+                ew = make_float4(ea.ew.x, ea.ew.y, eb.ew.x, eb.ew.y);
+                vw = make_float4(ea.vw.x, ea.vw.y, eb.vw.x, eb.vw.y);
+                kl2 += ea.kl + eb.kl;
+                amu2 += ea.amu + eb.amu;
+                avar2 += ea.avar + eb.avar;
             }
             if constexpr (F16S) {
                 ew_keep[g] = ew; vw_keep[g] = vw;           // stored below, once the row maxima are known
@@ -549,8 +602,8 @@ __global__ __launch_bounds__(kRowNT, 3) void weight_rows_kernel(const WeightRows
 #pragma unroll
             for (int g = 0; g < kRowB; ++g) {
                 if (g >= G) break;
-                me = fmaxf(me, fmaxf(fmaxf(fabsf(ew_keep[g].x), fabsf(ew_keep[g].y)), fmaxf(fabsf(ew_keep[g].z), fabsf(ew_keep[g].w))));
-                mv = fmaxf(mv, fmaxf(fmaxf(vw_keep[g].x, vw_keep[g].y), fmaxf(vw_keep[g].z, vw_keep[g].w)));
+                me = fmaxf(fmaxf(fmaxf(fmaxf(me, fabsf(ew_keep[g].x)), fabsf(ew_keep[g].y)), fabsf(ew_keep[g].z)), fabsf(ew_keep[g].w));
+                mv = fmaxf(fmaxf(fmaxf(fmaxf(mv, vw_keep[g].x), vw_keep[g].y), vw_keep[g].z), vw_keep[g].w);   // chains: v_max3_f32
             }
             me = wave_max(me); mv = wave_max(mv);
             pow2_scale(me, se, ie);
@@ -572,7 +625,7 @@ __global__ __launch_bounds__(kRowNT, 3) void weight_rows_kernel(const WeightRows
             uint2 hi, lo;
             {
                 const float4 w = ew_keep[g];
-                if (f16s) split4_h(make_float4(w.x * se, w.y * se, w.z * se, w.w * se), hi, lo);
+                if (f16s) split4_hs(w, se, hi, lo);
                 else split4(w, hi, lo);
                 const uint32_t r0 = dpp_xor1(odd ? hi.x : lo.x), r1 = dpp_xor1(odd ? hi.y : lo.y);
                 const uint4 unit = make_uint4(odd ? r0 : hi.x, odd ? r1 : hi.y, odd ? lo.x : r0, odd ? lo.y : r1);
@@ -586,7 +639,7 @@ __global__ __launch_bounds__(kRowNT, 3) void weight_rows_kernel(const WeightRows
                     make_uint2(cvt_pk_h(w.x * sv, w.y * sv), cvt_pk_h(w.z * sv, w.w * sv));
             } else if (vwp) {
                 const float4 w = vw_keep[g];
-                if (f16s) split4_h(make_float4(w.x * sv, w.y * sv, w.z * sv, w.w * sv), hi, lo);
+                if (f16s) split4_hs(w, sv, hi, lo);
                 else split4(w, hi, lo);
                 const uint32_t r0 = dpp_xor1(odd ? hi.x : lo.x), r1 = dpp_xor1(odd ? hi.y : lo.y);
                 const uint4 unit = make_uint4(odd ? r0 : hi.x, odd ? r1 : hi.y, odd ? lo.x : r0, odd ? lo.y : r1);
@@ -599,7 +652,7 @@ __global__ __launch_bounds__(kRowNT, 3) void weight_rows_kernel(const WeightRows
         }
     }
     if (want_kl || want_act) {
-        kl = wave_sum(kl); amu = wave_sum(amu); avar = wave_sum(avar);
+        const float kl = wave_sum(kl2.x + kl2.y), amu = wave_sum(amu2.x + amu2.y), avar = wave_sum(avar2.x + avar2.y);
         if (lane == 0) {
             if (want_kl) a.kl_rows[o] = kl;
             if (want_act) { a.act_mu[o] = amu; a.act_var[o] = avar; }
