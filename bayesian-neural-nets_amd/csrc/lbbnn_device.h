@@ -171,6 +171,10 @@ __device__ __forceinline__ float k1_sigma_of(float y) {
 }
 __device__ __forceinline__ float k1_sigma(float rho) { return k1_sigma_of(k1_exp_acc(rho)); }
 
+// sqrt of an activation variance in the GEMM epilogues: v_sqrt_f32 alone (1 ulp).  sqrtf compiles to 12 instructions (range
+// scaling + a Newton step for the last half ulp) -- 40 of them per lane of a 128 x 80 tile; a variance below 2^-126 gives 0.
+__device__ __forceinline__ float sqrt_hw(float x) { return __builtin_amdgcn_sqrtf(x); }
+
 __device__ __forceinline__ float tanh_fast(float x) {
     const float t = __expf(-2.f * fabsf(x));
     const float r = (1.f - t) * __frcp_rn(1.f + t);

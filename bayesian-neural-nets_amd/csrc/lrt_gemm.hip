@@ -128,7 +128,7 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& a, const EpiCtx& c, co
     for (int r = 0; r < 4; ++r) {
         float mean = am[r] + oc.bm[r];
         sd[r] = 0.f;
-        if (!MEAN_ONLY) { sd[r] = sqrtf(av[r] * oc.vs[r] + oc.bv[r]); mean += sd[r] * e[r]; }
+        if (!MEAN_ONLY) { sd[r] = sqrt_hw(av[r] * oc.vs[r] + oc.bv[r]); mean += sd[r] * e[r]; }
         res[r] = a.relu ? fmaxf(mean, 0.f) : mean;
     }
     if (MEAN_ONLY && a.comb_x) {

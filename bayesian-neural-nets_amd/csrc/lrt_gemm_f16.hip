@@ -190,7 +190,7 @@ __device__ __forceinline__ void epilogue16(const G16Args& a, int o0, int q, int 
             float res[4], sd[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                sd[r] = sqrtf(accv[i][j][r] * oc[i].vs[r] + oc[i].bv[r]);
+                sd[r] = sqrt_hw(accv[i][j][r] * oc[i].vs[r] + oc[i].bv[r]);
                 const float m = accm[i][j][r] * oc[i].ms[r] + oc[i].bm[r] + sd[r] * e[r];
                 res[r] = a.relu ? fmaxf(m, 0.f) : m;
             }
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(const HeadFinArgs a)
         const int c = c0 + r;
         const bool in = rowok && c < a.C;
         const float bm = (in && a.bias_mean) ? a.bias_mean[c] : 0.f, bv = (in && a.bias_var) ? a.bias_var[c] : 0.f;
-        const float sd = sqrtf(v[r] * (kS2inv / kHeadVS) + bv);
+        const float sd = sqrt_hw(v[r] * (kS2inv / kHeadVS) + bv);
         res[r] = m[r] * (1.f / kHeadES) + bm + sd * e[r];
         if (in) mx = fmaxf(mx, res[r]);
     }
