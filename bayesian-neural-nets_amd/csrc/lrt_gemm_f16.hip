@@ -446,6 +446,19 @@ __device__ __forceinline__ void gemm_f16s_body(const G16Args& a) {
     // step's MFMAs, the VALU port being idle four cycles out of five in this loop -- bit-identical outputs, no spills at 8
     // tiles, and 0.1499 ms per forward against 0.1473: a wave issues in order, so the 140 instructions lengthen ITS chain of
     // the step by what the epilogue saves, and the chain of a wave, not the occupancy of a pipe, is what a step costs.)
+    // (Measured and dropped, round 3, after the VALU trims (forward 0.1255 ms): (a) ROLLING FRAGMENT PREFETCH -- the weight
+    // fragments of tile row i re-loaded for step c + 1 right after step c's MFMAs of row i (same registers, order given by
+    // sched_group_barrier; 15 of the 19 ds_reads under the wave's own MFMAs), the LDS-DMA two steps ahead: bit-identical,
+    // 0.1303 ms -- the piece issue then sits between the barrier and the first MFMA instead of under the ds_read latency.
+    // (b) STRAIGHT-LINE PIECE ISSUE -- per-piece descriptors / LDS offsets / strides in scalar registers set up once, 8 x
+    // (s_mov m0, s_add, buffer_load lds) per step instead of ~20 scalar branches: 0.1276 ms.  Neither the branches nor the
+    // (a) + (b) with the pieces issued two at a time BETWEEN the MFMA groups: 0.1559 ms -- a wave issues in order, and a
+    // buffer_load ... lds that waits for a slot in the fill queue holds back the MFMAs behind it.  (c) 64 x 80 per wave, two
+    // waves per workgroup, one wave per SIMD with 160 accumulator AGPRs (`<5, 4, 2>`: every weight fragment read by two waves
+    // instead of four, 92 KB of fragment reads per CU-step instead of 152): 0.1699 ms against 0.1271 -- nothing hides a lone
+    // wave's waits.  Neither the branches nor the order is what a step costs: 62 pieces at ~20 cycles each (LDS written at
+    // ~51 B/clk) plus 152 KB of fragment reads at 128 B/clk are 2456 of the 2592 cycles a step takes -- the LDS port is busy
+    // 95 % of the time, the matrix pipe 49 %; the piece issue is cheapest where it is, under the ds_read latency.)
     dma_step(0, smc);
     __syncthreads();
     for (int c = 0; c < nsteps; ++c) {
