@@ -170,6 +170,12 @@ __device__ __forceinline__ float k1_sigma_of(float y) {
     return log1pf(y);
 }
 __device__ __forceinline__ float k1_sigma(float rho) { return k1_sigma_of(k1_exp_acc(rho)); }
+// log(softplus(rho)) from the same y: rho + (-y/2 + 5y^2/24 - y^3/8 + 251y^4/2880) in the series range (|next term| < 7e-9)
+__device__ __forceinline__ float k1_log_sigma_of(float rho, float y, float sigma) {
+    if (y < 0.04f)
+        return __builtin_fmaf(y, __builtin_fmaf(y, __builtin_fmaf(y, __builtin_fmaf(y, 0.08715278f, -0.125f), 0.20833333f), -0.5f), rho);
+    return __logf(sigma);
+}
 
 // sqrt of an activation variance in the GEMM epilogues: v_sqrt_f32 alone (1 ulp).  sqrtf compiles to 12 instructions (range
 // scaling + a Newton step for the last half ulp) -- 40 of them per lane of a 128 x 80 tile; a variance below 2^-126 gives 0.

@@ -159,6 +159,33 @@ __global__ __launch_bounds__(HD_COLS) void head_dx_kernel(const float* __restric
     }
 }
 
+// ... for the class counts this is built for (the reference's head has 10 classes: LBBNN-GP-MF-MNF.py:247): the gradient row
+// of a batch row is the same for every thread, so it is read with SCALAR loads (uniform address, read-only) and enters the
+// multiply-adds as scalar operands -- no LDS stage, no broadcast reads (the generic kernel above spends 32 ds_reads per
+// output on them and pads the class loop to 16), C x 2 multiply-adds per output.
+template <int C>
+__global__ __launch_bounds__(HD_COLS) void head_dx_c_kernel(const float* __restrict__ gm, const float* __restrict__ gv, int ldg,
+                                                            const float* __restrict__ wmT, const float* __restrict__ wvT, int ldw,
+                                                            const float* __restrict__ x, int ldx, float* __restrict__ out, int ldo,
+                                                            int B, int I) {
+    const int b0 = blockIdx.y * HD_ROWS, i = blockIdx.x * HD_COLS + threadIdx.x;
+    if (i >= I) return;
+    float wm[C], wv[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) { wm[c] = wmT[(size_t)i * ldw + c]; wv[c] = wvT[(size_t)i * ldw + c]; }
+    const int nr = min(HD_ROWS, B - b0);
+#pragma unroll 4
+    for (int r = 0; r < nr; ++r) {
+        const float* __restrict__ pm = gm + (size_t)(b0 + r) * ldg;
+        const float* __restrict__ pv = gv + (size_t)(b0 + r) * ldg;
+        const float xv = x[(size_t)(b0 + r) * ldx + i];
+        float am = 0.f, av = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) { am += pm[c] * wm[c]; av += pv[c] * wv[c]; }
+        out[(size_t)(b0 + r) * ldo + i] = am + 2.f * xv * av;
+    }
+}
+
 }  // namespace
 
 extern "C" int lbbnn_head_dx(const float* gm, const float* gv, int ldg, const float* wmT, const float* wvT, int ldw,
@@ -166,8 +193,13 @@ extern "C" int lbbnn_head_dx(const float* gm, const float* gv, int ldg, const fl
     if (!gm || !wmT || !out) return LBBNN_E_NULL;
     if ((gv == nullptr) != (wvT == nullptr) || (gv && !x)) return LBBNN_E_NULL;
     if (B <= 0 || C <= 0 || C > HD_MAXC || I <= 0 || ldg < C || ldw < C || ldo < I || (x && ldx < I)) return LBBNN_E_SHAPE;
-    hipLaunchKernelGGL(head_dx_kernel, dim3((I + HD_COLS - 1) / HD_COLS, (B + HD_ROWS - 1) / HD_ROWS), dim3(HD_COLS), 0,
-                       static_cast<hipStream_t>(stream), gm, gv, ldg, wmT, wvT, ldw, x, ldx, out, ldo, B, C, I);
+    const dim3 grid((I + HD_COLS - 1) / HD_COLS, (B + HD_ROWS - 1) / HD_ROWS);
+    if (C == 10 && gv)
+        hipLaunchKernelGGL(head_dx_c_kernel<10>, grid, dim3(HD_COLS), 0, static_cast<hipStream_t>(stream), gm, gv, ldg, wmT, wvT,
+                           ldw, x, ldx, out, ldo, B, I);
+    else
+        hipLaunchKernelGGL(head_dx_kernel, grid, dim3(HD_COLS), 0, static_cast<hipStream_t>(stream), gm, gv, ldg, wmT, wvT, ldw,
+                           x, ldx, out, ldo, B, C, I);
     return (int)hipGetLastError();
 }
 

@@ -1,6 +1,6 @@
 // K1b -- analytic backward of the fused weight pass (see include/lbbnn.h).  HBM-bound: 20 B read + 12 B
 // written per weight.  A 256-thread workgroup owns 64 column groups (4 columns each, or 1 on the unaligned path) x
-// RB = 16 rows: every global access is a coalesced row segment, the three column sums (dz_fwd, dz_kl, dr0_c)
+// RB = 8 rows: every global access is a coalesced row segment, the three column sums (dz_fwd, dz_kl, dr0_c)
 // accumulate in registers, and the per-row-block partials are reduced in a fixed order by a second launch
 // (deterministic, no float atomics).
 #include <cmath>
@@ -10,7 +10,7 @@
 namespace {
 
 using namespace lbbnn;
-constexpr int RB = 16;
+constexpr int RB = 8;
 
 struct Consts { float mp, inv_sp2, log_sp, log_ap, log_1map, gk; };
 
@@ -18,11 +18,13 @@ struct Consts { float mp, inv_sp2, log_sp, log_ap, log_1map, gk; };
 __device__ __forceinline__ void elem_bwd(float mu, float rho, float lam, float gWm, float gWv, float zf, float zk, float rc,
                                          float dam, float dav, const Consts& c, bool has_kl, bool has_act,
                                          float& dmu, float& drho, float& dlam, float& czf, float& czk, float& crc) {
-    const float ex = __expf(-lam);
-    const float alpha = __frcp_rn(1.f + ex);
-    const float er = __expf(rho);
-    const float sigma = er < 0.04f ? er * (1.f + er * (-0.5f + er * (0.33333334f + er * (-0.25f + er * 0.2f)))) : log1pf(er);
-    const float dsig = er * __frcp_rn(1.f + er);              // d softplus / d rho = sigmoid(rho)
+    // the forward's own forms (lbbnn_device.h k1_*: raw v_exp / v_rcp / v_log, no denormal scaling, no cancellation)
+    const float ex = k1_exp_raw(-lam);
+    const float ope = 1.f + ex;
+    const float alpha = __builtin_amdgcn_rcpf(ope);
+    const float er = k1_exp_acc(rho);
+    const float sigma = k1_sigma_of(er);
+    const float dsig = er * __builtin_amdgcn_rcpf(1.f + er);  // d softplus / d rho = sigmoid(rho)
     const float a2 = alpha * alpha, s2 = sigma * sigma;
     float Gmu = gWm * alpha * zf;
     float Gsig = gWv * 2.f * sigma * a2;
@@ -32,10 +34,11 @@ __device__ __forceinline__ void elem_bwd(float mu, float rho, float lam, float g
     if (has_kl) {
         const float d = mu * zk - c.mp;
         const float one_m = 1.f - alpha;
-        const float T = (c.log_sp - __logf(sigma)) - 0.5f + (__logf(alpha) - c.log_ap) + (s2 + d * d) * 0.5f * c.inv_sp2;
+        const float la = -0.6931471805599453f * __builtin_amdgcn_logf(ope);       // log(alpha) = -log(1 + exp(-lambda))
+        const float T = (c.log_sp - k1_log_sigma_of(rho, er, sigma)) - 0.5f + (la - c.log_ap) + (s2 + d * d) * 0.5f * c.inv_sp2;
         Gmu += c.gk * alpha * d * zk * c.inv_sp2;
-        Gsig += c.gk * alpha * (sigma * c.inv_sp2 - __frcp_rn(sigma));
-        Gal += c.gk * (T - (__logf(one_m) - c.log_1map));
+        Gsig += c.gk * alpha * (sigma * c.inv_sp2 - __builtin_amdgcn_rcpf(sigma));
+        Gal += c.gk * (T - ((la - lam) - c.log_1map));                             // log(1 - alpha) = log(alpha) - lambda
         czk = c.gk * alpha * d * mu * c.inv_sp2;
     }
     if (has_act) {
@@ -51,9 +54,9 @@ __device__ __forceinline__ void elem_bwd(float mu, float rho, float lam, float g
     dlam = Gal * alpha * (1.f - alpha);
 }
 
-// Workgroup = 64 column groups (of W columns) x 4 row lanes, RB = 16 rows: thread (cg, rl) walks rows rl, rl+4, ...
+// Workgroup = 64 column groups (of W columns) x 4 row lanes, RB = 8 rows: thread (cg, rl) owns rows rl and rl + 4
 // of its column group (a wave reads 64 x 16 B = 1 KiB of one row), keeps the three column sums in registers, and
-// the 4 row lanes are added through LDS in a fixed order.  Grid = (column blocks, row blocks): 5 x 75 workgroups
+// the 4 row lanes are added through LDS in a fixed order.  Grid = (column blocks, row blocks): 5 x 150 workgroups
 // for 1200 x 1200 -- the first version (one workgroup per 8 full rows) had 150 workgroups for 256 CUs and an
 // 85 %-idle second loop trip.
 template <int W>
@@ -79,51 +82,86 @@ __global__ __launch_bounds__(256) void weight_pass_bwd_kernel(const lbbnn_wpb_ar
         rc[k] = (a.r0_c && in) ? a.r0_c[i] : 0.f;
         szf[k] = szk[k] = src[k] = 0.f;
     }
-    if (live)
-        for (int r = r0 + rl; r < r1; r += 4) {
-            const size_t off = (size_t)r * a.I + i0;
-            const float dam = has_act ? a.da_mu[r] : 0.f, dav = has_act ? a.da_var[r] : 0.f;
-            float mu[W], rho[W], lam[W], gm[W], gv[W];
-            if (W == 4) {
-                const float4 t0 = *reinterpret_cast<const float4*>(a.mu + off), t1 = *reinterpret_cast<const float4*>(a.rho + off);
-                const float4 t2 = *reinterpret_cast<const float4*>(a.lambdal + off);
-                float4 t3 = *reinterpret_cast<const float4*>(a.dWm + off);
-                float4 t4 = a.dWv ? *reinterpret_cast<const float4*>(a.dWv + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int sp = 1; sp < a.nsplit; ++sp) {               // split-K slabs, fixed order
-                    const float4 u3 = *reinterpret_cast<const float4*>(a.dWm + (size_t)sp * a.split_stride + off);
-                    t3.x += u3.x; t3.y += u3.y; t3.z += u3.z; t3.w += u3.w;
-                    if (a.dWv) {
-                        const float4 u4 = *reinterpret_cast<const float4*>(a.dWv + (size_t)sp * a.split_stride + off);
-                        t4.x += u4.x; t4.y += u4.y; t4.z += u4.z; t4.w += u4.w;
+    if (live && W == 4) {
+        // NR = RB / 4 rows per thread, every load of all of them in flight together: the parameters, slab 0 of both weight
+        // gradients, then the remaining split-K slabs four at a time (fixed order of additions).  The first version walked
+        // rows and slabs one after the other -- a chain of dependent memory latencies per workgroup (the 10-row head with
+        // its 16 slabs took as long as a 1200-row layer: 22 us).
+        constexpr int NR = RB / 4;
+        float4 t[NR][5];
+        bool ok[NR];
+        size_t offs[NR];
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            const int r = r0 + rl + 4 * q;
+            ok[q] = r < r1;
+            offs[q] = (size_t)r * a.I + i0;
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            t[q][0] = t[q][1] = t[q][2] = t[q][3] = t[q][4] = z4;
+            if (ok[q]) {
+                t[q][0] = *reinterpret_cast<const float4*>(a.mu + offs[q]);
+                t[q][1] = *reinterpret_cast<const float4*>(a.rho + offs[q]);
+                t[q][2] = *reinterpret_cast<const float4*>(a.lambdal + offs[q]);
+                t[q][3] = *reinterpret_cast<const float4*>(a.dWm + offs[q]);
+                if (a.dWv) t[q][4] = *reinterpret_cast<const float4*>(a.dWv + offs[q]);
+            }
+        }
+        for (int sp = 1; sp < a.nsplit; sp += 4) {
+            float4 u3[NR][4], u4[NR][4];
+#pragma unroll
+            for (int q = 0; q < NR; ++q)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    u3[q][k] = make_float4(0.f, 0.f, 0.f, 0.f); u4[q][k] = u3[q][k];
+                    if (ok[q] && sp + k < a.nsplit) {
+                        u3[q][k] = *reinterpret_cast<const float4*>(a.dWm + (size_t)(sp + k) * a.split_stride + offs[q]);
+                        if (a.dWv) u4[q][k] = *reinterpret_cast<const float4*>(a.dWv + (size_t)(sp + k) * a.split_stride + offs[q]);
                     }
                 }
-                mu[0] = t0.x; mu[1] = t0.y; mu[2] = t0.z; mu[3] = t0.w;  rho[0] = t1.x; rho[1] = t1.y; rho[2] = t1.z; rho[3] = t1.w;
-                lam[0] = t2.x; lam[1] = t2.y; lam[2] = t2.z; lam[3] = t2.w;  gm[0] = t3.x; gm[1] = t3.y; gm[2] = t3.z; gm[3] = t3.w;
-                gv[0] = t4.x; gv[1] = t4.y; gv[2] = t4.z; gv[3] = t4.w;
-            } else {
-                mu[0] = a.mu[off]; rho[0] = a.rho[off]; lam[0] = a.lambdal[off]; gm[0] = a.dWm[off]; gv[0] = a.dWv ? a.dWv[off] : 0.f;
-                for (int sp = 1; sp < a.nsplit; ++sp) {
-                    gm[0] += a.dWm[(size_t)sp * a.split_stride + off];
-                    if (a.dWv) gv[0] += a.dWv[(size_t)sp * a.split_stride + off];
-                }
-            }
-            float dm[W], dr[W], dl[W];
 #pragma unroll
-            for (int k = 0; k < W; ++k) {
+            for (int q = 0; q < NR; ++q)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {                          // slabs in order (an absent slab adds +0: exact)
+                    t[q][3].x += u3[q][k].x; t[q][3].y += u3[q][k].y; t[q][3].z += u3[q][k].z; t[q][3].w += u3[q][k].w;
+                    t[q][4].x += u4[q][k].x; t[q][4].y += u4[q][k].y; t[q][4].z += u4[q][k].z; t[q][4].w += u4[q][k].w;
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            if (!ok[q]) continue;
+            const int r = r0 + rl + 4 * q;
+            const float dam = has_act ? a.da_mu[r] : 0.f, dav = has_act ? a.da_var[r] : 0.f;
+            const float mu[4] = {t[q][0].x, t[q][0].y, t[q][0].z, t[q][0].w}, rho[4] = {t[q][1].x, t[q][1].y, t[q][1].z, t[q][1].w};
+            const float lam[4] = {t[q][2].x, t[q][2].y, t[q][2].z, t[q][2].w}, gm[4] = {t[q][3].x, t[q][3].y, t[q][3].z, t[q][3].w};
+            const float gv[4] = {t[q][4].x, t[q][4].y, t[q][4].z, t[q][4].w};
+            float dm[4], dr[4], dl[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
                 float czf, czk, crc;
                 elem_bwd(mu[k], rho[k], lam[k], gm[k], gv[k], zf[k], zk[k], rc[k], dam, dav, c, has_kl, has_act,
                          dm[k], dr[k], dl[k], czf, czk, crc);
                 szf[k] += czf; szk[k] += czk; src[k] += crc;
             }
-            if (W == 4) {
-                *reinterpret_cast<float4*>(a.dmu + off) = make_float4(dm[0], dm[1], dm[2], dm[3]);
-                *reinterpret_cast<float4*>(a.drho + off) = make_float4(dr[0], dr[1], dr[2], dr[3]);
-                *reinterpret_cast<float4*>(a.dlambdal + off) = make_float4(dl[0], dl[1], dl[2], dl[3]);
-            } else {
-                a.dmu[off] = dm[0]; a.drho[off] = dr[0]; a.dlambdal[off] = dl[0];
-            }
+            *reinterpret_cast<float4*>(a.dmu + offs[q]) = make_float4(dm[0], dm[1], dm[2], dm[3]);
+            *reinterpret_cast<float4*>(a.drho + offs[q]) = make_float4(dr[0], dr[1], dr[2], dr[3]);
+            *reinterpret_cast<float4*>(a.dlambdal + offs[q]) = make_float4(dl[0], dl[1], dl[2], dl[3]);
         }
-    // column sums of this workgroup's 16 rows: row lanes 0..3 added in order
+    } else if (live) {
+        for (int r = r0 + rl; r < r1; r += 4) {
+            const size_t off = (size_t)r * a.I + i0;
+            const float dam = has_act ? a.da_mu[r] : 0.f, dav = has_act ? a.da_var[r] : 0.f;
+            float mu = a.mu[off], rho = a.rho[off], lam = a.lambdal[off], gm = a.dWm[off], gv = a.dWv ? a.dWv[off] : 0.f;
+            for (int sp = 1; sp < a.nsplit; ++sp) {
+                gm += a.dWm[(size_t)sp * a.split_stride + off];
+                if (a.dWv) gv += a.dWv[(size_t)sp * a.split_stride + off];
+            }
+            float czf, czk, crc, dm, dr, dl;
+            elem_bwd(mu, rho, lam, gm, gv, zf[0], zk[0], rc[0], dam, dav, c, has_kl, has_act, dm, dr, dl, czf, czk, crc);
+            szf[0] += czf; szk[0] += czk; src[0] += crc;
+            a.dmu[off] = dm; a.drho[off] = dr; a.dlambdal[off] = dl;
+        }
+    }
+    // column sums of this workgroup's RB rows: row lanes 0..3 added in order
 #pragma unroll
     for (int k = 0; k < W; ++k) { red[0][rl][cg * W + k] = szf[k]; red[1][rl][cg * W + k] = szk[k]; red[2][rl][cg * W + k] = src[k]; }
     __syncthreads();
