@@ -459,6 +459,11 @@ __device__ __forceinline__ void gemm_f16s_body(const G16Args& a) {
     // wave's waits.  Neither the branches nor the order is what a step costs: 62 pieces at ~20 cycles each (LDS written at
     // ~51 B/clk) plus 152 KB of fragment reads at 128 B/clk are 2456 of the 2592 cycles a step takes -- the LDS port is busy
     // 95 % of the time, the matrix pipe 49 %; the piece issue is cheapest where it is, under the ds_read latency.)
+    // (VERDICT r02 item 6's premise tested, round 3: the second workgroup of every CU (linear id >= 256) delayed by d at its
+    // start, so that one workgroup's VALU-bound epilogue falls beside the other's LDS-bound loop: forward 0.1255 ms at
+    // d = 0, 0.1271 / 0.1279 / 0.1304 / 0.1322 at d = 0.85 / 1.7 / 3.4 / 5.1 us -- two thirds of every microsecond of skew
+    // come back as time.  A workgroup looping alone does not use what its neighbour leaves free, so an uneven K split
+    // between them would buy less than its combine costs: not built.)
     dma_step(0, smc);
     __syncthreads();
     for (int c = 0; c < nsteps; ++c) {
