@@ -341,7 +341,9 @@ __device__ __forceinline__ float4 fma4(const float4 u, float s, const float4 z) 
 }
 __device__ __forceinline__ uint32_t dpp_xor1(uint32_t v) { return (uint32_t)dpp_mov<0xB1>((int)v); }   // lane ^ 1
 
-template <bool F16S>
+// INFLOW: some layer of the launch computes its planar flows inside its workgroups (f.on); the fused forwards since K3v have
+// none, and their instantiation carries neither that code nor its register pressure.
+template <bool F16S, bool INFLOW>
 __global__ __launch_bounds__(kRowNT, 3) void weight_rows_kernel(const WeightRowsBatch bt_) {
     const LBBNN_CONST_AS WeightRowsBatch* bt = kernarg_as<WeightRowsBatch>();
     extern __shared__ __attribute__((aligned(16))) float sm[];          // zf[P] | zk[P] | rc[P]
@@ -372,8 +374,21 @@ __global__ __launch_bounds__(kRowNT, 3) void weight_rows_kernel(const WeightRows
     // (Measured and dropped, round 2: requesting the row AHEAD of the prologue -- held in registers: 98 spilled VGPRs at the
     // 168-register budget three workgroups per CU need; touched line by line with unused asm loads: 35.7 us against 33.6.)
 
+    // Round 3: with the flows computed by their own launch (f.on == 0: the fused forwards since K3v) the row's first batch of
+    // parameter loads is requested HERE, ahead of the staging of the per-column vectors -- 15 x 16 B per lane in flight while
+    // the z vectors make their round trip to LDS, instead of after the barrier behind it.  (With the in-kernel flows the same
+    // hoist spilled: see above; that path keeps the loads below.)
+    float4 mu[kRowB], rho[kRowB], lam[kRowB];
+    if (!INFLOW && has_row) {
+#pragma unroll
+        for (int g = 0; g < kRowB; ++g) {
+            const int j = lane + 64 * g;
+            if (g < G && j < iq) { mu[g] = ld4(a.mu + rowoff, j); rho[g] = ld4(a.rho + rowoff, j); lam[g] = ld4(a.lambdal + rowoff, j); }
+        }
+    }
+
     // ---------------------------------------------------------------- per-column vectors of this layer -> LDS
-    if (f.on) {
+    if (INFLOW && f.on) {
         const int Tz = f.Tz, NT = f.Tz + f.Tr;
         const bool klb = f.want_kl != 0;
         uint64_t seed = 0, offs = 0;
@@ -540,11 +555,12 @@ __global__ __launch_bounds__(kRowNT, 3) void weight_rows_kernel(const WeightRows
     const bool vhi_only = a.split == 3;               // LBBNN_F_VAR1 operands: var_w = plain fp16 rows (the hi part alone)
     float4 ew_keep[F16S ? kRowB : 1], vw_keep[F16S ? kRowB : 1];
     for (int g0 = 0; g0 < G; g0 += kRowB) {
-        float4 mu[kRowB], rho[kRowB], lam[kRowB];
+        if (INFLOW || g0 > 0) {                                  // (the first batch of a flow-less launch is in flight already)
 #pragma unroll
-        for (int g = 0; g < kRowB; ++g) {
-            const int j = lane + 64 * (g0 + g);
-            if (g0 + g < G && j < iq) { mu[g] = ld4(a.mu + rowoff, j); rho[g] = ld4(a.rho + rowoff, j); lam[g] = ld4(a.lambdal + rowoff, j); }
+            for (int g = 0; g < kRowB; ++g) {
+                const int j = lane + 64 * (g0 + g);
+                if (g0 + g < G && j < iq) { mu[g] = ld4(a.mu + rowoff, j); rho[g] = ld4(a.rho + rowoff, j); lam[g] = ld4(a.lambdal + rowoff, j); }
+            }
         }
 #pragma unroll
         for (int g = 0; g < kRowB; ++g) {
@@ -752,11 +768,14 @@ int launch_weight_pass(const WeightPassArgs* a, int n, hipStream_t s, uint64_t* 
         bt.n = n;
         bt.members = members;
         if (members > 1) for (int i = 0; i < n; ++i) if (bt.f[i].on || a[i].kl_rows || a[i].act_mu) return LBBNN_E_FLAGS;
-        if (any_f16)
-            hipLaunchKernelGGL(weight_rows_kernel<true>, dim3(wgs, 1), dim3(kRowNT), (size_t)3 * maxld * sizeof(float), s, bt);
-        else
-            hipLaunchKernelGGL(weight_rows_kernel<false>, dim3(wgs, members > 1 ? members : 1), dim3(kRowNT),
-                               (size_t)3 * maxld * sizeof(float), s, bt);
+        bool any_flow = false;
+        for (int i = 0; i < n; ++i) any_flow = any_flow || bt.f[i].on;
+        const dim3 grid(wgs, any_f16 ? 1 : (members > 1 ? members : 1));
+        const size_t lds = (size_t)3 * maxld * sizeof(float);
+        if (any_f16 && any_flow)  hipLaunchKernelGGL((weight_rows_kernel<true, true>), grid, dim3(kRowNT), lds, s, bt);
+        else if (any_f16)         hipLaunchKernelGGL((weight_rows_kernel<true, false>), grid, dim3(kRowNT), lds, s, bt);
+        else if (any_flow)        hipLaunchKernelGGL((weight_rows_kernel<false, true>), grid, dim3(kRowNT), lds, s, bt);
+        else                      hipLaunchKernelGGL((weight_rows_kernel<false, false>), grid, dim3(kRowNT), lds, s, bt);
         return (int)hipGetLastError();
     }
     if (members > 1) return LBBNN_E_ALIGN;                  // the member dimension exists in the row kernel only

@@ -60,6 +60,38 @@ def test_weight_pass_vs_oracle(bnn, dev, O, I):
     assert rel_err(bias_var, orc.sigma_of(p["bias_rho"]) ** 2) < TIGHT
 
 
+@pytest.mark.parametrize("O,I", [(64, 1200), (9, 33)])
+def test_weight_pass_wide_parameter_ranges(bnn, dev, O, I):
+    """K1's arithmetic over the ranges TRAINED parameters reach, not only the reference's initial ones (rho in [-5, -4],
+    lambdal in [0, 1]): rho in [-14, 4] crosses both softplus branches (series below exp(rho) = 0.04, log1p above), lambdal
+    in [-14, 14] takes alpha from 1e-6 to 1 - 1e-6, |mu| up to 3.  Every operand ELEMENT within 3e-6 relative of the fp64
+    oracle (the raw hardware exp2 / rcp forms of round 3 are held to the bar of the library forms they replaced), the KL row
+    sums within 1e-5; row kernel (I % 4 == 0) and generic kernel."""
+    ops = bnn.ops
+    g = torch.Generator().manual_seed(O + I)
+    mu = (3 * (2 * torch.rand(O, I, generator=g) - 1)).double()
+    rho = (-14 + 18 * torch.rand(O, I, generator=g)).double()
+    lam = (-14 + 28 * torch.rand(O, I, generator=g)).double()
+    zf = (1 + 0.3 * torch.randn(I, generator=g)).double()
+    zk = (1 + 0.3 * torch.randn(I, generator=g)).double()
+    rc = torch.randn(I, generator=g).double()
+    f = lambda t: t.float().to(dev)
+    ld = ops.operand_ld(I)
+    e_w, var_w = torch.empty(O, ld, device=dev), torch.empty(O, ld, device=dev)
+    kl_rows, act_mu, act_var = (torch.empty(O, device=dev) for _ in range(3))
+    ops.weight_pass(f(mu), f(rho), f(lam), z_fwd=f(zf), z_kl=f(zk), r0_c=f(rc), priors=bnn.Priors(), e_w=e_w, var_w=var_w,
+                    kl_rows=kl_rows, act_mu=act_mu, act_var=act_var)
+    mu, rho, lam, zf, zk, rc = (t.float().double() for t in (mu, rho, lam, zf, zk, rc))      # the fp32 values the kernel saw
+    alpha, sigma = torch.sigmoid(lam), torch.nn.functional.softplus(rho)
+    ref_e, ref_v = mu * alpha * zf, sigma ** 2 * alpha ** 2
+    assert float(((e_w[:, :I].cpu().double() - ref_e).abs() / ref_e.abs().clamp_min(1e-30)).max()) < 3e-6
+    assert float(((var_w[:, :I].cpu().double() - ref_v).abs() / ref_v.abs().clamp_min(1e-30)).max()) < 3e-6
+    ref_rows = orc.kl_weight_elem(mu * zk, sigma, alpha, orc.Priors()).sum(1)
+    assert torch.isfinite(kl_rows).all() and rel_err(kl_rows, ref_rows) < 1e-5
+    assert rel_err(act_mu, rc @ (zk * mu * alpha).T) < 2e-5
+    assert rel_err(act_var, rc ** 2 @ ref_v.T) < 1e-5
+
+
 def test_weight_pass_deterministic(bnn, dev):
     ops = bnn.ops
     g = torch.Generator().manual_seed(5)
