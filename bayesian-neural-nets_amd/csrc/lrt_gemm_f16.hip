@@ -446,19 +446,25 @@ __device__ __forceinline__ void gemm_f16s_body(const G16Args& a) {
     // step's MFMAs, the VALU port being idle four cycles out of five in this loop -- bit-identical outputs, no spills at 8
     // tiles, and 0.1499 ms per forward against 0.1473: a wave issues in order, so the 140 instructions lengthen ITS chain of
     // the step by what the epilogue saves, and the chain of a wave, not the occupancy of a pipe, is what a step costs.)
-    // (Measured and dropped, round 3, after the VALU trims (forward 0.1255 ms): (a) ROLLING FRAGMENT PREFETCH -- the weight
-    // fragments of tile row i re-loaded for step c + 1 right after step c's MFMAs of row i (same registers, order given by
-    // sched_group_barrier; 15 of the 19 ds_reads under the wave's own MFMAs), the LDS-DMA two steps ahead: bit-identical,
-    // 0.1303 ms -- the piece issue then sits between the barrier and the first MFMA instead of under the ds_read latency.
+    // (Measured and dropped, round 3, after the VALU trims (forward 0.1255 ms); all bit-identical.
+    // (a) ROLLING FRAGMENT PREFETCH -- the weight fragments of tile row i re-loaded for step c + 1 right after step c's MFMAs
+    //     of row i (same registers, order given by sched_group_barrier; 15 of the 19 ds_reads under the wave's own MFMAs), the
+    //     LDS-DMA two steps ahead: 0.1303 ms -- the piece issue then sits between the barrier and the first MFMA instead of
+    //     under the ds_read latency; with the issue after the MFMA groups: 0.1318 against 0.1271.
     // (b) STRAIGHT-LINE PIECE ISSUE -- per-piece descriptors / LDS offsets / strides in scalar registers set up once, 8 x
-    // (s_mov m0, s_add, buffer_load lds) per step instead of ~20 scalar branches: 0.1276 ms.  Neither the branches nor the
+    //     (s_mov m0, s_add, buffer_load lds) per step instead of ~20 scalar branches: 0.1276 ms.
     // (a) + (b) with the pieces issued two at a time BETWEEN the MFMA groups: 0.1559 ms -- a wave issues in order, and a
-    // buffer_load ... lds that waits for a slot in the fill queue holds back the MFMAs behind it.  (c) 64 x 80 per wave, two
-    // waves per workgroup, one wave per SIMD with 160 accumulator AGPRs (`<5, 4, 2>`: every weight fragment read by two waves
-    // instead of four, 92 KB of fragment reads per CU-step instead of 152): 0.1699 ms against 0.1271 -- nothing hides a lone
-    // wave's waits.  Neither the branches nor the order is what a step costs: 62 pieces at ~20 cycles each (LDS written at
-    // ~51 B/clk) plus 152 KB of fragment reads at 128 B/clk are 2456 of the 2592 cycles a step takes -- the LDS port is busy
-    // 95 % of the time, the matrix pipe 49 %; the piece issue is cheapest where it is, under the ds_read latency.)
+    //     buffer_load ... lds that waits for a slot in the vector-memory queue holds back the MFMAs behind it.
+    // (c) 64 x 80 per wave, two waves per workgroup, one wave per SIMD with 160 accumulator AGPRs (`<5, 4, 2>`: every weight
+    //     fragment read by two waves instead of four): 0.1699 ms against 0.1271 -- nothing hides a lone wave's waits.
+    // (d) x global -> VGPR from FRAGMENT-ORDERED planes (timing only: every load instruction 1 KiB contiguous, the penalty of
+    //     the row-major form above gone), LDS holding the weights alone: 0.1288 against 0.1289; the same with THREE weight
+    //     buffers and the LDS-DMA two steps ahead (vmcnt-counted barrier): 0.1282 against 0.1279.  Neither the LDS (x no longer
+    //     in it) nor the latency of a piece (a whole extra step of slack) is what a step waits for.
+    // What is left: the CU's ONE vector-memory path takes ~20 cycles per KiB whatever the destination (62 KiB per CU-step =
+    // 1240 cycles), a wave stands still while its pieces / loads queue for it (~100 cycles each with eight waves queueing), and
+    // the 2 x 640 MFMA cycles of a SIMD's two waves fit into what remains of the 2592-cycle step only where the other wave is
+    // not queueing too.  The piece issue is cheapest where it is, under the ds_read latency.)
     // (VERDICT r02 item 6's premise tested, round 3: the second workgroup of every CU (linear id >= 256) delayed by d at its
     // start, so that one workgroup's VALU-bound epilogue falls beside the other's LDS-bound loop: forward 0.1255 ms at
     // d = 0, 0.1271 / 0.1279 / 0.1304 / 0.1322 at d = 0.85 / 1.7 / 3.4 / 5.1 us -- two thirds of every microsecond of skew
