@@ -213,6 +213,7 @@ SIGNATURES = {
     "lbbnn_output_grad_workspace": (c_i64, [c_i, c_i]),
     "lbbnn_output_grad": (c_i, [ctypes.POINTER(OutGradArgs), c_p]),
     "lbbnn_head_dx": (c_i, [c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "lbbnn_head_dw": (c_i, [c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "lbbnn_flow_chain": (c_i, [ctypes.POINTER(FlowChain), c_p, c_p, c_p, c_p, c_p, c_u32, c_i, c_p, c_p, c_p, c_p, c_p]),
     "lbbnn_flow_chain_rows": (c_i, [ctypes.POINTER(FlowChain), c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p]),
     "lbbnn_mnf_aux_backward": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_u32, c_p]),

@@ -186,7 +186,77 @@ __global__ __launch_bounds__(HD_COLS) void head_dx_c_kernel(const float* __restr
     }
 }
 
+// Weight gradients of a <= 16-class head as split-K slabs, without a transposed copy of x:
+//   dWm[s][c][i] = sum_{b in range s} gm[b][c] x[b][i],   dWv[s][c][i] = sum_{b in range s} gv[b][c] x[b][i]^2
+// (d/dW of x.e_w^T and x^2.var_w^T, LBBNN-GP-MF-LRT.py:172-173).  The generic route builds x^T | (x^2)^T as GEMM operands
+// (one pass over x: 13 us for the 4096 x 1200 activation) and runs two K = 4096 launches of the small-tile GEMM whose 16-row
+// tiles are 37 % padding at 10 classes (2 x 9.6 us).  Here a thread owns one column i and a quarter of a row range: x is read
+// once, row-major, coalesced; the gradient rows are wave-uniform (scalar loads, scalar operands); 2 C accumulators per
+// thread; the eight row lanes (waves) of a workgroup are added through LDS in a fixed order.  S slabs for
+// lbbnn_weight_pass_backward to add (fixed order there too): deterministic.  Eight rows' loads in flight per thread and 2.4
+// waves per SIMD: the first version (four row lanes, four rows in flight, 1.2 waves per SIMD) was a chain of exposed load
+// latencies -- 27.9 us for 19.7 MB.
+constexpr int HW_COLS = 64, HW_LANES = 8;
+
+template <int C>
+__global__ __launch_bounds__(HW_COLS * HW_LANES) void head_dw_kernel(const float* __restrict__ gm, const float* __restrict__ gv,
+                                                                     int ldg, const float* __restrict__ x, int ldx,
+                                                                     float* __restrict__ dWm, float* __restrict__ dWv,
+                                                                     int B, int I, int rows_per_slab) {
+    __shared__ float red[HW_LANES][2 * C][HW_COLS];
+    const int cg = threadIdx.x & (HW_COLS - 1);
+    const int rl = __builtin_amdgcn_readfirstlane(threadIdx.x / HW_COLS);              // the wave's index: uniform, and the compiler must know (scalar loads of the gradient rows)
+    const int i = blockIdx.x * HW_COLS + cg, s = blockIdx.y;
+    const int r0 = s * rows_per_slab, r1 = min(r0 + rows_per_slab, B);
+    float am[C], av[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) { am[c] = 0.f; av[c] = 0.f; }
+    if (i < I) {
+#pragma unroll 4
+        for (int b = r0 + rl; b < r1; b += HW_LANES) {
+            const float* __restrict__ pm = gm + (size_t)b * ldg;
+            const float xv = x[(size_t)b * ldx + i], x2 = xv * xv;
+#pragma unroll
+            for (int c = 0; c < C; ++c) am[c] += pm[c] * xv;
+            if (gv) {
+                const float* __restrict__ pv = gv + (size_t)b * ldg;
+#pragma unroll
+                for (int c = 0; c < C; ++c) av[c] += pv[c] * x2;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) { red[rl][c][cg] = am[c]; red[rl][C + c][cg] = av[c]; }
+    __syncthreads();
+    // thread (cg, rl) finishes the values q = rl, rl + 8, ... of column cg: row lanes 0..7 in order
+    if (i < I)
+        for (int q = rl; q < 2 * C; q += HW_LANES) {
+            float v = red[0][q][cg];
+#pragma unroll
+            for (int l = 1; l < HW_LANES; ++l) v += red[l][q][cg];
+            if (q < C) dWm[((size_t)s * C + q) * I + i] = v;
+            else if (dWv) dWv[((size_t)s * C + (q - C)) * I + i] = v;
+        }
+}
+
 }  // namespace
+
+extern "C" int lbbnn_head_dw(const float* gm, const float* gv, int ldg, const float* x, int ldx, float* dWm, float* dWv,
+                             int B, int C, int I, int nslabs, void* stream) {
+    if (!gm || !x || !dWm) return LBBNN_E_NULL;
+    if ((gv == nullptr) != (dWv == nullptr)) return LBBNN_E_NULL;
+    if (B <= 0 || C <= 0 || C > HD_MAXC || I <= 0 || ldg < C || ldx < I || nslabs <= 0 || nslabs > B) return LBBNN_E_SHAPE;
+    const int rows = (B + nslabs - 1) / nslabs;
+    const dim3 grid((I + HW_COLS - 1) / HW_COLS, nslabs), block(HW_COLS * HW_LANES);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define LBBNN_HEAD_DW(CC) case CC: hipLaunchKernelGGL(head_dw_kernel<CC>, grid, block, 0, s, gm, gv, ldg, x, ldx, dWm, dWv, B, I, rows); break;
+    switch (C) {
+        LBBNN_HEAD_DW(1) LBBNN_HEAD_DW(2) LBBNN_HEAD_DW(3) LBBNN_HEAD_DW(4) LBBNN_HEAD_DW(5) LBBNN_HEAD_DW(6) LBBNN_HEAD_DW(7) LBBNN_HEAD_DW(8)
+        LBBNN_HEAD_DW(9) LBBNN_HEAD_DW(10) LBBNN_HEAD_DW(11) LBBNN_HEAD_DW(12) LBBNN_HEAD_DW(13) LBBNN_HEAD_DW(14) LBBNN_HEAD_DW(15) LBBNN_HEAD_DW(16)
+    }
+#undef LBBNN_HEAD_DW
+    return (int)hipGetLastError();
+}
 
 extern "C" int lbbnn_head_dx(const float* gm, const float* gv, int ldg, const float* wmT, const float* wvT, int ldw,
                              const float* x, int ldx, float* out, int ldo, int B, int C, int I, void* stream) {

@@ -50,6 +50,7 @@ _DENSE_DEFER = {"0": False, "always": "always"}.get(_os.environ.get("LBBNN_DENSE
 # 0.1392 ms): no form of the pre-pass beats the in-register split, so the simpler one is the default.
 # LBBNN_HEAD_FOLD=0: keep the 10-class head a GEMM launch of its own (the skinny kernel) in the fused fp16 forward
 _HEAD_FOLD = _os.environ.get("LBBNN_HEAD_FOLD", "1") != "0"
+_HEAD_DW = _os.environ.get("LBBNN_HEAD_DW", "1") != "0"           # the head's weight gradients through lbbnn_head_dw (A/B knob)
 _F16_FIRST_PLANES = _os.environ.get("LBBNN_F16_FIRST", "f32") != "f32"
 _SIDE = {}
 
@@ -308,10 +309,16 @@ class _BayesLinearFn(torch.autograd.Function):
                 gx = _hip_matmul_nt(g, ops.transpose_operand, bw[0][:, :I], module=layer)
                 if stochastic:
                     gx = ops.dx_combine(gx, _hip_matmul_nt(g_v, ops.transpose_operand, bw[1][:, :I], module=layer), x)
-        pair = _x_operand_pair(x, gT, g_vT, layer) if stochastic else None
-        dWm = _hip_matmul_nt(gT, ops.transpose_operand, x, allow_splitk=True, op=pair[0] if pair else None, module=layer)
-        dWv = (_hip_matmul_nt(g_vT, ops.transpose_operand, x, square=True, allow_splitk=True, op=pair[1] if pair else None,
-                              module=layer) if stochastic else None)
+        if (_HEAD_DW and layer.out_features <= 16 and g is not None and (g_v is not None or not stochastic) and x.dim() == 2
+                and x.stride(1) == 1 and x.dtype == torch.float32 and B >= 64):
+            # the <= 16-class head: split-K slabs of both weight gradients straight from the row-major G and x (lbbnn_head_dw) --
+            # no x^T | (x^2)^T operand pass, no 16-row GEMM tiles that are 37 % padding at 10 classes
+            dWm, dWv = ops.head_dw(g, g_v if stochastic else None, x, nslabs=16)
+        else:
+            pair = _x_operand_pair(x, gT, g_vT, layer) if stochastic else None
+            dWm = _hip_matmul_nt(gT, ops.transpose_operand, x, allow_splitk=True, op=pair[0] if pair else None, module=layer)
+            dWv = (_hip_matmul_nt(g_vT, ops.transpose_operand, x, square=True, allow_splitk=True, op=pair[1] if pair else None,
+                                  module=layer) if stochastic else None)
         # ---- K1b: the whole (O,I) chain in one pass
         dmu, drho, dlam, dz_k, dz2, dr0c = ops.weight_pass_backward(
             mu, rho, lam, dWm, dWv, z_fwd=z_k, z_kl=z2, r0_c=r0_c, da_mu=da_mu, da_var=da_var, g_kl=g_kl,

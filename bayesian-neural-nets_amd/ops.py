@@ -248,6 +248,22 @@ def head_dx(gm, gv, wmT, wvT, x, *, C: int, I: int):
     return out
 
 
+
+def head_dw(gm, gv, x, *, nslabs: int = 16):
+    """lbbnn_head_dw: (S, C, I) split-K slabs of dW_m = G_m^T x and dW_v = G_v^T x^2 of a <= 16-class head, from the row-major
+    gradients (B, C) and the row-major layer input (B, I); gv None: (dWm, None)."""
+    B, C = gm.shape
+    I = x.shape[1]
+    S = max(1, min(int(nslabs), B))
+    dWm = torch.empty((S, C, I), dtype=torch.float32, device=gm.device)
+    dWv = torch.empty((S, C, I), dtype=torch.float32, device=gm.device) if gv is not None else None
+    rc = _lib.lib().lbbnn_head_dw(_ptr_rows(gm, "gm"), _ptr_rows(gv, "gv") if gv is not None else None, gm.stride(0),
+                                  _ptr_rows(x, "x"), x.stride(0), dWm.data_ptr(), dWv.data_ptr() if dWv is not None else None,
+                                  B, C, I, S, _stream())
+    _lib.check(rc, "lbbnn_head_dw")
+    return dWm, dWv
+
+
 def matmul_splitk(a, w_op, *, K: int, N: int, kchunk: int):
     """lbbnn_matmul_splitk: slabs out[z] = a[:, Kz] @ w[Kz, :] (w given as its bf16x3 operand [N][ld(K)]);
     returns (S, M, N) with S = ceil(K / kchunk)."""

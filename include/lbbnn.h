@@ -605,6 +605,13 @@ int lbbnn_output_grad(const lbbnn_outgrad_args_t* args, void* stream);    /* gm 
  * (gv == wvT == NULL: the first sum alone).  wmT / wvT: [I][ldw] fp32, the (e_w z)^T / var_w^T operands of lbbnn_weight_operands_t. */
 int lbbnn_head_dx(const float* gm, const float* gv, int ldg, const float* wmT, const float* wvT, int ldw,
                   const float* x, int ldx, float* out, int ldo, int B, int C, int I, void* stream);
+/* Weight gradients of a <= 16-class head as nslabs split-K slabs (lbbnn_weight_pass_backward adds them in order):
+ *   dWm[s][c][i] = sum_{b in slab s} gm[b][c] x[b][i],  dWv[s][c][i] = sum_{b in slab s} gv[b][c] x[b][i]^2   ([nslabs][C][I] fp32 each)
+ * from the row-major gradients (B,C; row stride ldg) and the row-major layer input (B,I; row stride ldx) -- no transposed
+ * operand of x is built (autograd of torch.mm at LBBNN-GP-MF-LRT.py:172-173).  gv == dWv == NULL: the mean product alone.
+ * Slab s covers rows [s r, min((s + 1) r, B)), r = ceil(B / nslabs).  Deterministic (fixed order of every addition). */
+int lbbnn_head_dw(const float* gm, const float* gv, int ldg, const float* x, int ldx, float* dWm, float* dWv,
+                  int B, int C, int I, int nslabs, void* stream);
 /* gx (B,I dense) += 2 * x (B,I; row stride ldx) * gxv (B,I dense): the input gradient of the variance GEMM folded
  * into dX = G_m.W_m + 2 x (.) (G_v.W_v)  (d/dx of (x^2).var_w^T, LBBNN-GP-MF-LRT.py:173). */
 /* out = comb_add + 2 * comb_x (.) (x . w_op^T): the mean-only product of lbbnn_lrt_gemm with lbbnn_dx_combine fused into

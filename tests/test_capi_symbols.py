@@ -153,3 +153,9 @@ def test_round3_entry_points_argument_checks(lib):
                                      None, None, None, None, 4, 2048, 0x80, None) == -2   # rows longer than one register batch
     assert lib.lbbnn_weight_pass_f16(fake, fake, fake, None, None, None, None, ctypes.byref(pr), fake, fake, 64, fake, fake,
                                      None, None, None, None, 4, 64, 0x4, None) == -4      # only LBBNN_F_VAR1 is a flag here
+    # lbbnn_head_dw: NULL / paired-argument / shape checks
+    assert lib.lbbnn_head_dw(None, None, 10, fake, 64, fake, None, 128, 10, 64, 16, None) == -1
+    assert lib.lbbnn_head_dw(fake, fake, 10, fake, 64, fake, None, 128, 10, 64, 16, None) == -1       # gv without dWv
+    assert lib.lbbnn_head_dw(fake, None, 10, fake, 64, fake, None, 128, 17, 64, 16, None) == -2       # more than 16 classes
+    assert lib.lbbnn_head_dw(fake, None, 8, fake, 64, fake, None, 128, 10, 64, 16, None) == -2        # ldg < C
+    assert lib.lbbnn_head_dw(fake, None, 10, fake, 64, fake, None, 8, 10, 64, 16, None) == -2         # more slabs than rows

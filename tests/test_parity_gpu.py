@@ -2597,3 +2597,50 @@ def test_training_forward_fuses_log_softmax_and_sums_kl_on_device(bnn, dev, prec
     assert rel_err(out, out2) < 1e-6 and rel_err(kl, kl2) < 1e-6 and rel_err(loss, loss2) < 1e-6
     for k, p in net.named_parameters():
         assert rel_err(got[k], p.grad) < 2e-5, (k, rel_err(got[k], p.grad))
+
+
+@pytest.mark.parametrize("B,C,I,S,stoch", [(4096, 10, 1200, 16, True), (130, 3, 70, 4, True), (64, 16, 33, 7, False), (257, 1, 64, 3, True)])
+def test_head_dw_slabs_vs_fp64(bnn, dev, B, C, I, S, stoch):
+    """lbbnn_head_dw: the split-K slabs of dW_m = G_m^T x and dW_v = G_v^T x^2 (autograd of the two torch.mm of
+    LBBNN-GP-MF-LRT.py:172-173 for a <= 16-class head) against fp64 -- every slab on its own row range (ragged last slab,
+    columns past a multiple of 64, non-dense row strides), 2e-6 of the slab's max; bitwise reproducible."""
+    ops = bnn.ops
+    g = torch.Generator().manual_seed(B + C + I)
+    gm_full = torch.randn(B, C + 3, generator=g).to(dev)
+    gv_full = torch.randn(B, C + 3, generator=g).to(dev)
+    x_full = torch.randn(B, I + 5, generator=g).to(dev)
+    gm, gv, x = gm_full[:, :C], gv_full[:, :C], x_full[:, :I]
+    dWm, dWv = ops.head_dw(gm, gv if stoch else None, x, nslabs=S)
+    assert dWm.shape == (S, C, I) and (dWv is None) == (not stoch)
+    r = (B + S - 1) // S
+    for s in range(S):
+        lo, hi = s * r, min((s + 1) * r, B)
+        ref_m = gm[lo:hi].double().T @ x[lo:hi].double()
+        assert rel_err(dWm[s], ref_m) < 2e-6
+        if stoch:
+            assert rel_err(dWv[s], gv[lo:hi].double().T @ (x[lo:hi].double() ** 2)) < 2e-6
+    again = ops.head_dw(gm, gv if stoch else None, x, nslabs=S)
+    assert torch.equal(again[0], dWm) and (not stoch or torch.equal(again[1], dWv))
+
+
+def test_head_weight_gradients_same_through_head_dw_and_the_gemm_route(bnn, dev, monkeypatch):
+    """A 784-48-32-10 planar MNF net, one ELBO backward: the head's weight gradients through lbbnn_head_dw against the
+    route it replaces (x^T | (x^2)^T operands + two split-K GEMM launches): every parameter gradient of the net within 2e-5
+    (both are fp32-accumulate sums of the same products in different orders; bf16x3 operands on the GEMM route)."""
+    from bnn_amd import layers
+    grads = {}
+    for mode in (True, False):
+        monkeypatch.setattr(layers, "_HEAD_DW", mode)
+        bnn.manual_seed(5, 0)
+        torch.manual_seed(5)
+        net = bnn.mnf.BayesianNetwork((784, 48, 32, 10), 2, z_flow_type="Planar", r_flow_type="Planar").to(dev).train()
+        xg = torch.Generator().manual_seed(1)
+        x = torch.rand(256, 784, generator=xg).to(dev)
+        y = torch.randint(0, 10, (256,), generator=xg).to(dev)
+        out = net(x, sample=True)
+        loss = torch.nn.functional.nll_loss(out, y, reduction="sum") + net.kl() / 10
+        loss.backward()
+        grads[mode] = {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+        del loss, out
+    for n in grads[True]:
+        assert rel_err(grads[True][n], grads[False][n]) < 2e-5, n
