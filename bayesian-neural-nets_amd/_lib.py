@@ -80,6 +80,12 @@ class GateArgs(ctypes.Structure):
                [(n, c_i) for n in ("O", "I", "ld", "mode", "exact", "want_lp", "flags")] + [("layer_id", c_u32)]
 
 
+class ReduceJob(ctypes.Structure):
+    """lbbnn_reduce_job_t (include/lbbnn.h)."""
+    _fields_ = [("work", c_p), ("out", c_p * 3), ("block_stride", ctypes.c_int64), ("q_stride", ctypes.c_int64),
+                ("nblk", c_i), ("ncols", c_i), ("nq", c_i)]
+
+
 class WpbArgs(ctypes.Structure):
     """lbbnn_wpb_args_t"""
     _fields_ = [(n, c_p) for n in ("mu", "rho", "lambdal", "dWm", "dWv", "z_fwd", "z_kl", "r0_c",
@@ -214,6 +220,7 @@ SIGNATURES = {
     "lbbnn_output_grad": (c_i, [ctypes.POINTER(OutGradArgs), c_p]),
     "lbbnn_head_dx": (c_i, [c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p]),
     "lbbnn_head_dw": (c_i, [c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "lbbnn_reduce_partials_batch": (c_i, [c_p, c_i, c_p]),
     "lbbnn_flow_chain": (c_i, [ctypes.POINTER(FlowChain), c_p, c_p, c_p, c_p, c_p, c_u32, c_i, c_p, c_p, c_p, c_p, c_p]),
     "lbbnn_flow_chain_rows": (c_i, [ctypes.POINTER(FlowChain), c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p]),
     "lbbnn_mnf_aux_backward": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_u32, c_p]),

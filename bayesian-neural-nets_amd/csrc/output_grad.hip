@@ -4,6 +4,7 @@
 // padded LDS tiles, and the tile's column sums as per-tile partials that a second launch adds in a fixed order.
 #include "lbbnn_device.h"
 #include "lbbnn_internal.h"
+#include "reduce_partials.h"
 
 namespace {
 
@@ -93,23 +94,20 @@ __global__ __launch_bounds__(256) void output_grad_kernel(const lbbnn_outgrad_ar
     }
 }
 
-// g_sum[o] = sum over row tiles of the partials; a workgroup owns 64 columns, its 16 waves each add every 16th
-// tile (coalesced 256-B rows), then the 16 partials are added in a fixed order.
+// g_sum[o] = sum over row tiles of the partials (reduce_partials.h: the body shared with lbbnn_reduce_partials_batch)
 __global__ __launch_bounds__(1024) void output_grad_sum_kernel(const float* __restrict__ work, int nbt, int O, float* g_sum, float* gv_sum) {
-    __shared__ float part[2][16][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int o = blockIdx.x * 64 + lane;
-    float s = 0.f, v = 0.f;
-    if (o < O)
-        for (int t = w; t < nbt; t += 16) { s += work[(size_t)t * O + o]; if (gv_sum) v += work[((size_t)nbt + t) * O + o]; }
-    part[0][w][lane] = s; part[1][w][lane] = v;
-    __syncthreads();
-    if (w < 2 && o < O && (w == 0 || gv_sum)) {
-        float t2 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) t2 += part[w][k][lane];
-        (w == 0 ? g_sum : gv_sum)[o] = t2;
-    }
+    __shared__ float part[3][16][64];
+    float* const out[3] = {g_sum, gv_sum, nullptr};
+    reduce_partials_body(work, O, (long long)nbt * O, nbt, O, gv_sum ? 2 : 1, out, blockIdx.x, part);
+}
+
+struct ReduceBatch { lbbnn_reduce_job_t j[LBBNN_MAX_REDUCE_JOBS]; };
+__global__ __launch_bounds__(1024) void reduce_partials_batch_kernel(const ReduceBatch bt) {
+    __shared__ float part[3][16][64];
+    const LBBNN_CONST_AS lbbnn_reduce_job_t& j = kernarg_as<ReduceBatch>()->j[blockIdx.y];
+    if ((int)blockIdx.x * 64 >= j.ncols) return;                      // (uniform per workgroup)
+    float* const out[3] = {j.out[0], j.out[1], j.out[2]};
+    reduce_partials_body(j.work, j.block_stride, j.q_stride, j.nblk, j.ncols, j.nq, out, blockIdx.x, part);
 }
 
 // dX = G_m.W_m + 2 x (.) (G_v.W_v):  gx += 2 * x * gxv   (one pass instead of three elementwise launches)
@@ -281,16 +279,35 @@ extern "C" int64_t lbbnn_output_grad_workspace(int B, int O) {
 extern "C" int lbbnn_output_grad(const lbbnn_outgrad_args_t* p, void* stream) {
     if (!p) return LBBNN_E_NULL;
     const lbbnn_outgrad_args_t& a = *p;
-    if (!a.g_out || !a.gmT || !a.g_sum || !a.work) return LBBNN_E_NULL;
+    if (!a.g_out || !a.gmT || !a.work) return LBBNN_E_NULL;
+    if (!a.g_sum && a.gv_sum) return LBBNN_E_NULL;
     if (a.relu && !a.out) return LBBNN_E_NULL;
-    if (a.std && (!a.gvT || !a.gv_sum || ((a.gm == nullptr) != (a.gv == nullptr)))) return LBBNN_E_NULL;
+    if (a.std && (!a.gvT || (a.g_sum && !a.gv_sum) || ((a.gm == nullptr) != (a.gv == nullptr)))) return LBBNN_E_NULL;
     if (a.std && !a.eps && !a.rng) return LBBNN_E_NOISE;
     if (a.B <= 0 || a.O <= 0 || a.ldg < a.O || ((a.relu || a.std) && a.ldo < a.O)) return LBBNN_E_SHAPE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int nbt = (a.B + TS - 1) / TS;
     hipLaunchKernelGGL(output_grad_kernel, dim3((a.O + TS - 1) / TS, nbt), dim3(256), 0, s, a, nbt);
-    hipLaunchKernelGGL(output_grad_sum_kernel, dim3((a.O + 63) / 64), dim3(1024), 0, s, a.work, nbt, a.O, a.g_sum,
-                       a.std ? a.gv_sum : nullptr);
+    if (a.g_sum)                                            // (else the partials wait in `work` for lbbnn_reduce_partials_batch)
+        hipLaunchKernelGGL(output_grad_sum_kernel, dim3((a.O + 63) / 64), dim3(1024), 0, s, a.work, nbt, a.O, a.g_sum,
+                           a.std ? a.gv_sum : nullptr);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lbbnn_reduce_partials_batch(const lbbnn_reduce_job_t* jobs, int n, void* stream) {
+    if (n == 0) return LBBNN_OK;
+    if (!jobs) return LBBNN_E_NULL;
+    if (n < 0 || n > LBBNN_MAX_REDUCE_JOBS) return LBBNN_E_SHAPE;
+    ReduceBatch bt;
+    int maxcols = 0;
+    for (int k = 0; k < n; ++k) {
+        const lbbnn_reduce_job_t& j = jobs[k];
+        if (!j.work) return LBBNN_E_NULL;
+        if (j.nblk <= 0 || j.ncols <= 0 || j.nq < 1 || j.nq > 3 || j.block_stride < j.ncols || j.q_stride < j.ncols) return LBBNN_E_SHAPE;
+        bt.j[k] = j;
+        maxcols = j.ncols > maxcols ? j.ncols : maxcols;
+    }
+    hipLaunchKernelGGL(reduce_partials_batch_kernel, dim3((maxcols + 63) / 64, n), dim3(1024), 0, static_cast<hipStream_t>(stream), bt);
     return (int)hipGetLastError();
 }
 

@@ -3,6 +3,7 @@
 // i = tid + k*1024 of each vector, so the per-index state in `work` is private to its thread and only the
 // block sums (fixed-order, double accumulation) cross threads.
 #include <cmath>
+#include <cstdlib>
 #include "lbbnn_device.h"
 #include "lbbnn_internal.h"
 
@@ -77,6 +78,7 @@ struct FlowBwdCompact {
     const uint64_t* rng;
     uint32_t layer_id;
     int in_lds;
+    int reg_form;                 // I <= 2 * NT: the register form (one reduction) instead of the LDS chain
 };
 struct FlowBwdBatch { FlowBwdCompact l[LBBNN_MAX_LAYERS]; };
 
@@ -238,6 +240,279 @@ __device__ __forceinline__ void flow_planar_backward_body(const A& a, int in_lds
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 3: the same chain in REGISTERS with ONE reduction (I <= 2 * NT, at most kBatchT transforms per flow).
+//
+// Every vector of the chain above is a combination of a few base vectors with scalar coefficients: zf_t = z0f + Sum_{s<t}
+// thF_s u_s, DK = DK_0 + Sum dinr_s wr_s + dz_kl + Sum dink_s w_s, ...  So every inner product the chain takes (nine block
+// reductions one after the other above, each a round trip through LDS and two barriers) is a combination of inner products of
+// BASE vectors, and those do not depend on the chain:
+//     A_wf[t] = w_t.z0f   A_wk[t] = w_t.z0k   X[a][b] = w_a.u_b   A_rk[t] = wr_t.z0k   C[a][b] = wr_a.u_b   R[a][b] = wr_a.ur_b
+//     Dkl[t] = dz_kl.u_t   Dfw[t] = dz_fwd.u_t   S_e = Sum_i e^{-b2_i m}   S_b = Sum_i b1_i e^{-b2_i m}
+// (Szb = Sum_i (zb - b1_i m) e^{-b2_i m} = zb S_e - m S_b needs no pass of its own).  One pass forms all of them -- float
+// partial sums per thread and wave, the 16 waves combined in double in a fixed order -- wave 0 then walks the scalar chains
+// (forward z on both draws, forward r, backward r, backward z: ~20 tanh / divisions in a row), and every thread writes the
+// gradients of its <= 2 elements from the base vectors it still holds.  Three barriers instead of ~40.
+constexpr int kRT = kBatchT;                      // transforms per flow in this form
+constexpr int kEPT = 2;                           // elements per thread: I <= kEPT * NT
+constexpr int NS_AWF = 0, NS_AWK = NS_AWF + kRT, NS_X = NS_AWK + kRT, NS_ARK = NS_X + kRT * kRT, NS_C = NS_ARK + kRT,
+              NS_R = NS_C + kRT * kRT, NS_DKL = NS_R + kRT * kRT, NS_DFW = NS_DKL + kRT, NS_SE = NS_DFW + kRT, NS_SB = NS_SE + 1,
+              NS_N = NS_SB + 1;                   // 70 sums
+// coefficients wave 0 hands to everyone
+constexpr int NC_THF = 0, NC_THK = NC_THF + kRT, NC_THR = NC_THK + kRT, NC_DINR = NC_THR + kRT, NC_CR = NC_DINR + kRT,
+              NC_DINK = NC_CR + kRT, NC_CK = NC_DINK + kRT, NC_DINF = NC_CK + kRT, NC_ZB = NC_DINF + kRT, NC_SZB = NC_ZB + 1,
+              NC_N = NC_SZB + 1;
+
+template <typename A>
+__device__ __forceinline__ void flow_planar_backward_reg_body(const A& a) {
+    __shared__ float wsum[NS_N][NWV];
+    __shared__ double tot[NS_N];
+    __shared__ float coef[NC_N];
+    __shared__ float lastv[1 + 2 * kRT];          // element I - 1 of z0k, u_s (z flow), ur_s (r flow)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, I = a.I, O = a.O;
+    const int Tz = a.z_flow.T, Tr = a.r_flow.T;
+    const bool has_kl = a.g_kl != nullptr;
+    const float G = has_kl ? a.g_kl[0] : 0.f;
+    const float m = has_kl ? a.aux[0] : 0.f;
+
+    // ---- bias terms (LBBNN-GP-MF-MNF.py:197-198, 234-236): independent of everything below
+    for (int o = tid; o < O; o += NT) {
+        const float er = expf(a.bias_rho[o]);
+        const float sb = log1pf(er), dsig = er / (1.f + er);
+        float gm = a.g_sum[o], gs = a.gv_sum ? a.gv_sum[o] * 2.f * sb : 0.f;
+        if (has_kl) {
+            const float inv = 1.f / (a.priors.bias_sigma_prior * a.priors.bias_sigma_prior);
+            gm += G * (a.bias_mu[o] - a.priors.bias_mu_prior) * inv;
+            gs += G * (sb * inv - 1.f / sb);
+        }
+        a.d_bias_mu[o] = gm;
+        a.d_bias_rho[o] = gs * dsig;
+    }
+
+    // ---- base vectors of this thread's elements
+    uint64_t seed = 0, offs = 0;
+    if (!a.eps_fwd) { seed = a.rng[0]; offs = a.rng[1]; }
+    float sd[kEPT], ef[kEPT], ek[kEPT], z0f[kEPT], z0k[kEPT], dzk[kEPT], dzf[kEPT], b1[kEPT], eb[kEPT];
+    float u[kRT][kEPT], w[kRT][kEPT], ur[kRT][kEPT], wr[kRT][kEPT];
+    float part[NS_N];
+#pragma unroll
+    for (int k = 0; k < NS_N; ++k) part[k] = 0.f;
+#pragma unroll
+    for (int e = 0; e < kEPT; ++e) {
+        const int i = tid + e * NT;
+        const bool in = i < I;
+        sd[e] = ef[e] = ek[e] = z0f[e] = z0k[e] = dzk[e] = dzf[e] = b1[e] = eb[e] = 0.f;
+#pragma unroll
+        for (int t = 0; t < kRT; ++t) { u[t][e] = w[t][e] = ur[t][e] = wr[t][e] = 0.f; }
+        if (in) {
+            if (a.eps_fwd) { ef[e] = a.eps_fwd[i]; if (has_kl) ek[e] = a.eps_kl[i]; }
+            else {
+                float n[4];
+                philox_normal4(seed, offs, LBBNN_STREAM_EPS_Z * 64u + a.layer_id, (uint64_t)(i >> 2), 0u, n); ef[e] = n[i & 3];
+                if (has_kl) { philox_normal4(seed, offs, LBBNN_STREAM_EPS_Z2 * 64u + a.layer_id, (uint64_t)(i >> 2), 0u, n); ek[e] = n[i & 3]; }
+            }
+            const float qm = a.q0_mean[i];
+            sd[e] = expf(0.5f * a.q0_log_var[i]);
+            z0f[e] = qm + sd[e] * ef[e];
+            if (has_kl) z0k[e] = qm + sd[e] * ek[e];
+            dzf[e] = a.dz_fwd ? a.dz_fwd[i] : 0.f;
+            if (has_kl) {
+                dzk[e] = a.dz_kl ? a.dz_kl[i] : 0.f;
+                b1[e] = a.r0_b1[i];
+                eb[e] = expf(-a.r0_b2[i] * m);
+                part[NS_SE] += eb[e];
+                part[NS_SB] += b1[e] * eb[e];
+            }
+#pragma unroll
+            for (int t = 0; t < kRT; ++t) {
+                if (t < Tz) { u[t][e] = a.z_flow.u[t][i]; w[t][e] = a.z_flow.w[t][i]; }
+                if (has_kl && t < Tr) { ur[t][e] = a.r_flow.u[t][i]; wr[t][e] = a.r_flow.w[t][i]; }
+            }
+            if (i == I - 1) {
+                lastv[0] = z0k[e];
+#pragma unroll
+                for (int t = 0; t < kRT; ++t) { lastv[1 + t] = u[t][e]; lastv[1 + kRT + t] = ur[t][e]; }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < kRT; ++t) {
+            part[NS_AWF + t] += w[t][e] * z0f[e];
+            part[NS_AWK + t] += w[t][e] * z0k[e];
+            part[NS_ARK + t] += wr[t][e] * z0k[e];
+            part[NS_DKL + t] += dzk[e] * u[t][e];
+            part[NS_DFW + t] += dzf[e] * u[t][e];
+#pragma unroll
+            for (int b = 0; b < kRT; ++b) {
+                part[NS_X + t * kRT + b] += w[t][e] * u[b][e];
+                part[NS_C + t * kRT + b] += wr[t][e] * u[b][e];
+                part[NS_R + t * kRT + b] += wr[t][e] * ur[b][e];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NS_N; ++k) {
+        const float v = wave_sum(part[k]);
+        if (lane == 0) wsum[k][wv] = v;
+    }
+    __syncthreads();
+    if (tid < NS_N) {
+        double t2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < NWV; ++k) t2 += (double)wsum[tid][k];
+        tot[tid] = t2;
+    }
+    __syncthreads();
+
+    // ---- the scalar chains (flows2.py:87-95 forward, its derivative backward): wave 0, every lane the same values
+    if (wv == 0) {
+        auto S = [&](int k) -> float { return (float)tot[k]; };
+        float thF[kRT], thK[kRT], thR[kRT], dinr[kRT], cr[kRT], dink[kRT], ck[kRT], dinf[kRT];
+#pragma unroll
+        for (int t = 0; t < kRT; ++t) thF[t] = thK[t] = thR[t] = dinr[t] = cr[t] = dink[t] = ck[t] = dinf[t] = 0.f;
+#pragma unroll
+        for (int t = 0; t < kRT; ++t)
+            if (t < Tz) {
+                double inf = tot[NS_AWF + t], ink = tot[NS_AWK + t];
+#pragma unroll
+                for (int s2 = 0; s2 < t; ++s2) { inf += (double)thF[s2] * tot[NS_X + t * kRT + s2]; ink += (double)thK[s2] * tot[NS_X + t * kRT + s2]; }
+                const float b = a.z_flow.b[t][0];
+                thF[t] = tanhf((float)inf + b);
+                if (has_kl) thK[t] = tanhf((float)ink + b);
+            }
+        float zb = 0.f, szb = 0.f;
+        if (has_kl) {
+#pragma unroll
+            for (int t = 0; t < kRT; ++t)
+                if (t < Tr) {
+                    double inr = tot[NS_ARK + t];
+#pragma unroll
+                    for (int s2 = 0; s2 < kRT; ++s2) if (s2 < Tz) inr += (double)thK[s2] * tot[NS_C + t * kRT + s2];
+#pragma unroll
+                    for (int s2 = 0; s2 < t; ++s2) inr += (double)thR[s2] * tot[NS_R + t * kRT + s2];
+                    thR[t] = tanhf((float)inr + a.r_flow.b[t][0]);
+                }
+            zb = lastv[0];
+#pragma unroll
+            for (int t = 0; t < kRT; ++t) { if (t < Tz) zb += lastv[1 + t] * thK[t]; }
+#pragma unroll
+            for (int t = 0; t < kRT; ++t) { if (t < Tr) zb += lastv[1 + kRT + t] * thR[t]; }       // z_b[-1]: last ELEMENT (quirk 2)
+            szb = (float)((double)zb * tot[NS_SE] - (double)m * tot[NS_SB]);
+            const float dk_last = G * szb;                                                      // DK_0 = dk_last e_{I-1}
+            // r flow backward (multiplier on log_det_r is -G)
+#pragma unroll
+            for (int t = kRT - 1; t >= 0; --t)
+                if (t < Tr) {
+                    double d1 = (double)dk_last * (double)lastv[1 + kRT + t];
+#pragma unroll
+                    for (int s2 = t + 1; s2 < kRT; ++s2) if (s2 < Tr) d1 += (double)dinr[s2] * tot[NS_R + s2 * kRT + t];
+                    const float th = thR[t], psi = 1.f - th * th, uw = S(NS_R + t * kRT + t), D = 1.f + psi * uw;
+                    const float dth = (float)d1 + (-G) * (-2.f * th * uw) / D;
+                    dinr[t] = dth * psi;
+                    cr[t] = (-G) * psi / D;
+                }
+            // z flow backward, KL draw
+#pragma unroll
+            for (int t = kRT - 1; t >= 0; --t)
+                if (t < Tz) {
+                    double dk = (double)dk_last * (double)lastv[1 + t] + tot[NS_DKL + t];
+#pragma unroll
+                    for (int s2 = 0; s2 < kRT; ++s2) if (s2 < Tr) dk += (double)dinr[s2] * tot[NS_C + s2 * kRT + t];
+#pragma unroll
+                    for (int s2 = t + 1; s2 < kRT; ++s2) if (s2 < Tz) dk += (double)dink[s2] * tot[NS_X + s2 * kRT + t];
+                    const float uw = S(NS_X + t * kRT + t), tk = thK[t], psik = 1.f - tk * tk, Dk = 1.f + psik * uw;
+                    const float dthk = (float)dk + (-G) * (-2.f * tk * uw) / Dk;
+                    dink[t] = dthk * psik;
+                    ck[t] = (-G) * psik / Dk;
+                }
+        }
+        // z flow backward, forward draw (its log-det is unused)
+#pragma unroll
+        for (int t = kRT - 1; t >= 0; --t)
+            if (t < Tz) {
+                double df = tot[NS_DFW + t];
+#pragma unroll
+                for (int s2 = t + 1; s2 < kRT; ++s2) if (s2 < Tz) df += (double)dinf[s2] * tot[NS_X + s2 * kRT + t];
+                dinf[t] = (float)df * (1.f - thF[t] * thF[t]);
+            }
+        if (lane == 0) {
+#pragma unroll
+            for (int t = 0; t < kRT; ++t) {
+                coef[NC_THF + t] = thF[t]; coef[NC_THK + t] = thK[t]; coef[NC_THR + t] = thR[t]; coef[NC_DINR + t] = dinr[t];
+                coef[NC_CR + t] = cr[t]; coef[NC_DINK + t] = dink[t]; coef[NC_CK + t] = ck[t]; coef[NC_DINF + t] = dinf[t];
+                if (t < Tz) a.d_z_flow.b[t][0] = dink[t] + dinf[t];
+                if (t < Tr) a.d_r_flow.b[t][0] = dinr[t];
+            }
+            coef[NC_ZB] = zb; coef[NC_SZB] = szb;
+        }
+    }
+    __syncthreads();
+
+    // ---- every thread: the gradients of its elements
+    float thF[kRT], thK[kRT], thR[kRT], dinr[kRT], cr[kRT], dink[kRT], ck[kRT], dinf[kRT];
+#pragma unroll
+    for (int t = 0; t < kRT; ++t) {
+        thF[t] = coef[NC_THF + t]; thK[t] = coef[NC_THK + t]; thR[t] = coef[NC_THR + t]; dinr[t] = coef[NC_DINR + t];
+        cr[t] = coef[NC_CR + t]; dink[t] = coef[NC_DINK + t]; ck[t] = coef[NC_CK + t]; dinf[t] = coef[NC_DINF + t];
+    }
+    const float zb = coef[NC_ZB], szb = coef[NC_SZB];
+#pragma unroll
+    for (int e = 0; e < kEPT; ++e) {
+        const int i = tid + e * NT;
+        if (i >= I) continue;
+        float DK = 0.f;
+        if (has_kl) {
+            const float dlt = zb - b1[e] * m;
+            a.d_r0_b1[i] = -G * dlt * m * eb[e];
+            a.d_r0_b2[i] = -G * (-0.5f * m + 0.5f * dlt * dlt * m * eb[e]);
+            DK = (i == I - 1) ? G * szb : 0.f;
+            // r_t[i] = z2[i] + Sum_{s<t} thR_s ur_s[i],  z2 = z0k + Sum_s thK_s u_s
+            float z2 = z0k[e];
+#pragma unroll
+            for (int t = 0; t < kRT; ++t) z2 += u[t][e] * thK[t];                  // (u_t = 0, thK_t = 0 beyond Tz)
+            float rt[kRT];
+            {
+                float r = z2;
+#pragma unroll
+                for (int t = 0; t < kRT; ++t) { rt[t] = r; r += ur[t][e] * thR[t]; }
+            }
+#pragma unroll
+            for (int t = kRT - 1; t >= 0; --t)
+                if (t < Tr) {
+                    a.d_r_flow.u[t][i] = DK * thR[t] + cr[t] * wr[t][e];
+                    a.d_r_flow.w[t][i] = dinr[t] * rt[t] + cr[t] * ur[t][e];
+                    DK += dinr[t] * wr[t][e];
+                }
+            DK += dzk[e];
+        } else {
+            a.d_r0_b1[i] = 0.f; a.d_r0_b2[i] = 0.f;
+#pragma unroll
+            for (int t = 0; t < kRT; ++t) if (t < Tr) { a.d_r_flow.u[t][i] = 0.f; a.d_r_flow.w[t][i] = 0.f; }
+        }
+        float DF = dzf[e];
+        float zft[kRT], zkt[kRT];
+        {
+            float f = z0f[e], k2 = z0k[e];
+#pragma unroll
+            for (int t = 0; t < kRT; ++t) { zft[t] = f; zkt[t] = k2; f += u[t][e] * thF[t]; k2 += u[t][e] * thK[t]; }
+        }
+#pragma unroll
+        for (int t = kRT - 1; t >= 0; --t)
+            if (t < Tz) {
+                a.d_z_flow.u[t][i] = DK * thK[t] + ck[t] * w[t][e] + DF * thF[t];
+                a.d_z_flow.w[t][i] = dink[t] * (has_kl ? zkt[t] : 0.f) + ck[t] * u[t][e] + dinf[t] * zft[t];
+                DK += dink[t] * w[t][e];
+                DF += dinf[t] * w[t][e];
+            }
+        // q0 (LBBNN-GP-MF-MNF.py:183-185, 201-205): dlog_q0/dlog_var = -1/2 exactly, dlog_q0/dmean = 0
+        a.d_q0_mean[i] = DK + DF;
+        a.d_q0_log_var[i] = 0.5f * sd[e] * (DK * ek[e] + DF * ef[e]) - 0.5f * G;
+    }
+    if (!has_kl && tid == 0) {
+#pragma unroll
+        for (int t = 0; t < kRT; ++t) if (t < Tr) a.d_r_flow.b[t][0] = 0.f;
+    }
+}
+
 __global__ __launch_bounds__(NT) void mnf_flow_planar_backward_kernel(const lbbnn_flow_bwd_args_t a, int in_lds) {
     extern __shared__ __attribute__((aligned(16))) float dyn[];
     flow_planar_backward_body(a, in_lds, dyn);
@@ -246,7 +521,8 @@ __global__ __launch_bounds__(NT) void mnf_flow_planar_backward_kernel(const lbbn
 __global__ __launch_bounds__(NT) void mnf_flow_planar_backward_batch_kernel(const FlowBwdBatch bt) {
     extern __shared__ __attribute__((aligned(16))) float dyn[];
     const LBBNN_CONST_AS FlowBwdCompact& a = kernarg_as<FlowBwdBatch>()->l[blockIdx.x];
-    flow_planar_backward_body(a, a.in_lds, dyn);
+    if (a.reg_form) flow_planar_backward_reg_body(a);                  // (uniform per workgroup)
+    else flow_planar_backward_body(a, a.in_lds, dyn);
 }
 
 }  // namespace
@@ -267,6 +543,8 @@ extern "C" int64_t lbbnn_mnf_flow_backward_workspace(int I, int Tz, int Tr) {
     return (int64_t)I * (2 * (Tz + 1) + Tr + 4);
 }
 
+extern "C" int lbbnn_mnf_flow_planar_backward_batch(const lbbnn_flow_bwd_args_t* args, int n, void* stream);
+
 extern "C" int lbbnn_mnf_flow_planar_backward(const lbbnn_flow_bwd_args_t* p, void* stream) {
     if (!p) return LBBNN_E_NULL;
     const lbbnn_flow_bwd_args_t& a = *p;
@@ -280,6 +558,9 @@ extern "C" int lbbnn_mnf_flow_planar_backward(const lbbnn_flow_bwd_args_t* p, vo
         if (!a.z_flow.u[t] || !a.z_flow.w[t] || !a.z_flow.b[t] || !a.d_z_flow.u[t] || !a.d_z_flow.w[t] || !a.d_z_flow.b[t]) return LBBNN_E_NULL;
     for (int t = 0; t < a.r_flow.T; ++t)
         if (!a.r_flow.u[t] || !a.r_flow.w[t] || !a.r_flow.b[t] || !a.d_r_flow.u[t] || !a.d_r_flow.w[t] || !a.d_r_flow.b[t]) return LBBNN_E_NULL;
+    // the register form lives in the batch kernel: a chain it admits takes that kernel with n = 1, so that a layer's
+    // gradients do not depend on whether its chain was deferred and batched (bitwise)
+    if (a.I <= 2 * NT && a.z_flow.T <= kBatchT && a.r_flow.T <= kBatchT) return lbbnn_mnf_flow_planar_backward_batch(p, 1, stream);
     const size_t bytes = (size_t)lbbnn_mnf_flow_backward_workspace(a.I, a.z_flow.T, a.r_flow.T) * sizeof(float);
     const int in_lds = bytes <= 144 * 1024 ? 1 : 0;
     static size_t raised = 0;
@@ -331,7 +612,9 @@ extern "C" int lbbnn_mnf_flow_planar_backward_batch(const lbbnn_flow_bwd_args_t*
         c.rng = a.rng; c.layer_id = a.layer_id;
         const size_t bytes = (size_t)lbbnn_mnf_flow_backward_workspace(a.I, a.z_flow.T, a.r_flow.T) * sizeof(float);
         c.in_lds = bytes <= 144 * 1024 ? 1 : 0;
-        if (c.in_lds && bytes > dyn_bytes) dyn_bytes = bytes;
+        static const bool reg_off = getenv("LBBNN_V2_REG") && getenv("LBBNN_V2_REG")[0] == '0';      // A/B knob
+        c.reg_form = (!reg_off && a.I <= 2 * NT) ? 1 : 0;
+        if (!c.reg_form && c.in_lds && bytes > dyn_bytes) dyn_bytes = bytes;
     }
     static size_t raised = 0;
     if (dyn_bytes > 64 * 1024 && dyn_bytes > raised) {

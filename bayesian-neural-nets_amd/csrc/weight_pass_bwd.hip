@@ -6,6 +6,7 @@
 #include <cmath>
 #include "lbbnn_device.h"
 #include "lbbnn_internal.h"
+#include "reduce_partials.h"
 
 namespace {
 
@@ -175,28 +176,13 @@ __global__ __launch_bounds__(256) void weight_pass_bwd_kernel(const lbbnn_wpb_ar
     }
 }
 
-// column sums: out[q][i] = sum over row blocks of work[b][q][i].  A workgroup owns 64 columns; its 16 waves
-// each sum every 16th row block (coalesced 256-B rows), then one wave adds the 16 partials in a fixed order.
+// column sums: out[q][i] = sum over row blocks of work[b][q][i] (reduce_partials.h: the body shared with
+// lbbnn_reduce_partials_batch)
 __global__ __launch_bounds__(1024) void wpb_reduce_kernel(const float* __restrict__ work, int nblk, int ldw, int I,
                                                           float* dz_fwd, float* dz_kl, float* dr0_c) {
     __shared__ float part[3][16][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + lane;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    if (i < I)
-        for (int b = w; b < nblk; b += 16) {
-            const float* p = work + (size_t)b * 3 * ldw;
-            s0 += p[i]; s1 += p[ldw + i]; s2 += p[2 * ldw + i];
-        }
-    part[0][w][lane] = s0; part[1][w][lane] = s1; part[2][w][lane] = s2;
-    __syncthreads();
-    if (w < 3 && i < I) {
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) s += part[w][k][lane];
-        float* out = w == 0 ? dz_fwd : (w == 1 ? dz_kl : dr0_c);
-        if (out) out[i] = s;
-    }
+    float* const out[3] = {dz_fwd, dz_kl, dr0_c};
+    reduce_partials_body(work, 3LL * ldw, ldw, nblk, I, 3, out, blockIdx.x, part);
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

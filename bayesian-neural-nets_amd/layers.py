@@ -50,6 +50,7 @@ _DENSE_DEFER = {"0": False, "always": "always"}.get(_os.environ.get("LBBNN_DENSE
 # 0.1392 ms): no form of the pre-pass beats the in-register split, so the simpler one is the default.
 # LBBNN_HEAD_FOLD=0: keep the 10-class head a GEMM launch of its own (the skinny kernel) in the fused fp16 forward
 _HEAD_FOLD = _os.environ.get("LBBNN_HEAD_FOLD", "1") != "0"
+_DEFER_SUMS = _os.environ.get("LBBNN_DEFER_SUMS", "1") != "0"      # column sums finished with the deferred vector chains (A/B knob)
 _HEAD_DW = _os.environ.get("LBBNN_HEAD_DW", "1") != "0"           # the head's weight gradients through lbbnn_head_dw (A/B knob)
 _F16_FIRST_PLANES = _os.environ.get("LBBNN_F16_FIRST", "f32") != "f32"
 _SIDE = {}
@@ -71,11 +72,11 @@ def _side_stream(dev):
 # (lbbnn_mnf_flow_dense_backward_batch) instead of one per layer.  OFF unless a caller that also FLUSHES before the
 # optimizer step turns it on (graphs.make_graphed_train_step, or `with layers.vector_backward_overlap(): loss.backward()`):
 # the gradients such a backward returns are only complete after join_vector_backward().
-_OVERLAP = {"on": False, "planar": [], "dense": [], "adopt": []}
+_OVERLAP = {"on": False, "planar": [], "dense": [], "adopt": [], "sums": []}
 
 
 def _drop_deferred():
-    for k in ("planar", "dense", "adopt"):
+    for k in ("planar", "dense", "adopt", "sums"):
         _OVERLAP[k].clear()
 
 
@@ -94,6 +95,9 @@ def join_vector_backward():
                            "pass ran under conditions vector_backward_overlap does not support; nothing was launched, "
                            "the gradients of this step are incomplete" % ", ".join(bad[:3]))
     _OVERLAP["adopt"].clear()
+    # the second level of the layers' column sums (Sum_b G, dz_k, dz_2, dr0_c) first: the chains below read them
+    if _OVERLAP["sums"]:
+        ops.reduce_partials_flush(_OVERLAP["sums"])
     if _OVERLAP["planar"]:
         ops.mnf_flow_planar_backward_flush(_OVERLAP["planar"])
     if _OVERLAP["dense"]:
@@ -235,12 +239,16 @@ class _BayesLinearFn(torch.autograd.Function):
         explicit = ctx.saved.get("noise") or {}
         if ctx.saved.get("lsm"):
             g_out = ops.log_softmax_backward(g_out, out)              # grad wrt log-probabilities -> grad wrt the logits
+        planar = layer._mnf and layer._check_flows() == "planar"
+        dense = layer._mnf and ctx.saved.get("dense_save") is not None
+        # With the vector chains deferred (they are the only readers of the column sums Sum_b G_m / G_v, dz_k, dz_2, dr0_c)
+        # the second level of those sums is deferred with them: one lbbnn_reduce_partials_batch launch for all layers
+        # instead of two ~5 us launches per layer
+        defer_sums = _OVERLAP["sums"] if (can_defer and (planar or dense) and _DEFER_SUMS) else None
         g, g_v, gT, g_vT, g_sum, gv_sum = ops.output_grad(
             g_out, out=out if relu else None, std=std if stochastic else None, eps=explicit.get("eps_out"),
             rng=ctx.saved.get("rng"), rng_stream=ops.STREAM_EPS_OUT * 64 + layer._layer_id, row_offset=layer.row_offset,
-            relu=relu, want_g=bool(ctx.needs_input_grad[1]))
-        planar = layer._mnf and layer._check_flows() == "planar"
-        dense = layer._mnf and ctx.saved.get("dense_save") is not None
+            relu=relu, want_g=bool(ctx.needs_input_grad[1]), defer_sums=defer_sums)
         # planar / dense MNF layers re-create their small draws inside V1 / V2; the torch-graph paths need them as tensors
         rng_snap = ctx.saved.get("rng")
         in_kernel = (planar or dense) and not explicit and rng_snap is not None
@@ -313,7 +321,11 @@ class _BayesLinearFn(torch.autograd.Function):
                 and x.stride(1) == 1 and x.dtype == torch.float32 and B >= 64):
             # the <= 16-class head: split-K slabs of both weight gradients straight from the row-major G and x (lbbnn_head_dw) --
             # no x^T | (x^2)^T operand pass, no 16-row GEMM tiles that are 37 % padding at 10 classes
-            dWm, dWv = ops.head_dw(g, g_v if stochastic else None, x, nslabs=16)
+            # (K1b adds slabs whose stride O * I is a multiple of 4 floats; other shapes get one slab)
+            dWm, dWv = ops.head_dw(g, g_v if stochastic else None, x,
+                                   nslabs=16 if (layer.out_features * layer.in_features) % 4 == 0 else 1)
+            if dWm.shape[0] == 1:
+                dWm, dWv = dWm[0], (dWv[0] if dWv is not None else None)
         else:
             pair = _x_operand_pair(x, gT, g_vT, layer) if stochastic else None
             dWm = _hip_matmul_nt(gT, ops.transpose_operand, x, allow_splitk=True, op=pair[0] if pair else None, module=layer)
@@ -322,7 +334,7 @@ class _BayesLinearFn(torch.autograd.Function):
         # ---- K1b: the whole (O,I) chain in one pass
         dmu, drho, dlam, dz_k, dz2, dr0c = ops.weight_pass_backward(
             mu, rho, lam, dWm, dWv, z_fwd=z_k, z_kl=z2, r0_c=r0_c, da_mu=da_mu, da_var=da_var, g_kl=g_kl,
-            priors=layer.priors)
+            priors=layer.priors, defer_sums=defer_sums)
         if planar:
             zp, rp = layer._planar_params_from(params)
             e1 = None if in_kernel else noise["eps_z"].contiguous()

@@ -199,9 +199,11 @@ def weight_pass(mu, rho, lambdal, *, z_fwd=None, z_kl=None, r0_c=None, bias_rho=
 
 
 def output_grad(g_out, *, out=None, std=None, eps=None, rng=None, rng_stream: int = 0, row_offset: int = 0,
-                relu: bool = False, gv_scale=None, want_g: bool = True):
+                relu: bool = False, gv_scale=None, want_g: bool = True, defer_sums=None):
     """lbbnn_output_grad.  Returns (gm, gv, gmT, gvT, g_sum, gv_sum); the gv* are None for a posterior-mean forward.
-    gv_scale (O,): per-column factor on G_v (the variational-dropout alpha)."""
+    gv_scale (O,): per-column factor on G_v (the variational-dropout alpha).
+    defer_sums: a list -- the column-sum partials stay in the workspace and a job for reduce_partials_flush is appended to
+    it; g_sum / gv_sum are returned as (still unwritten) tensors that the flush fills."""
     B, O = g_out.shape
     f = dict(dtype=torch.float32, device=g_out.device)
     if g_out.stride(1) != 1:
@@ -227,9 +229,15 @@ def output_grad(g_out, *, out=None, std=None, eps=None, rng=None, rng_stream: in
     a.eps = _ptr(eps, "eps") if (stoch and eps is not None) else None
     a.rng = rng.data_ptr() if rng is not None else None
     work = torch.empty(_lib.lib().lbbnn_output_grad_workspace(B, O), **f)
-    a.gm, a.gmT, a.g_sum, a.work = (gm.data_ptr() if gm is not None else None), gmT.data_ptr(), g_sum.data_ptr(), work.data_ptr()
+    a.gm, a.gmT, a.work = (gm.data_ptr() if gm is not None else None), gmT.data_ptr(), work.data_ptr()
+    a.g_sum = g_sum.data_ptr() if defer_sums is None else None
     if stoch:
-        a.gv, a.gvT, a.gv_sum = (gv.data_ptr() if gv is not None else None), gvT.data_ptr(), gv_sum.data_ptr()
+        a.gv, a.gvT = (gv.data_ptr() if gv is not None else None), gvT.data_ptr()
+        a.gv_sum = gv_sum.data_ptr() if defer_sums is None else None
+    if defer_sums is not None:
+        nbt = (B + 63) // 64
+        defer_sums.append(dict(work=work, outs=(g_sum, gv_sum, None), block_stride=O, q_stride=nbt * O, nblk=nbt, ncols=O,
+                               nq=2 if stoch else 1))
     a.row_offset, a.rng_stream = row_offset, rng_stream
     a.gv_scale = _ptr(gv_scale, "gv_scale") if (stoch and gv_scale is not None) else None
     a.B, a.O, a.ldg, a.ldo, a.relu = B, O, g_out.stride(0), ldo, 1 if relu else 0
@@ -285,9 +293,10 @@ def dx_combine(gx, gxv, x):
 
 
 def weight_pass_backward(mu, rho, lambdal, dWm, dWv=None, *, z_fwd=None, z_kl=None, r0_c=None, da_mu=None,
-                         da_var=None, g_kl=None, priors: Priors, work: Optional[torch.Tensor] = None):
+                         da_var=None, g_kl=None, priors: Priors, work: Optional[torch.Tensor] = None, defer_sums=None):
     """lbbnn_weight_pass_backward (K1b).  Returns (dmu, drho, dlambdal, dz_fwd, dz_kl, dr0_c); the three
-    vector gradients are None when the corresponding input vector was not given."""
+    vector gradients are None when the corresponding input vector was not given.
+    defer_sums: a list -- as in output_grad: the three column sums are finished by reduce_partials_flush."""
     O, I = mu.shape
     a = _lib.WpbArgs()
     a.mu, a.rho, a.lambdal = _ptr(mu, "weight_mu"), _ptr(rho, "weight_rho"), _ptr(lambdal, "lambdal")
@@ -309,11 +318,37 @@ def weight_pass_backward(mu, rho, lambdal, dWm, dWv=None, *, z_fwd=None, z_kl=No
     if work is None or work.numel() < need:
         work = torch.empty(need, **f)
     a.dmu, a.drho, a.dlambdal = dmu.data_ptr(), drho.data_ptr(), dlam.data_ptr()
-    a.dz_fwd, a.dz_kl, a.dr0_c, a.work = _ptr(dz_fwd), _ptr(dz_kl), _ptr(dr0_c), work.data_ptr()
+    deferred = defer_sums is not None and (dz_fwd is not None or dz_kl is not None or dr0_c is not None)
+    a.work = work.data_ptr()
+    a.dz_fwd, a.dz_kl, a.dr0_c = (None, None, None) if deferred else (_ptr(dz_fwd), _ptr(dz_kl), _ptr(dr0_c))
     a.O, a.I = O, I
     a.nsplit, a.split_stride = nsplit, O * I
     _lib.check(_lib.lib().lbbnn_weight_pass_backward(ctypes.byref(a), _stream()), "lbbnn_weight_pass_backward")
+    if deferred:
+        ld = (I + 3) & ~3
+        # dr0_c is RETURNED as a parameter gradient: autograd adopts it as .grad only while nobody else holds a reference
+        # (layers.join_vector_backward checks the adoption), so the job keeps its address, not the tensor
+        defer_sums.append(dict(work=work, outs=(dz_fwd, dz_kl, None), ptrs=(_ptr(dz_fwd), _ptr(dz_kl), _ptr(dr0_c)),
+                               block_stride=3 * ld, q_stride=ld, nblk=(O + 7) // 8, ncols=I, nq=3))
     return dmu, drho, dlam, dz_fwd, dz_kl, dr0_c
+
+
+def reduce_partials_flush(pending):
+    """lbbnn_reduce_partials_batch: finish the column sums that output_grad / weight_pass_backward left as partials
+    (``defer_sums``), up to 8 jobs per launch, in filing order; clears the list."""
+    i = 0
+    while i < len(pending):
+        grp = pending[i:i + 8]
+        arr = (_lib.ReduceJob * len(grp))()
+        for k, j in enumerate(grp):
+            arr[k].work = j["work"].data_ptr()
+            for q in range(3):
+                arr[k].out[q] = j["ptrs"][q] if "ptrs" in j else (j["outs"][q].data_ptr() if j["outs"][q] is not None else None)
+            arr[k].block_stride, arr[k].q_stride = j["block_stride"], j["q_stride"]
+            arr[k].nblk, arr[k].ncols, arr[k].nq = j["nblk"], j["ncols"], j["nq"]
+        _lib.check(_lib.lib().lbbnn_reduce_partials_batch(arr, len(grp), _stream()), "lbbnn_reduce_partials_batch")
+        i += 8
+    pending.clear()
 
 
 # ----------------------------------------------------------------------------------------- K2

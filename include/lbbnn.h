@@ -600,7 +600,26 @@ typedef struct lbbnn_outgrad_args {
 } lbbnn_outgrad_args_t;
 
 int64_t lbbnn_output_grad_workspace(int B, int O);
-int lbbnn_output_grad(const lbbnn_outgrad_args_t* args, void* stream);    /* gm == gv == NULL: only the transposes and the sums */
+int lbbnn_output_grad(const lbbnn_outgrad_args_t* args, void* stream);    /* gm == gv == NULL: only the transposes and the sums;
+                                                                             g_sum == gv_sum == NULL: the column-sum partials
+                                                                             stay in `work` for lbbnn_reduce_partials_batch   */
+/* The second level of the two-level column sums of lbbnn_output_grad (Sum_b G_m, Sum_b G_v) and lbbnn_weight_pass_backward
+ * (dz_fwd, dz_kl, dr0_c) for SEVERAL layers in one launch: both kernels leave per-row-block partial vectors in their `work`
+ * arrays and normally finish them with a launch of their own (six ~5 us launches per training step of a three-layer net);
+ * their results are read by the vector-sized backward chains only, so a caller that defers those chains can defer the sums
+ * too.  Job: out[q][i] = Sum_b work[b * block_stride + q * q_stride + i], q < nq <= 3, i < ncols, b < nblk, in the order
+ * the stand-alone launches use (16 interleaved partial sums over b, added in order): bit-identical results.
+ *   lbbnn_output_grad(B, O):              nblk = ceil(B / 64), ncols = O, block_stride = O, q_stride = nblk * O, nq = 1 or 2
+ *   lbbnn_weight_pass_backward(O, I):     nblk = ceil(O / 8), ncols = I, ld = (I + 3) & ~3, block_stride = 3 ld, q_stride = ld, nq = 3
+ * A NULL out[q] skips that vector.  At most LBBNN_MAX_REDUCE_JOBS jobs per call. */
+#define LBBNN_MAX_REDUCE_JOBS 8
+typedef struct {
+    const float* work;
+    float* out[3];
+    int64_t block_stride, q_stride;
+    int nblk, ncols, nq;
+} lbbnn_reduce_job_t;
+int lbbnn_reduce_partials_batch(const lbbnn_reduce_job_t* jobs, int n, void* stream);
 /* Input gradient of a <= 16-class head in ONE launch: out[b][i] = sum_c gm[b][c] wmT[i][c] + 2 x[b][i] sum_c gv[b][c] wvT[i][c]
  * (gv == wvT == NULL: the first sum alone).  wmT / wvT: [I][ldw] fp32, the (e_w z)^T / var_w^T operands of lbbnn_weight_operands_t. */
 int lbbnn_head_dx(const float* gm, const float* gv, int ldg, const float* wmT, const float* wvT, int ldw,

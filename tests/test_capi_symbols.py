@@ -76,7 +76,8 @@ def test_ctypes_struct_layouts_match_the_header(tmp_path):
              ("lbbnn_dense_layer_t", _lib.DenseLayer, "draw_masks"), ("lbbnn_dense_grad_t", _lib.DenseGrad, "b_b"),
              ("lbbnn_outgrad_args_t", _lib.OutGradArgs, "relu"), ("lbbnn_flow_step_t", _lib.FlowStep, "M"),
              ("lbbnn_flow_chain_t", _lib.FlowChain, "n"), ("lbbnn_planar_grad_t", _lib.PlanarGrad, "b"),
-             ("lbbnn_flow_bwd_args_t", _lib.FlowBwdArgs, "layer_id"), ("lbbnn_dense_bwd_args_t", _lib.DenseBwdArgs, "layer_id")]
+             ("lbbnn_flow_bwd_args_t", _lib.FlowBwdArgs, "layer_id"), ("lbbnn_dense_bwd_args_t", _lib.DenseBwdArgs, "layer_id"),
+             ("lbbnn_reduce_job_t", _lib.ReduceJob, "nq")]
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "%s"' % os.path.join(ROOT, "include", "lbbnn.h"), "int main(void) {"]
     for cname, _, last in pairs:
         lines.append('printf("%s %%zu %%zu\\n", sizeof(%s), %s);' % (cname, cname, "offsetof(%s, %s)" % (cname, last) if last else "(size_t)0"))
@@ -159,3 +160,12 @@ def test_round3_entry_points_argument_checks(lib):
     assert lib.lbbnn_head_dw(fake, None, 10, fake, 64, fake, None, 128, 17, 64, 16, None) == -2       # more than 16 classes
     assert lib.lbbnn_head_dw(fake, None, 8, fake, 64, fake, None, 128, 10, 64, 16, None) == -2        # ldg < C
     assert lib.lbbnn_head_dw(fake, None, 10, fake, 64, fake, None, 8, 10, 64, 16, None) == -2         # more slabs than rows
+    # lbbnn_reduce_partials_batch
+    assert lib.lbbnn_reduce_partials_batch(None, 0, None) == 0
+    assert lib.lbbnn_reduce_partials_batch(None, 1, None) == -1
+    jobs = (_lib.ReduceJob * 9)()
+    assert lib.lbbnn_reduce_partials_batch(jobs, 9, None) == -2                # more than LBBNN_MAX_REDUCE_JOBS
+    assert lib.lbbnn_reduce_partials_batch(jobs, 1, None) == -1                # no workspace
+    jobs[0].work, jobs[0].nblk, jobs[0].ncols, jobs[0].nq = 4096, 4, 64, 4
+    jobs[0].block_stride = jobs[0].q_stride = 64
+    assert lib.lbbnn_reduce_partials_batch(jobs, 1, None) == -2                # nq > 3

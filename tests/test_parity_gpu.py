@@ -2644,3 +2644,67 @@ def test_head_weight_gradients_same_through_head_dw_and_the_gemm_route(bnn, dev,
         del loss, out
     for n in grads[True]:
         assert rel_err(grads[True][n], grads[False][n]) < 2e-5, n
+
+
+def test_deferred_column_sums_are_bitwise_the_stand_alone_ones(bnn, dev):
+    """lbbnn_reduce_partials_batch: the second level of lbbnn_output_grad's and lbbnn_weight_pass_backward's column sums for
+    several layers in one launch == the launches those entry points make themselves, bit for bit (one shared device body);
+    ragged shapes, a posterior-mean (one-vector) job, NULL outputs, more than one launch group."""
+    ops = bnn.ops
+    g = torch.Generator().manual_seed(3)
+    jobs, want = [], []
+    for (B, O) in [(4096, 1200), (130, 70), (64, 10)]:
+        gout = torch.randn(B, O, generator=g).to(dev)
+        out = torch.randn(B, O, generator=g).to(dev)
+        std = (0.1 + torch.rand(B, O, generator=g)).to(dev)
+        eps = torch.randn(B, O, generator=g).to(dev)
+        for stoch in (True, False):
+            kw = dict(out=out, std=std if stoch else None, eps=eps if stoch else None, relu=True)
+            ref = ops.output_grad(gout, **kw)
+            got = ops.output_grad(gout, defer_sums=jobs, **kw)
+            want.append((ref[4], got[4])); want.append((ref[5], got[5]))
+    for (O, I) in [(1200, 784), (10, 1200), (33, 68)]:
+        mu = (0.1 * torch.randn(O, I, generator=g)).to(dev)
+        rho = (-4.5 + 0.3 * torch.randn(O, I, generator=g)).to(dev)
+        lam = torch.randn(O, I, generator=g).to(dev)
+        dWm, dWv = torch.randn(O, I, generator=g).to(dev), torch.randn(O, I, generator=g).to(dev)
+        zf, zk, rc = ((1 + 0.1 * torch.randn(I, generator=g)).to(dev) for _ in range(3))
+        dam, dav = torch.randn(O, generator=g).to(dev), torch.randn(O, generator=g).to(dev)
+        gk = torch.tensor(0.7, device=dev)
+        kw = dict(z_fwd=zf, z_kl=zk, r0_c=rc, da_mu=dam, da_var=dav, g_kl=gk, priors=bnn.Priors())
+        ref = ops.weight_pass_backward(mu, rho, lam, dWm, dWv, **kw)
+        got = ops.weight_pass_backward(mu, rho, lam, dWm, dWv, defer_sums=jobs, **kw)
+        for k in range(3):
+            assert torch.equal(ref[k], got[k])
+        want += [(ref[3], got[3]), (ref[4], got[4]), (ref[5], got[5])]
+    assert len(jobs) == 9                                   # two launch groups (8 + 1)
+    ops.reduce_partials_flush(jobs)
+    assert not jobs
+    torch.cuda.synchronize()
+    for r, t in want:
+        assert (r is None) == (t is None)
+        if r is not None:
+            assert torch.equal(r, t)
+
+
+def test_training_step_same_with_and_without_deferred_column_sums(bnn, dev, monkeypatch):
+    """One ELBO backward of a 784-48-32-10 planar MNF net inside vector_backward_overlap: every parameter gradient bitwise
+    the same whether the layers' column sums are finished by their own launches or by the one batched launch at the end."""
+    from bnn_amd import layers
+    grads = {}
+    for mode in (True, False):
+        monkeypatch.setattr(layers, "_DEFER_SUMS", mode)
+        bnn.manual_seed(5, 0)
+        torch.manual_seed(5)
+        net = bnn.mnf.BayesianNetwork((784, 48, 32, 10), 2, z_flow_type="Planar", r_flow_type="Planar").to(dev).train()
+        xg = torch.Generator().manual_seed(1)
+        x = torch.rand(256, 784, generator=xg).to(dev)
+        y = torch.randint(0, 10, (256,), generator=xg).to(dev)
+        out = net(x, sample=True)
+        loss = torch.nn.functional.nll_loss(out, y, reduction="sum") + net.kl() / 10
+        with layers.vector_backward_overlap():
+            loss.backward()
+        grads[mode] = {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+        del loss, out
+    for n in grads[True]:
+        assert torch.equal(grads[True][n], grads[False][n]), n
