@@ -134,6 +134,8 @@ def make_graphed_train_step(net, optimizer, loss_fn, example_x, example_y, warmu
     torch.cuda.current_stream(dev).wait_stream(side)
     graph = torch.cuda.CUDAGraph()
     optimizer.zero_grad(set_to_none=True)
+    one = torch.ones((), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize(dev)
     # the warm-up ran on a side stream, the capture runs on torch's capture stream: the AccumulateGrad nodes created during
     # warm-up therefore sit on another (non-default) stream than the captured backward -- intended, as in torch's own
     # whole-network capture recipe; newer torch versions warn about it
@@ -143,7 +145,9 @@ def make_graphed_train_step(net, optimizer, loss_fn, example_x, example_y, warmu
     with capture(graph):
         static_loss = loss_fn(net, static_x, static_y)
         with ov():
-            static_loss.backward()
+            # the root gradient as a tensor made once, outside the capture: loss.backward() alone fills a fresh ones_like(loss)
+            # on every replay (a ~4.7 us launch between the loss kernel and its backward)
+            static_loss.backward(one if (static_loss.dim() == 0 and static_loss.dtype == torch.float32) else None)
         optimizer.step()
 
     if _quiet is not None:
@@ -161,6 +165,7 @@ def make_graphed_train_step(net, optimizer, loss_fn, example_x, example_y, warmu
 
     step.graph = graph
     step.inputs = (static_x, static_y)
+    step._root_grad = one                          # read by every replay: lives as long as the step
     return step
 
 

@@ -192,12 +192,13 @@ class DataParallelELBO:
         net, dev = self.net, example_x.device
         ov = layers.vector_backward_overlap
         static_x, static_y = example_x.clone(), example_y.clone()
+        one = torch.ones((), dtype=torch.float32, device=dev)       # the root gradient, made once (graphs.make_graphed_train_step)
 
         def fwd_bwd():
             optimizer.zero_grad(set_to_none=True)
             loss = self.loss(net(static_x, sample=True), static_y, num_batches)
             with ov():
-                loss.backward()
+                loss.backward(one if (loss.dim() == 0 and loss.dtype == torch.float32) else None)
             self.bucket.pack()
             return loss
 
@@ -235,6 +236,7 @@ class DataParallelELBO:
 
         step.graphs = (g_a, g_b)
         step.inputs = (static_x, static_y)
+        step._root_grad = one                          # read by every replay of graph A: lives as long as the step
         return step
 
     def describe_collective(self) -> str:
