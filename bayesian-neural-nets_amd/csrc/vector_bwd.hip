@@ -349,9 +349,22 @@ __device__ __forceinline__ void flow_planar_backward_reg_body(const A& a) {
             }
         }
     }
+    // (only the sums this layer's flows use: 24 of the 70 at Tz = Tr = 2; the others are sums of zeros and stay zero)
+    auto used = [&](int k) -> bool {
+        if (k >= NS_SE) return has_kl;
+        if (k >= NS_DFW) return k - NS_DFW < Tz;
+        if (k >= NS_DKL) return has_kl && k - NS_DKL < Tz;
+        if (k >= NS_R) return has_kl && (k - NS_R) / kRT < Tr && (k - NS_R) % kRT < Tr;
+        if (k >= NS_C) return has_kl && (k - NS_C) / kRT < Tr && (k - NS_C) % kRT < Tz;
+        if (k >= NS_ARK) return has_kl && k - NS_ARK < Tr;
+        if (k >= NS_X) return (k - NS_X) / kRT < Tz && (k - NS_X) % kRT < Tz;
+        if (k >= NS_AWK) return has_kl && k - NS_AWK < Tz;
+        return k < Tz;
+    };
 #pragma unroll
     for (int k = 0; k < NS_N; ++k) {
-        const float v = wave_sum(part[k]);
+        float v = 0.f;
+        if (used(k)) v = wave_sum(part[k]);                            // uniform
         if (lane == 0) wsum[k][wv] = v;
     }
     __syncthreads();
@@ -363,7 +376,8 @@ __device__ __forceinline__ void flow_planar_backward_reg_body(const A& a) {
     }
     __syncthreads();
 
-    // ---- the scalar chains (flows2.py:87-95 forward, its derivative backward): wave 0, every lane the same values
+    // ---- the scalar chains (flows2.py:87-95 forward, its derivative backward): wave 0, every lane the same values;
+    // tanh as the forward's K3v takes it (tanh_fast: one v_exp + one v_rcp)
     if (wv == 0) {
         auto S = [&](int k) -> float { return (float)tot[k]; };
         float thF[kRT], thK[kRT], thR[kRT], dinr[kRT], cr[kRT], dink[kRT], ck[kRT], dinf[kRT];
@@ -376,8 +390,8 @@ __device__ __forceinline__ void flow_planar_backward_reg_body(const A& a) {
 #pragma unroll
                 for (int s2 = 0; s2 < t; ++s2) { inf += (double)thF[s2] * tot[NS_X + t * kRT + s2]; ink += (double)thK[s2] * tot[NS_X + t * kRT + s2]; }
                 const float b = a.z_flow.b[t][0];
-                thF[t] = tanhf((float)inf + b);
-                if (has_kl) thK[t] = tanhf((float)ink + b);
+                thF[t] = tanh_fast((float)inf + b);
+                if (has_kl) thK[t] = tanh_fast((float)ink + b);
             }
         float zb = 0.f, szb = 0.f;
         if (has_kl) {
@@ -389,7 +403,7 @@ __device__ __forceinline__ void flow_planar_backward_reg_body(const A& a) {
                     for (int s2 = 0; s2 < kRT; ++s2) if (s2 < Tz) inr += (double)thK[s2] * tot[NS_C + t * kRT + s2];
 #pragma unroll
                     for (int s2 = 0; s2 < t; ++s2) inr += (double)thR[s2] * tot[NS_R + t * kRT + s2];
-                    thR[t] = tanhf((float)inr + a.r_flow.b[t][0]);
+                    thR[t] = tanh_fast((float)inr + a.r_flow.b[t][0]);
                 }
             zb = lastv[0];
 #pragma unroll
