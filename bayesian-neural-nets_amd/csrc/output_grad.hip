@@ -194,43 +194,36 @@ __global__ __launch_bounds__(HD_COLS) void head_dx_c_kernel(const float* __restr
 // lbbnn_weight_pass_backward to add (fixed order there too): deterministic.  Eight rows' loads in flight per thread and 2.4
 // waves per SIMD: the first version (four row lanes, four rows in flight, 1.2 waves per SIMD) was a chain of exposed load
 // latencies -- 27.9 us for 19.7 MB.
+// (Measured and dropped: the head's dX formed in the same pass -- both kernels want the batch row's gradients as scalars and
+// x[b][i] once.  34.2 us fused against 14.7 (lbbnn_head_dx) + 14.8 here: 40 accumulator / operand registers per thread and a
+// 256-B store per wave and row inside the loop cost more than the second read of the 19.7 MB activation.)
 constexpr int HW_COLS = 64, HW_LANES = 8;
 
-// With wmT (and wvT) given the same pass also writes the head's input gradient (lbbnn_head_dx's sum): both need the batch row's
-// gradients as scalars and x[b][i] once -- one read of the 19.7 MB activation instead of two.
 template <int C>
 __global__ __launch_bounds__(HW_COLS * HW_LANES) void head_dw_kernel(const float* __restrict__ gm, const float* __restrict__ gv,
                                                                      int ldg, const float* __restrict__ x, int ldx,
                                                                      float* __restrict__ dWm, float* __restrict__ dWv,
-                                                                     int B, int I, int rows_per_slab,
-                                                                     const float* __restrict__ wmT, const float* __restrict__ wvT,
-                                                                     int ldw, float* __restrict__ dx, int lddx) {
+                                                                     int B, int I, int rows_per_slab) {
     __shared__ float red[HW_LANES][2 * C][HW_COLS];
     const int cg = threadIdx.x & (HW_COLS - 1);
     const int rl = __builtin_amdgcn_readfirstlane(threadIdx.x / HW_COLS);              // the wave's index: uniform, and the compiler must know (scalar loads of the gradient rows)
     const int i = blockIdx.x * HW_COLS + cg, s = blockIdx.y;
     const int r0 = s * rows_per_slab, r1 = min(r0 + rows_per_slab, B);
-    float am[C], av[C], wm[C], wv[C];
+    float am[C], av[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) { am[c] = 0.f; av[c] = 0.f; wm[c] = 0.f; wv[c] = 0.f; }
+    for (int c = 0; c < C; ++c) { am[c] = 0.f; av[c] = 0.f; }
     if (i < I) {
-        if (dx) {
-#pragma unroll
-            for (int c = 0; c < C; ++c) { wm[c] = wmT[(size_t)i * ldw + c]; if (wvT) wv[c] = wvT[(size_t)i * ldw + c]; }
-        }
 #pragma unroll 4
         for (int b = r0 + rl; b < r1; b += HW_LANES) {
             const float* __restrict__ pm = gm + (size_t)b * ldg;
             const float xv = x[(size_t)b * ldx + i], x2 = xv * xv;
-            float dm = 0.f, dv = 0.f;
 #pragma unroll
-            for (int c = 0; c < C; ++c) { am[c] += pm[c] * xv; dm += pm[c] * wm[c]; }
+            for (int c = 0; c < C; ++c) am[c] += pm[c] * xv;
             if (gv) {
                 const float* __restrict__ pv = gv + (size_t)b * ldg;
 #pragma unroll
-                for (int c = 0; c < C; ++c) { av[c] += pv[c] * x2; dv += pv[c] * wv[c]; }
+                for (int c = 0; c < C; ++c) av[c] += pv[c] * x2;
             }
-            if (dx) dx[(size_t)b * lddx + i] = gv ? dm + 2.f * xv * dv : dm;         // (the order of lbbnn_head_dx's sums)
         }
     }
 #pragma unroll
@@ -249,30 +242,21 @@ __global__ __launch_bounds__(HW_COLS * HW_LANES) void head_dw_kernel(const float
 
 }  // namespace
 
-extern "C" int lbbnn_head_dw_dx(const float* gm, const float* gv, int ldg, const float* x, int ldx, float* dWm, float* dWv,
-                                int B, int C, int I, int nslabs, const float* wmT, const float* wvT, int ldw, float* dx, int lddx,
-                                void* stream) {
+extern "C" int lbbnn_head_dw(const float* gm, const float* gv, int ldg, const float* x, int ldx, float* dWm, float* dWv,
+                             int B, int C, int I, int nslabs, void* stream) {
     if (!gm || !x || !dWm) return LBBNN_E_NULL;
     if ((gv == nullptr) != (dWv == nullptr)) return LBBNN_E_NULL;
-    if (dx && (!wmT || (gv != nullptr) != (wvT != nullptr))) return LBBNN_E_NULL;
     if (B <= 0 || C <= 0 || C > HD_MAXC || I <= 0 || ldg < C || ldx < I || nslabs <= 0 || nslabs > B) return LBBNN_E_SHAPE;
-    if (dx && (ldw < C || lddx < I)) return LBBNN_E_SHAPE;
     const int rows = (B + nslabs - 1) / nslabs;
     const dim3 grid((I + HW_COLS - 1) / HW_COLS, nslabs), block(HW_COLS * HW_LANES);
     hipStream_t s = static_cast<hipStream_t>(stream);
-#define LBBNN_HEAD_DW(CC) case CC: hipLaunchKernelGGL(head_dw_kernel<CC>, grid, block, 0, s, gm, gv, ldg, x, ldx, dWm, dWv, B, I, rows, \
-                                                      wmT, wvT, ldw, dx, lddx); break;
+#define LBBNN_HEAD_DW(CC) case CC: hipLaunchKernelGGL(head_dw_kernel<CC>, grid, block, 0, s, gm, gv, ldg, x, ldx, dWm, dWv, B, I, rows); break;
     switch (C) {
         LBBNN_HEAD_DW(1) LBBNN_HEAD_DW(2) LBBNN_HEAD_DW(3) LBBNN_HEAD_DW(4) LBBNN_HEAD_DW(5) LBBNN_HEAD_DW(6) LBBNN_HEAD_DW(7) LBBNN_HEAD_DW(8)
         LBBNN_HEAD_DW(9) LBBNN_HEAD_DW(10) LBBNN_HEAD_DW(11) LBBNN_HEAD_DW(12) LBBNN_HEAD_DW(13) LBBNN_HEAD_DW(14) LBBNN_HEAD_DW(15) LBBNN_HEAD_DW(16)
     }
 #undef LBBNN_HEAD_DW
     return (int)hipGetLastError();
-}
-
-extern "C" int lbbnn_head_dw(const float* gm, const float* gv, int ldg, const float* x, int ldx, float* dWm, float* dWv,
-                             int B, int C, int I, int nslabs, void* stream) {
-    return lbbnn_head_dw_dx(gm, gv, ldg, x, ldx, dWm, dWv, B, C, I, nslabs, nullptr, nullptr, 0, nullptr, 0, stream);
 }
 
 extern "C" int lbbnn_head_dx(const float* gm, const float* gv, int ldg, const float* wmT, const float* wvT, int ldw,

@@ -281,7 +281,6 @@ class _BayesLinearFn(torch.autograd.Function):
                 da_mu, da_var = torch.autograd.grad(vg["kl"], [am, av], g_kl, retain_graph=True)
         # ---- the four big products on the HIP GEMM kernels
         gx = None
-        head_dw_done = None
         if ctx.needs_input_grad[1]:
             # (e_w z)^T and var_w^T straight from the parameters in one pass (lbbnn_weight_operands_t)
             from . import _lib
@@ -298,14 +297,8 @@ class _BayesLinearFn(torch.autograd.Function):
                     ops.F_SPLIT16 if split_m else 0, torch.cuda.current_stream(x.device).cuda_stream), "lbbnn_weight_operands_t")
                 w_shape = torch.empty((O, I), device="meta")       # shape carrier for _hip_matmul_nt
                 if O <= 16 and not split_m and x.stride(1) == 1 and g.stride(0) == (g_v.stride(0) if stochastic else g.stride(0)):
-                    # the 10-class head: ten multiply-adds per output are one elementwise-shaped launch, not two GEMMs --
-                    # and the SAME pass over x gives the head's weight-gradient slabs (lbbnn_head_dw_dx)
-                    if _HEAD_DW and x.dim() == 2 and x.dtype == torch.float32 and B >= 64:
-                        dWm_h, dWv_h, gx = ops.head_dw(g, g_v if stochastic else None, x, wmT=e_t, wvT=v_t if stochastic else None,
-                                                       nslabs=16 if (O * I) % 4 == 0 else 1)
-                        head_dw_done = (dWm_h, dWv_h) if dWm_h.shape[0] > 1 else (dWm_h[0], dWv_h[0] if dWv_h is not None else None)
-                    else:
-                        gx = ops.head_dx(g, g_v if stochastic else None, e_t, v_t if stochastic else None, x, C=O, I=I)
+                    # the 10-class head: ten multiply-adds per output are one elementwise-shaped launch, not two GEMMs
+                    gx = ops.head_dx(g, g_v if stochastic else None, e_t, v_t if stochastic else None, x, C=O, I=I)
                     stochastic_done = True
                 else:
                     stochastic_done = False
@@ -324,9 +317,7 @@ class _BayesLinearFn(torch.autograd.Function):
                 gx = _hip_matmul_nt(g, ops.transpose_operand, bw[0][:, :I], module=layer)
                 if stochastic:
                     gx = ops.dx_combine(gx, _hip_matmul_nt(g_v, ops.transpose_operand, bw[1][:, :I], module=layer), x)
-        if head_dw_done is not None:
-            dWm, dWv = head_dw_done
-        elif (_HEAD_DW and layer.out_features <= 16 and g is not None and (g_v is not None or not stochastic) and x.dim() == 2
+        if (_HEAD_DW and layer.out_features <= 16 and g is not None and (g_v is not None or not stochastic) and x.dim() == 2
                 and x.stride(1) == 1 and x.dtype == torch.float32 and B >= 64):
             # the <= 16-class head: split-K slabs of both weight gradients straight from the row-major G and x (lbbnn_head_dw) --
             # no x^T | (x^2)^T operand pass, no 16-row GEMM tiles that are 37 % padding at 10 classes

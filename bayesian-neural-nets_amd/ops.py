@@ -257,29 +257,19 @@ def head_dx(gm, gv, wmT, wvT, x, *, C: int, I: int):
 
 
 
-def head_dw(gm, gv, x, *, nslabs: int = 16, wmT=None, wvT=None):
+def head_dw(gm, gv, x, *, nslabs: int = 16):
     """lbbnn_head_dw: (S, C, I) split-K slabs of dW_m = G_m^T x and dW_v = G_v^T x^2 of a <= 16-class head, from the row-major
-    gradients (B, C) and the row-major layer input (B, I); gv None: (dWm, None).
-    wmT (and wvT when gv is given): the transposed fp32 operands [I][ld] -- the same pass then also returns the head's input
-    gradient dX (B, I) as lbbnn_head_dx forms it (lbbnn_head_dw_dx): (dWm, dWv, dX)."""
+    gradients (B, C) and the row-major layer input (B, I); gv None: (dWm, None)."""
     B, C = gm.shape
     I = x.shape[1]
     S = max(1, min(int(nslabs), B))
     dWm = torch.empty((S, C, I), dtype=torch.float32, device=gm.device)
     dWv = torch.empty((S, C, I), dtype=torch.float32, device=gm.device) if gv is not None else None
-    if wmT is None:
-        rc = _lib.lib().lbbnn_head_dw(_ptr_rows(gm, "gm"), _ptr_rows(gv, "gv") if gv is not None else None, gm.stride(0),
-                                      _ptr_rows(x, "x"), x.stride(0), dWm.data_ptr(), dWv.data_ptr() if dWv is not None else None,
-                                      B, C, I, S, _stream())
-        _lib.check(rc, "lbbnn_head_dw")
-        return dWm, dWv
-    dx = torch.empty((B, I), dtype=torch.float32, device=gm.device)
-    rc = _lib.lib().lbbnn_head_dw_dx(_ptr_rows(gm, "gm"), _ptr_rows(gv, "gv") if gv is not None else None, gm.stride(0),
-                                     _ptr_rows(x, "x"), x.stride(0), dWm.data_ptr(), dWv.data_ptr() if dWv is not None else None,
-                                     B, C, I, S, _ptr(wmT), _ptr(wvT) if gv is not None else None, wmT.stride(0), dx.data_ptr(), I,
-                                     _stream())
-    _lib.check(rc, "lbbnn_head_dw_dx")
-    return dWm, dWv, dx
+    rc = _lib.lib().lbbnn_head_dw(_ptr_rows(gm, "gm"), _ptr_rows(gv, "gv") if gv is not None else None, gm.stride(0),
+                                  _ptr_rows(x, "x"), x.stride(0), dWm.data_ptr(), dWv.data_ptr() if dWv is not None else None,
+                                  B, C, I, S, _stream())
+    _lib.check(rc, "lbbnn_head_dw")
+    return dWm, dWv
 
 
 def matmul_splitk(a, w_op, *, K: int, N: int, kchunk: int):

@@ -631,11 +631,6 @@ int lbbnn_head_dx(const float* gm, const float* gv, int ldg, const float* wmT, c
  * Slab s covers rows [s r, min((s + 1) r, B)), r = ceil(B / nslabs).  Deterministic (fixed order of every addition). */
 int lbbnn_head_dw(const float* gm, const float* gv, int ldg, const float* x, int ldx, float* dWm, float* dWv,
                   int B, int C, int I, int nslabs, void* stream);
-/* ... and, in the same pass over x, the head's input gradient dx[b][i] (row stride lddx) as lbbnn_head_dx forms it from the
- * transposed fp32 operands wmT / wvT ([I][ldw]); dx == NULL: lbbnn_head_dw. */
-int lbbnn_head_dw_dx(const float* gm, const float* gv, int ldg, const float* x, int ldx, float* dWm, float* dWv,
-                     int B, int C, int I, int nslabs, const float* wmT, const float* wvT, int ldw, float* dx, int lddx,
-                     void* stream);
 /* gx (B,I dense) += 2 * x (B,I; row stride ldx) * gxv (B,I dense): the input gradient of the variance GEMM folded
  * into dX = G_m.W_m + 2 x (.) (G_v.W_v)  (d/dx of (x^2).var_w^T, LBBNN-GP-MF-LRT.py:173). */
 /* out = comb_add + 2 * comb_x (.) (x . w_op^T): the mean-only product of lbbnn_lrt_gemm with lbbnn_dx_combine fused into

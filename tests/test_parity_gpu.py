@@ -2621,17 +2621,6 @@ def test_head_dw_slabs_vs_fp64(bnn, dev, B, C, I, S, stoch):
             assert rel_err(dWv[s], gv[lo:hi].double().T @ (x[lo:hi].double() ** 2)) < 2e-6
     again = ops.head_dw(gm, gv if stoch else None, x, nslabs=S)
     assert torch.equal(again[0], dWm) and (not stoch or torch.equal(again[1], dWv))
-    # the fused form (lbbnn_head_dw_dx): the same slabs bit for bit, and dX == lbbnn_head_dx bit for bit
-    ld = ops.operand_ld(C)
-    wmT, wvT = torch.randn(I, ld, generator=g).to(dev), torch.randn(I, ld, generator=g).to(dev)
-    f = ops.head_dw(gm, gv if stoch else None, x, nslabs=S, wmT=wmT, wvT=wvT if stoch else None)
-    assert torch.equal(f[0], dWm) and (not stoch or torch.equal(f[1], dWv))
-    ref_dx = ops.head_dx(gm, gv if stoch else None, wmT, wvT if stoch else None, x, C=C, I=I)
-    assert rel_err(f[2], ref_dx) < 1e-6
-    want = gm.double() @ wmT[:, :C].double().T
-    if stoch:
-        want = want + 2 * x.double() * (gv.double() @ wvT[:, :C].double().T)
-    assert rel_err(f[2], want) < 2e-6
 
 
 def test_head_weight_gradients_same_through_head_dw_and_the_gemm_route(bnn, dev, monkeypatch):
