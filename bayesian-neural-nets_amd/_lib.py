@@ -86,6 +86,12 @@ class ReduceJob(ctypes.Structure):
                 ("nblk", c_i), ("ncols", c_i), ("nq", c_i)]
 
 
+class AuxBwdArgs(ctypes.Structure):
+    """lbbnn_aux_bwd_args_t (include/lbbnn.h)."""
+    _fields_ = [(n, c_p) for n in ("act_mu", "act_var", "eps_act", "r0_b1", "r0_b2", "zb_last", "g_kl", "da_mu", "da_var", "aux",
+                                   "rng")] + [("O", c_i), ("I", c_i), ("layer_id", ctypes.c_uint32)]
+
+
 class WpbArgs(ctypes.Structure):
     """lbbnn_wpb_args_t"""
     _fields_ = [(n, c_p) for n in ("mu", "rho", "lambdal", "dWm", "dWv", "z_fwd", "z_kl", "r0_c",
@@ -224,6 +230,7 @@ SIGNATURES = {
     "lbbnn_flow_chain": (c_i, [ctypes.POINTER(FlowChain), c_p, c_p, c_p, c_p, c_p, c_u32, c_i, c_p, c_p, c_p, c_p, c_p]),
     "lbbnn_flow_chain_rows": (c_i, [ctypes.POINTER(FlowChain), c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p]),
     "lbbnn_mnf_aux_backward": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_u32, c_p]),
+    "lbbnn_mnf_aux_backward_batch": (c_i, [c_p, c_i, c_p]),
     "lbbnn_mnf_flow_backward_workspace": (c_i64, [c_i, c_i, c_i]),
     "lbbnn_mnf_flow_planar_backward": (c_i, [ctypes.POINTER(FlowBwdArgs), c_p]),
     "lbbnn_mnf_flow_planar_backward_batch": (c_i, [ctypes.POINTER(FlowBwdArgs), c_i, c_p]),

@@ -24,11 +24,11 @@ __device__ __forceinline__ void bsum3(double& a, double& b, double& c, double* s
     a = sa; b = sb; c = sc;
 }
 
-__global__ __launch_bounds__(NT) void mnf_aux_backward_kernel(const float* __restrict__ act_mu, const float* __restrict__ act_var,
-                                                              const float* __restrict__ eps_act, const float* __restrict__ b1,
-                                                              const float* __restrict__ b2, const float* zb_last, const float* g_kl,
-                                                              int O, int I, float* da_mu, float* da_var, float* aux,
-                                                              const uint64_t* rng, uint32_t layer) {
+__device__ __forceinline__ void mnf_aux_backward_body(const float* __restrict__ act_mu, const float* __restrict__ act_var,
+                                                      const float* __restrict__ eps_act, const float* __restrict__ b1,
+                                                      const float* __restrict__ b2, const float* zb_last, const float* g_kl,
+                                                      int O, int I, float* da_mu, float* da_var, float* aux,
+                                                      const uint64_t* rng, uint32_t layer) {
     __shared__ double scratch[3 * NWV];
     const int tid = threadIdx.x;
     uint64_t seed = 0, offs = 0;
@@ -59,6 +59,23 @@ __global__ __launch_bounds__(NT) void mnf_aux_backward_kernel(const float* __res
         da_var[o] = d * e / (2.f * sd);
     }
     if (tid == 0) aux[0] = m;
+}
+
+__global__ __launch_bounds__(NT) void mnf_aux_backward_kernel(const float* __restrict__ act_mu, const float* __restrict__ act_var,
+                                                              const float* __restrict__ eps_act, const float* __restrict__ b1,
+                                                              const float* __restrict__ b2, const float* zb_last, const float* g_kl,
+                                                              int O, int I, float* da_mu, float* da_var, float* aux,
+                                                              const uint64_t* rng, uint32_t layer) {
+    mnf_aux_backward_body(act_mu, act_var, eps_act, b1, b2, zb_last, g_kl, O, I, da_mu, da_var, aux, rng, layer);
+}
+
+// V1 of up to LBBNN_MAX_LAYERS layers in one launch (one workgroup per layer): every input is a by-product of the FORWARD, so
+// once d loss / d kl is known all layers' V1 can run together instead of one ~7 us single-workgroup launch per layer.
+struct AuxBatch { lbbnn_aux_bwd_args_t l[LBBNN_MAX_LAYERS]; };
+__global__ __launch_bounds__(NT) void mnf_aux_backward_batch_kernel(const AuxBatch bt) {
+    const LBBNN_CONST_AS lbbnn_aux_bwd_args_t& a = kernarg_as<AuxBatch>()->l[blockIdx.x];
+    mnf_aux_backward_body(a.act_mu, a.act_var, a.eps_act, a.r0_b1, a.r0_b2, a.zb_last, a.g_kl, a.O, a.I, a.da_mu, a.da_var, a.aux,
+                          a.rng, a.layer_id & 63u);
 }
 
 // Compact form of lbbnn_flow_bwd_args_t (flows of at most kBatchT transforms) so that the arguments of several layers fit
@@ -549,6 +566,21 @@ extern "C" int lbbnn_mnf_aux_backward(const float* act_mu, const float* act_var,
     if (O <= 0 || I <= 0) return LBBNN_E_SHAPE;
     hipLaunchKernelGGL(mnf_aux_backward_kernel, dim3(1), dim3(NT), 0, static_cast<hipStream_t>(stream), act_mu, act_var, eps_act,
                        r0_b1, r0_b2, zb_last, g_kl, O, I, da_mu, da_var, aux, rng, layer_id & 63u);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lbbnn_mnf_aux_backward_batch(const lbbnn_aux_bwd_args_t* args, int n, void* stream) {
+    if (!args) return LBBNN_E_NULL;
+    if (n <= 0 || n > LBBNN_MAX_LAYERS) return LBBNN_E_SHAPE;
+    AuxBatch bt;
+    for (int k = 0; k < n; ++k) {
+        const lbbnn_aux_bwd_args_t& a = args[k];
+        if (!a.act_mu || !a.act_var || !a.r0_b1 || !a.r0_b2 || !a.zb_last || !a.g_kl || !a.da_mu || !a.da_var || !a.aux) return LBBNN_E_NULL;
+        if (!a.eps_act && !a.rng) return LBBNN_E_NOISE;
+        if (a.O <= 0 || a.I <= 0) return LBBNN_E_SHAPE;
+        bt.l[k] = a;
+    }
+    hipLaunchKernelGGL(mnf_aux_backward_batch_kernel, dim3(n), dim3(NT), 0, static_cast<hipStream_t>(stream), bt);
     return (int)hipGetLastError();
 }
 

@@ -50,6 +50,7 @@ _DENSE_DEFER = {"0": False, "always": "always"}.get(_os.environ.get("LBBNN_DENSE
 # 0.1392 ms): no form of the pre-pass beats the in-register split, so the simpler one is the default.
 # LBBNN_HEAD_FOLD=0: keep the 10-class head a GEMM launch of its own (the skinny kernel) in the fused fp16 forward
 _HEAD_FOLD = _os.environ.get("LBBNN_HEAD_FOLD", "1") != "0"
+_V1_BATCH = _os.environ.get("LBBNN_V1_BATCH", "1") != "0"          # all layers' V1 in one launch from the KL sum's backward (A/B knob)
 _DEFER_SUMS = _os.environ.get("LBBNN_DEFER_SUMS", "1") != "0"      # column sums finished with the deferred vector chains (A/B knob)
 _HEAD_DW = _os.environ.get("LBBNN_HEAD_DW", "1") != "0"           # the head's weight gradients through lbbnn_head_dw (A/B knob)
 _F16_FIRST_PLANES = _os.environ.get("LBBNN_F16_FIRST", "f32") != "f32"
@@ -202,6 +203,15 @@ class _BayesLinearFn(torch.autograd.Function):
             saved["z_fwd"] = ws.z_fwd
             if cfg[1]:
                 saved["act_mu"], saved["act_var"], saved["z_kl"], saved["scal"] = ws.act_mu, ws.act_var, ws.z_kl, ws.scal
+        layer._v1_slot = None
+        if layer._mnf and cfg[1] and _V1_BATCH and not saved.get("noise") and saved.get("rng") is not None \
+                and (layer._check_flows() == "planar" or dense) and "r0_b1" in layer._vec_names:
+            # V1 (lbbnn_mnf_aux_backward) reads by-products of THIS forward only: the backward of the network's KL sum
+            # (losses._SumKLFn), which learns d loss / d kl for all layers at once, runs all layers' V1 in one launch and
+            # leaves the results in this slot for the layer's own backward
+            slot = {"in": dict(act_mu=saved["act_mu"], act_var=saved["act_var"], zb_last=saved["scal"][3:4], rng=saved["rng"],
+                               r0_b1=layer.r0_b1, r0_b2=layer.r0_b2, layer_id=layer._layer_id)}
+            saved["v1_slot"] = layer._v1_slot = slot
         ctx.layer, ctx.cfg, ctx.saved = layer, cfg, saved
         from . import graphs
         graphs.mark_autograd_node(ctx, layer)          # capture guard: graphs.assert_no_live_graph
@@ -262,9 +272,13 @@ class _BayesLinearFn(torch.autograd.Function):
             z2 = ctx.saved["z_kl"] if want_kl else None
             if want_kl:
                 r0_c = P["r0_c"]
-                da_mu, da_var, aux = ops.mnf_aux_backward(ctx.saved["act_mu"], ctx.saved["act_var"], noise.get("eps_act"),
-                                                          P["r0_b1"], P["r0_b2"], ctx.saved["scal"][3:4], g_kl,
-                                                          rng=rng_snap, layer_id=layer._layer_id)
+                slot = ctx.saved.get("v1_slot")
+                if slot is not None and "out" in slot and slot["out"][3].data_ptr() == g_kl.data_ptr():
+                    da_mu, da_var, aux = slot.pop("out")[:3]               # run with the other layers' by losses._SumKLFn
+                else:
+                    da_mu, da_var, aux = ops.mnf_aux_backward(ctx.saved["act_mu"], ctx.saved["act_var"], noise.get("eps_act"),
+                                                              P["r0_b1"], P["r0_b2"], ctx.saved["scal"][3:4], g_kl,
+                                                              rng=rng_snap, layer_id=layer._layer_id)
         else:
             # ---- vector-sized graph (flows, q/r densities, bias terms) under autograd: O(I + O) work
             with torch.enable_grad():
@@ -1363,7 +1377,8 @@ class _NetworkBase(nn.Module):
             return self._kl_total                                     # summed on the device by K5
         if self._train_kl_total is not None and all(torch.is_tensor(l.kl) and l.kl.grad_fn is not None for l in self._layers()):
             from .losses import _SumKLFn                              # ... also in the training forward: no add kernels
-            return _SumKLFn.apply(self._train_kl_total, *[l.kl for l in self._layers()])
+            return _SumKLFn.apply(self._train_kl_total, [getattr(l, "_v1_slot", None) for l in self._layers()],
+                                  *[l.kl for l in self._layers()])
         return self.l1.kl + self.l2.kl + self.l3.kl                   # …LRT.py:213-214
 
     def set_row_offset(self, off: int):

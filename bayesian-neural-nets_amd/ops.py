@@ -615,6 +615,29 @@ def mnf_aux_backward(act_mu, act_var, eps_act, r0_b1, r0_b2, zb_last, g_kl, rng=
     return da_mu, da_var, aux
 
 
+def mnf_aux_backward_batch(items, g_kl):
+    """lbbnn_mnf_aux_backward_batch: V1 of several layers in one launch.  items: dicts with act_mu, act_var, eps_act (or
+    None), r0_b1, r0_b2, zb_last, rng (or None), layer_id.  Returns [(da_mu, da_var, aux)] in the same order."""
+    outs = []
+    i = 0
+    while i < len(items):
+        grp = items[i:i + 4]
+        arr = (_lib.AuxBwdArgs * len(grp))()
+        for k, it in enumerate(grp):
+            da_mu, da_var = torch.empty_like(it["act_mu"]), torch.empty_like(it["act_mu"])
+            aux = torch.empty(4, dtype=torch.float32, device=da_mu.device)
+            a = arr[k]
+            a.act_mu, a.act_var, a.eps_act = _ptr(it["act_mu"], "act_mu"), _ptr(it["act_var"], "act_var"), _ptr(it.get("eps_act"))
+            a.r0_b1, a.r0_b2, a.zb_last, a.g_kl = _ptr(it["r0_b1"]), _ptr(it["r0_b2"]), it["zb_last"].data_ptr(), _ptr(g_kl, "g_kl")
+            a.da_mu, a.da_var, a.aux = da_mu.data_ptr(), da_var.data_ptr(), aux.data_ptr()
+            a.rng = it["rng"].data_ptr() if it.get("rng") is not None else None
+            a.O, a.I, a.layer_id = da_mu.shape[0], it["r0_b1"].shape[0], it["layer_id"]
+            outs.append((da_mu, da_var, aux))
+        _lib.check(_lib.lib().lbbnn_mnf_aux_backward_batch(arr, len(grp), _stream()), "lbbnn_mnf_aux_backward_batch")
+        i += 4
+    return outs
+
+
 def mnf_flow_planar_backward(q0_mean, q0_log_var, z_params, r_params, *, eps_fwd=None, eps_kl=None, r0_b1=None, r0_b2=None,
                              aux=None, dz_fwd=None, dz_kl=None, g_kl=None, bias_mu, bias_rho, g_sum, gv_sum=None,
                              priors: Priors, rng=None, layer_id: int = 0, defer=None):

@@ -532,6 +532,17 @@ typedef struct lbbnn_flow_bwd_args {
 int lbbnn_mnf_aux_backward(const float* act_mu, const float* act_var, const float* eps_act, const float* r0_b1,
                            const float* r0_b2, const float* zb_last, const float* g_kl, int O, int I,
                            float* da_mu, float* da_var, float* aux, const uint64_t* rng, uint32_t layer_id, void* stream);
+/* The same for n <= LBBNN_MAX_LAYERS layers in ONE launch (one workgroup per layer).  Every input is a by-product of the
+ * forward pass, so a caller that knows d loss / d kl for all layers at once (bnn_amd: the backward of the network's KL sum)
+ * runs all of them together. */
+typedef struct {
+    const float *act_mu, *act_var, *eps_act, *r0_b1, *r0_b2, *zb_last, *g_kl;
+    float *da_mu, *da_var, *aux;
+    const uint64_t* rng;
+    int O, I;
+    uint32_t layer_id;
+} lbbnn_aux_bwd_args_t;
+int lbbnn_mnf_aux_backward_batch(const lbbnn_aux_bwd_args_t* args, int n, void* stream);
 int64_t lbbnn_mnf_flow_backward_workspace(int I, int Tz, int Tr);
 int lbbnn_mnf_flow_planar_backward(const lbbnn_flow_bwd_args_t* args, void* stream);
 /* The same for n <= LBBNN_MAX_LAYERS layers in ONE launch (one workgroup per layer): the chains are latency-bound and

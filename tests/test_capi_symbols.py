@@ -77,7 +77,7 @@ def test_ctypes_struct_layouts_match_the_header(tmp_path):
              ("lbbnn_outgrad_args_t", _lib.OutGradArgs, "relu"), ("lbbnn_flow_step_t", _lib.FlowStep, "M"),
              ("lbbnn_flow_chain_t", _lib.FlowChain, "n"), ("lbbnn_planar_grad_t", _lib.PlanarGrad, "b"),
              ("lbbnn_flow_bwd_args_t", _lib.FlowBwdArgs, "layer_id"), ("lbbnn_dense_bwd_args_t", _lib.DenseBwdArgs, "layer_id"),
-             ("lbbnn_reduce_job_t", _lib.ReduceJob, "nq")]
+             ("lbbnn_reduce_job_t", _lib.ReduceJob, "nq"), ("lbbnn_aux_bwd_args_t", _lib.AuxBwdArgs, "layer_id")]
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "%s"' % os.path.join(ROOT, "include", "lbbnn.h"), "int main(void) {"]
     for cname, _, last in pairs:
         lines.append('printf("%s %%zu %%zu\\n", sizeof(%s), %s);' % (cname, cname, "offsetof(%s, %s)" % (cname, last) if last else "(size_t)0"))
@@ -169,3 +169,7 @@ def test_round3_entry_points_argument_checks(lib):
     jobs[0].work, jobs[0].nblk, jobs[0].ncols, jobs[0].nq = 4096, 4, 64, 4
     jobs[0].block_stride = jobs[0].q_stride = 64
     assert lib.lbbnn_reduce_partials_batch(jobs, 1, None) == -2                # nq > 3
+    # lbbnn_mnf_aux_backward_batch
+    assert lib.lbbnn_mnf_aux_backward_batch(None, 1, None) == -1
+    assert lib.lbbnn_mnf_aux_backward_batch((_lib.AuxBwdArgs * 1)(), 5, None) == -2
+    assert lib.lbbnn_mnf_aux_backward_batch((_lib.AuxBwdArgs * 1)(), 1, None) == -1

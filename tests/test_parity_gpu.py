@@ -2708,3 +2708,29 @@ def test_training_step_same_with_and_without_deferred_column_sums(bnn, dev, monk
         del loss, out
     for n in grads[True]:
         assert torch.equal(grads[True][n], grads[False][n]), n
+
+
+@pytest.mark.parametrize("kind", ["Planar", "RNVP"])
+def test_batched_v1_from_the_kl_sum_backward_is_bitwise_the_per_layer_one(bnn, dev, monkeypatch, kind):
+    """lbbnn_mnf_aux_backward_batch: all layers' V1 launched once from the backward of the network's KL sum (losses._SumKLFn)
+    against one lbbnn_mnf_aux_backward per layer -- same device body, so every parameter gradient of an ELBO backward is
+    bitwise the same; and a loss that does not go through net.kl() (per-layer KLs added by hand) still gets its V1."""
+    from bnn_amd import layers
+    grads = {}
+    for mode in ("batch", "per_layer", "manual_kl"):
+        monkeypatch.setattr(layers, "_V1_BATCH", mode != "per_layer")
+        bnn.manual_seed(5, 0)
+        torch.manual_seed(5)
+        net = bnn.mnf.BayesianNetwork((784, 48, 32, 10), 2, z_flow_type=kind, r_flow_type=kind).to(dev).train()
+        xg = torch.Generator().manual_seed(1)
+        x = torch.rand(256, 784, generator=xg).to(dev)
+        y = torch.randint(0, 10, (256,), generator=xg).to(dev)
+        out = net(x, sample=True)
+        kl = net.kl() if mode != "manual_kl" else (net.l1.kl + net.l2.kl + net.l3.kl)
+        loss = torch.nn.functional.nll_loss(out, y, reduction="sum") + kl / 10
+        loss.backward()
+        grads[mode] = {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+        del loss, out, kl
+    for n in grads["batch"]:
+        assert torch.equal(grads["batch"][n], grads["per_layer"][n]), n
+        assert rel_err(grads["manual_kl"][n], grads["per_layer"][n]) < 1e-6, n
