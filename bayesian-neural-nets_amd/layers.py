@@ -50,6 +50,7 @@ _DENSE_DEFER = {"0": False, "always": "always"}.get(_os.environ.get("LBBNN_DENSE
 # 0.1392 ms): no form of the pre-pass beats the in-register split, so the simpler one is the default.
 # LBBNN_HEAD_FOLD=0: keep the 10-class head a GEMM launch of its own (the skinny kernel) in the fused fp16 forward
 _HEAD_FOLD = _os.environ.get("LBBNN_HEAD_FOLD", "1") != "0"
+_ADV_RIDE = _os.environ.get("LBBNN_ADV_RIDE", "1") != "0"          # training forward: the RNG advance rides in the first GEMM's launch
 _V1_BATCH = _os.environ.get("LBBNN_V1_BATCH", "1") != "0"          # all layers' V1 in one launch from the KL sum's backward (A/B knob)
 _DEFER_SUMS = _os.environ.get("LBBNN_DEFER_SUMS", "1") != "0"      # column sums finished with the deferred vector chains (A/B knob)
 _HEAD_DW = _os.environ.get("LBBNN_HEAD_DW", "1") != "0"           # the head's weight gradients through lbbnn_head_dw (A/B knob)
@@ -611,7 +612,14 @@ class _BayesLinearBase(nn.Module):
                 kl = pre["kl"]
                 if pre["first"]:
                     fin, sh["hosted"] = sh["fin_all"], True
+                    if _ADV_RIDE and pre.get("snap") is not None and rng is not None and sh.get("all_snap"):
+                        # ... and so does the forward's RNG advance: every kernel of this forward from here on reads the
+                        # SNAPSHOT the weight pass took (same {seed, offset}), so the live offset may move already
+                        fin = (fin[0], fin[1], pre["snap"].data_ptr(), fin[3], rng.data_ptr(), 1)
+                        sh["advanced"] = True
                 hosted_all = True
+            if sh.get("advanced"):
+                rng = pre["snap"]                     # the GEMM's noise from the snapshot (the live offset is, or is being, advanced)
         else:
             self._prep(cfg, rng, kl_layer=kl, finalize=not cfg[1])
         if cfg[1] and not hosted_all:
@@ -1111,8 +1119,9 @@ class _NetworkBase(nn.Module):
                     l._advance_rng = True
                     l._lsm_now = False
             if shared:
-                ops.RngState.get(x.device).advance(1)
                 sh = self._pre_shared
+                if not (sh is not None and sh.get("advanced")):
+                    ops.RngState.get(x.device).advance(1)
                 self._train_kl_total = sh["kl_total"] if (sh is not None and sh.get("hosted") and sh.get("kl_total") is not None) else None
                 self._pre_shared = None
             return x if fused_lsm else F.log_softmax(x, dim=1)       # …LRT.py:210
@@ -1204,7 +1213,9 @@ class _NetworkBase(nn.Module):
                                                          torch.cuda.current_stream(dev).cuda_stream), "lbbnn_layers_operands_snap")
         all_kl = all(c[1] for c in cfgs)
         kl_total = torch.empty((), dtype=torch.float32, device=dev) if all_kl else None
-        shared = {"hosted": False, "keep": keep, "kl_total": kl_total,
+        shared = {"hosted": False, "keep": keep, "kl_total": kl_total, "advanced": False,
+                  # every layer draws in-kernel from the shared state and the step has ONE snapshot: the advance may ride early
+                  "all_snap": bool(snap is not None and rng is not None and all(l._uses_rng(c) for l, c in zip(layers, cfgs))),
                   "fin_all": (descs, len(layers), rng.data_ptr() if rng is not None else None,
                               kl_total.data_ptr()) if all_kl else None}
         self._pre_shared = shared
