@@ -10,6 +10,6 @@ done; done
 export TMPDIR=/tmp
 for flow in Planar RNVP; do
   (cd /tmp && PREC=${TPREC:-fp16x3f} FLOW=$flow rocprofv3 --kernel-trace -d $R/gpurun_out/r03/prof_train_$flow -o t -- python3 $R/tools/train_step_time.py graph > /dev/null 2>&1)
-  python3 tools/trace_summary.py $(ls gpurun_out/r03/prof_train_$flow/*.db gpurun_out/r03/prof_train_$flow/*/*.db 2>/dev/null | head -1) 56 40 > gpurun_out/r03/train_step_graph_${flow}_kernel_summary.txt 2>&1
+  python3 tools/trace_summary.py $(ls gpurun_out/r03/prof_train_$flow/*.db gpurun_out/r03/prof_train_$flow/*/*.db 2>/dev/null | head -1) 106 40 > gpurun_out/r03/train_step_graph_${flow}_kernel_summary.txt 2>&1
   head -45 gpurun_out/r03/train_step_graph_${flow}_kernel_summary.txt | cut -c1-190
 done
