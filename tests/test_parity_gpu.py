@@ -1207,6 +1207,46 @@ def test_baseline_config1_lrt_400_b1024_split(bnn, dev):
         assert rel_err(kl, ref_kl) < TIGHT
 
 
+def test_baseline_config0_base_lbbnn_400_400_b100(bnn, dev):
+    """configs[0] at the dims BASELINE.json's string names -- LBBNN-GP-MF.py, 784-400-400-10, batch 100, one MC sample (the
+    reference's own BayesianNetwork() is 784-400-600-10: tests/golden/base_elbo.npz anchors that one): the whole sampled
+    network on the HIP path against the oracle's restatement of LBBNN-GP-MF.py:228-255, 285-319 on the same draws --
+    log-probabilities, log prior, log variational posterior, nll and the ELBO loss."""
+    dims, B = (784, 400, 400, 10), 100
+    torch.manual_seed(11)
+    net = bnn.base.BayesianNetwork(dims)
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand(B, 784, generator=g)
+    y = torch.randint(0, 10, (B,), generator=g)
+    layers = [net.l1, net.l2, net.l3]
+    P = [{k: v.detach().clone() for k, v in l.state_dict().items()} for l in layers]
+    gates = [torch.rand(l.out_features, l.in_features, generator=g) for l in layers]
+    noises = [{"eps_w": torch.randn(l.out_features, l.in_features, generator=g), "eps_b": torch.randn(l.out_features, generator=g),
+               "tau_w": 0.5 + torch.rand(1, generator=g), "tau_b": 0.5 + torch.rand(l.out_features, generator=g)} for l in layers]
+    h, lp_ref, lq_ref = x, 0.0, 0.0
+    for i, (p, cg, n) in enumerate(zip(P, gates, noises)):
+        h, lp, lq = orc.base_forward(h, p, cg, n, mode="sample")
+        lp_ref, lq_ref = lp_ref + lp, lq_ref + lq
+        if i < 2:
+            h = torch.relu(h)
+    ref_out = torch.log_softmax(h, dim=1)
+    ref_nll = torch.nn.functional.nll_loss(ref_out, y, reduction="sum")
+    ref_loss = ref_nll + (lq_ref - lp_ref) / 600
+    net = net.to(dev).train()
+    with torch.no_grad():
+        for l, n in zip(layers, noises):
+            l.alpha = 1 / (1 + torch.exp(-l.lambdal))                 # as sample_elbo does (LBBNN-GP-MF.py:292-297)
+            l.gamma.alpha = l.alpha
+            l.noise = {k: v.to(dev) for k, v in n.items()}
+        out = net(x.to(dev), gates[0].to(dev), gates[1].to(dev), gates[2].to(dev), sample=True)
+        lp, lq = net.log_prior(), net.log_variational_posterior()
+        nll = torch.nn.functional.nll_loss(out, y.to(dev), reduction="sum")
+        loss = nll + (lq - lp) / 600
+    assert rel_err(out, ref_out) < 2e-5
+    assert rel_err(lp, lp_ref) < 2e-5 and rel_err(lq, lq_ref) < 2e-5
+    assert rel_err(nll, ref_nll) < 2e-5 and rel_err(loss, ref_loss) < 2e-5
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("O,I,mnf", [(37, 53, True), (64, 128, True), (130, 1200, True), (48, 64, False)])
 def test_weight_pass_backward_kernel(bnn, dev, O, I, mnf):
