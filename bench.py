@@ -86,6 +86,8 @@ def parse():
                     help="skip the reduced-precision leg (one bf16 product per moment: OUTSIDE the 1e-4 contract)")
     ap.add_argument("--train", dest="train", action="store_true", default=None,
                     help="also time the data-parallel training step (default: only when N > 1)")
+    ap.add_argument("--train-timeout", type=int, default=240,
+                    help="seconds after which a training leg that has not finished is abandoned (the line is printed without it)")
     ap.add_argument("--no-train", dest="train", action="store_false")
     ap.add_argument("--plan", dest="launch", action="store_const", const="plan", default="plan",
                     help="(default) a step = bnn_amd.graphs.LaunchPlan: the forward's C calls (3 calls = 5 kernels in the fp16 forward) recorded once after "
@@ -703,105 +705,129 @@ def main():
         net.set_row_offset(rank * Bs)
         strong = forward_leg(args, bnn_amd, ops, net, x[:Bs], sync, args.precision, world)
         net.set_row_offset(rank * B)
+    def emit(train):
+        """Rank 0: build and print the ONE JSON line (everything but `train` was measured before this is called)."""
+
+        if rank == 0:
+            sum_io = sum(DIMS[i] * DIMS[i + 1] for i in range(3))
+            main_leg = legs[args.precision]
+            elapsed = main_leg["elapsed"]
+            total = B * world * args.steps
+            sampled_in = "separate eager pass after the timed region (every GEMM launch bracketed by HIP events)"
+            res = {
+                "metric": "ELBO forward samples/sec, 784-1200^2-10 MNF MLP, batch 4096 per GPU",
+                "value": total / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": DTYPE_OF[args.precision], "precision": args.precision,
+                "data": "synthetic", "hip_graph": main_leg["launch"] == "graph",
+                "launch": {"plan": "recorded launch plan (bnn_amd.graphs.LaunchPlan: the forward's C calls -- flows + weight pass, GEMM 1 with the KL "
+                                   "finalize riding, GEMM 2 with the head folded in + its finalize: 5 kernels -- replayed from a list)",
+                           "graph": "one HIP-graph replay per step", "eager": "5 launches per step from Python"}[main_leg["launch"]],
+                "launch_fallback_reason": main_leg["launch_fallback_reason"],
+                "config": {"workload": "LBBNN-GP-MF-MNF 784-1200-1200-10, 2 planar flows/layer, batch %d per GPU, "
+                                       "training-mode ELBO forward (activations + log_softmax + kl), in-kernel Philox noise" % B,
+                           "global_batch": B * world, "parallelism": "dp%d (replicated parameters, no forward collective)" % world},
+                "gflop_per_step_algorithmic": 4.0 * B * sum_io / 1e9,
+                "settle": main_leg["settle"], "timed_attempts": main_leg["attempts"],
+                "ranks": ranks,
+            }
+            step_stats(res, main_leg["per_step"])
+            if main_leg["events"]:
+                roof, why = roofline_object(main_leg["events"], args.precision, res["ms_per_step"], sampled_in)
+                if roof is not None:
+                    res["roofline"] = roof
+                else:
+                    res["roofline_invalid"] = why
+            if "fp32" in legs and args.precision != "fp32":
+                leg = legs["fp32"]
+                sec = {"dtype": "f32", "what": "the same step with the exact-fp32 MFMA GEMM (reference precision), same process",
+                       "value": total / leg["elapsed"], "unit": "samples/s", "steps": args.steps,
+                       "ms_per_step": leg["elapsed"] / args.steps * 1e3, "settle": leg["settle"],
+                       "timed_attempts": leg["attempts"]}
+                step_stats(sec, leg["per_step"])
+                if leg["events"]:
+                    roof, why = roofline_object(leg["events"], "fp32", sec["ms_per_step"], sampled_in)
+                    if roof is not None:
+                        sec["roofline"] = roof
+                    else:
+                        sec["roofline_invalid"] = why
+                res["secondary"] = sec
+            if "fp16x3" in legs and args.precision != "fp16x3":
+                leg = legs["fp16x3"]
+                st3 = {"dtype": DTYPE_OF["fp16x3"], "precision": "fp16x3",
+                       "what": "the same step with 3 + 3 products (2-3e-8 of max|out| against fp64: tighter than an fp32-accumulate "
+                               "torch.mm), same process",
+                       "value": total / leg["elapsed"], "unit": "samples/s", "steps": args.steps,
+                       "ms_per_step": leg["elapsed"] / args.steps * 1e3, "settle": leg["settle"], "timed_attempts": leg["attempts"]}
+                step_stats(st3, leg["per_step"])
+                if leg["events"]:
+                    roof, why = roofline_object(leg["events"], "fp16x3", st3["ms_per_step"], sampled_in)
+                    if roof is not None:
+                        st3["roofline"] = roof
+                    else:
+                        st3["roofline_invalid"] = why
+                res["secondary_strict_fp16x3"] = st3
+            if "bf16" in legs:
+                leg = legs["bf16"]
+                red = {"dtype": "bf16 (ONE product per moment)",
+                       "what": "REDUCED PRECISION, outside the 1e-4 contract (2e-3 relative on the mean GEMM): the plain bf16 MFMA "
+                               "arithmetic BASELINE configs[1] names, same step, same process; not comparable with `value`",
+                       "value": total / leg["elapsed"], "unit": "samples/s", "steps": args.steps,
+                       "ms_per_step": leg["elapsed"] / args.steps * 1e3, "settle": leg["settle"],
+                       "timed_attempts": leg["attempts"]}
+                step_stats(red, leg["per_step"])
+                if leg["events"]:
+                    roof, why = roofline_object(leg["events"], "bf16", red["ms_per_step"], sampled_in)
+                    if roof is not None:
+                        roof["executed_mfma_tflops"] = roof["achieved"]
+                        roof["note"] = "achieved = ALGORITHMIC 4*B*I*O flop per launch / HIP-event time; one bf16 product per algorithmic product"
+                        roof["traffic"], roof["traffic_source"] = None, None
+                        red["roofline"] = roof
+                    else:
+                        red["roofline_invalid"] = why
+                res["secondary_reduced_bf16"] = red
+            if strong is not None:
+                st = {"what": "STRONG scaling: the headline's global batch of %d rows split over the %d ranks (%d rows each), same step"
+                              % (B, world, B // world),
+                      "scaling": "strong", "global_batch": B, "value": B * args.steps / strong["elapsed"], "unit": "samples/s",
+                      "steps": args.steps, "ms_per_step": strong["elapsed"] / args.steps * 1e3, "settle": strong["settle"],
+                      "timed_attempts": strong["attempts"]}
+                step_stats(st, strong["per_step"])
+                res["secondary_strong"] = st
+            if train is not None:
+                if world > 1 and backend == "nccl":
+                    train["rccl"] = rccl_log_summary(os.environ.get("NCCL_DEBUG_FILE"))
+                res["secondary_train"] = train
+            if world == 1 and not args.no_cpu_baseline:
+                res["cpu_baseline"] = cpu_baseline(B, args.cpu_seconds)
+                res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
+            print(json.dumps(res), flush=True)
+
+    # The training leg is the only part of the run with a data-path collective (the gradient all-reduce): it runs LAST, behind a
+    # watchdog, so that neither an exception on one rank nor a collective that never returns can take the headline with it --
+    # after --train-timeout seconds rank 0 prints the line with the reason in place of the leg and every rank leaves with 0.
     train = None
     if want_train:
-        train = train_leg(args, bnn_amd, net, x, sync, world, rank)
+        import threading
 
-    if rank == 0:
-        sum_io = sum(DIMS[i] * DIMS[i + 1] for i in range(3))
-        main_leg = legs[args.precision]
-        elapsed = main_leg["elapsed"]
-        total = B * world * args.steps
-        sampled_in = "separate eager pass after the timed region (every GEMM launch bracketed by HIP events)"
-        res = {
-            "metric": "ELBO forward samples/sec, 784-1200^2-10 MNF MLP, batch 4096 per GPU",
-            "value": total / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": DTYPE_OF[args.precision], "precision": args.precision,
-            "data": "synthetic", "hip_graph": main_leg["launch"] == "graph",
-            "launch": {"plan": "recorded launch plan (bnn_amd.graphs.LaunchPlan: the forward's C calls -- flows + weight pass, GEMM 1 with the KL "
-                               "finalize riding, GEMM 2 with the head folded in + its finalize: 5 kernels -- replayed from a list)",
-                       "graph": "one HIP-graph replay per step", "eager": "5 launches per step from Python"}[main_leg["launch"]],
-            "launch_fallback_reason": main_leg["launch_fallback_reason"],
-            "config": {"workload": "LBBNN-GP-MF-MNF 784-1200-1200-10, 2 planar flows/layer, batch %d per GPU, "
-                                   "training-mode ELBO forward (activations + log_softmax + kl), in-kernel Philox noise" % B,
-                       "global_batch": B * world, "parallelism": "dp%d (replicated parameters, no forward collective)" % world},
-            "gflop_per_step_algorithmic": 4.0 * B * sum_io / 1e9,
-            "settle": main_leg["settle"], "timed_attempts": main_leg["attempts"],
-            "ranks": ranks,
-        }
-        step_stats(res, main_leg["per_step"])
-        if main_leg["events"]:
-            roof, why = roofline_object(main_leg["events"], args.precision, res["ms_per_step"], sampled_in)
-            if roof is not None:
-                res["roofline"] = roof
-            else:
-                res["roofline_invalid"] = why
-        if "fp32" in legs and args.precision != "fp32":
-            leg = legs["fp32"]
-            sec = {"dtype": "f32", "what": "the same step with the exact-fp32 MFMA GEMM (reference precision), same process",
-                   "value": total / leg["elapsed"], "unit": "samples/s", "steps": args.steps,
-                   "ms_per_step": leg["elapsed"] / args.steps * 1e3, "settle": leg["settle"],
-                   "timed_attempts": leg["attempts"]}
-            step_stats(sec, leg["per_step"])
-            if leg["events"]:
-                roof, why = roofline_object(leg["events"], "fp32", sec["ms_per_step"], sampled_in)
-                if roof is not None:
-                    sec["roofline"] = roof
-                else:
-                    sec["roofline_invalid"] = why
-            res["secondary"] = sec
-        if "fp16x3" in legs and args.precision != "fp16x3":
-            leg = legs["fp16x3"]
-            st3 = {"dtype": DTYPE_OF["fp16x3"], "precision": "fp16x3",
-                   "what": "the same step with 3 + 3 products (2-3e-8 of max|out| against fp64: tighter than an fp32-accumulate "
-                           "torch.mm), same process",
-                   "value": total / leg["elapsed"], "unit": "samples/s", "steps": args.steps,
-                   "ms_per_step": leg["elapsed"] / args.steps * 1e3, "settle": leg["settle"], "timed_attempts": leg["attempts"]}
-            step_stats(st3, leg["per_step"])
-            if leg["events"]:
-                roof, why = roofline_object(leg["events"], "fp16x3", st3["ms_per_step"], sampled_in)
-                if roof is not None:
-                    st3["roofline"] = roof
-                else:
-                    st3["roofline_invalid"] = why
-            res["secondary_strict_fp16x3"] = st3
-        if "bf16" in legs:
-            leg = legs["bf16"]
-            red = {"dtype": "bf16 (ONE product per moment)",
-                   "what": "REDUCED PRECISION, outside the 1e-4 contract (2e-3 relative on the mean GEMM): the plain bf16 MFMA "
-                           "arithmetic BASELINE configs[1] names, same step, same process; not comparable with `value`",
-                   "value": total / leg["elapsed"], "unit": "samples/s", "steps": args.steps,
-                   "ms_per_step": leg["elapsed"] / args.steps * 1e3, "settle": leg["settle"],
-                   "timed_attempts": leg["attempts"]}
-            step_stats(red, leg["per_step"])
-            if leg["events"]:
-                roof, why = roofline_object(leg["events"], "bf16", red["ms_per_step"], sampled_in)
-                if roof is not None:
-                    roof["executed_mfma_tflops"] = roof["achieved"]
-                    roof["note"] = "achieved = ALGORITHMIC 4*B*I*O flop per launch / HIP-event time; one bf16 product per algorithmic product"
-                    roof["traffic"], roof["traffic_source"] = None, None
-                    red["roofline"] = roof
-                else:
-                    red["roofline_invalid"] = why
-            res["secondary_reduced_bf16"] = red
-        if strong is not None:
-            st = {"what": "STRONG scaling: the headline's global batch of %d rows split over the %d ranks (%d rows each), same step"
-                          % (B, world, B // world),
-                  "scaling": "strong", "global_batch": B, "value": B * args.steps / strong["elapsed"], "unit": "samples/s",
-                  "steps": args.steps, "ms_per_step": strong["elapsed"] / args.steps * 1e3, "settle": strong["settle"],
-                  "timed_attempts": strong["attempts"]}
-            step_stats(st, strong["per_step"])
-            res["secondary_strong"] = st
-        if train is not None:
-            if world > 1 and backend == "nccl":
-                train["rccl"] = rccl_log_summary(os.environ.get("NCCL_DEBUG_FILE"))
-            res["secondary_train"] = train
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(B, args.cpu_seconds)
-            res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
-        print(json.dumps(res), flush=True)
+        def on_timeout():
+            if rank == 0:
+                emit({"error": "the training leg did not finish within %d s (rank 0 gave up; headline legs unaffected)" % args.train_timeout})
+            os._exit(0)
+
+        guard = threading.Timer(args.train_timeout, on_timeout)
+        guard.daemon = True
+        guard.start()
+        try:
+            train = train_leg(args, bnn_amd, net, x, sync, world, rank)
+        except Exception as e:                                   # noqa: BLE001 -- reported in the line; the other ranks' watchdogs end them
+            guard.cancel()
+            if rank == 0:
+                emit({"error": "%s: %s" % (type(e).__name__, str(e)[:300])})
+            os._exit(0)
+        guard.cancel()
+    emit(train)
     if world > 1:
         dist.destroy_process_group()
 

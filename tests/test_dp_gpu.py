@@ -182,3 +182,22 @@ def test_bench_gpus2_self_spawned_ranks_report_themselves():
     assert rk["all_reduce_of_ones"] == 2.0
     assert rk["backend"] in ("gloo", "nccl")
     assert "secondary_train" in d and d["secondary_train"]["value"] > 0        # the training leg (collective included) ran
+
+
+@pytest.mark.gpu
+def test_bench_training_leg_watchdog_keeps_the_headline():
+    """The training leg (the only part of a bench run with a data-path collective) runs last, behind a watchdog: with
+    --train-timeout 0 the watchdog fires at once -- rank 0 still prints exactly one line, the forward headline is in it,
+    the leg's place holds the reason, and every process leaves with 0 (two self-spawned ranks: the other rank's own
+    watchdog ends it)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                        "--no-secondary", "--no-kernel-events", "--train-timeout", "0"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    _keep("bench_train_watchdog", r)
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["ranks"]["world"] == 2
+    assert "did not finish" in d["secondary_train"]["error"]
