@@ -2,7 +2,7 @@ import os, sys, torch
 sys.path.insert(0, ".")
 import bnn_amd
 dev = torch.device("cuda:0")
-bnn_amd.set_precision("bf16x3")
+bnn_amd.set_precision(os.environ.get("PREC", "fp16x3f"))
 torch.manual_seed(0)
 FLOW = os.environ.get("FLOW", "Planar")       # Planar (headline) | RNVP (reference default) | MNF
 net = bnn_amd.mnf.BayesianNetwork((784, 1200, 1200, 10), 2, z_flow_type=FLOW, r_flow_type=FLOW).to(dev).train()
@@ -28,3 +28,5 @@ print("train-set accuracy of the posterior-mean network after 2000 graphed steps
 for n_, p in net.named_parameters():
     assert torch.isfinite(p).all(), n_
 print("all parameters finite; rng offset:", int(bnn_amd.ops.RngState.get(dev).t[1]))
+print("precision %s, flows %s, device memory allocated %.0f MB (max %.0f MB)" % (bnn_amd.get_precision(), FLOW, torch.cuda.memory_allocated() / 2 ** 20,
+                                                                                 torch.cuda.max_memory_allocated() / 2 ** 20))
