@@ -55,8 +55,12 @@ for it in range(SEEDS):
     # conditioning of the r0_c gradient: element-wise max-norm error relative to the LARGEST entry, so what matters is how much
     # the largest entry itself cancels
     gr = pc["r0_c"].grad
-    print("seed %2d  worst %-22s %.2e   r0_c err %.2e  |dr0_c| = %s" % (it, k, errs[k], errs.get("r0_c", 0.0),
-          ["%.2e" % float(v) for v in gr.abs()]))
+    # ... and of the auxiliary mean m = mean_o tanh(act_mu + sqrt(act_var) eps) (LBBNN-GP-MF-MNF.py:218-221): the gradients of
+    # r0_b1 / r0_b2 are proportional to it, so their relative error is the relative error of a sum of O tanh values
+    ai = (aux["act_mu"] + aux["act_var"].sqrt() * noise["eps_act"].double()).detach()
+    cond_m = float(torch.tanh(ai).abs().mean() / torch.tanh(ai).mean().abs().clamp_min(1e-300))
+    print("seed %2d  worst %-22s %.2e   r0_c err %.2e  r0_b2 err %.2e  cond(m) %.1e  |dr0_c| = %s" % (
+          it, k, errs[k], errs.get("r0_c", 0.0), errs.get("r0_b2", 0.0), cond_m, ["%.2e" % float(v) for v in gr.abs()][:4]))
 print("worst per parameter over %d seeds:" % SEEDS)
 for n, v in sorted(worst.items(), key=lambda kv: -kv[1])[:8]:
     print("  %-28s %.2e" % (n, v))

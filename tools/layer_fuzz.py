@@ -24,7 +24,7 @@ for it in range(N):
     I = random.choice([5, 8, 33, 64, 100, 200, 257, 784, 1201])
     O = random.choice([1, 7, 10, 17, 40, 64, 130])
     T = random.choice([1, 2, 3])
-    prec = random.choice(["fp32", "bf16x3"])
+    prec = random.choice(["fp32", "bf16x3", "fp16x3", "fp16x3f"])      # (shapes a 16-bit format does not take run the fp32 kernels)
     relu = random.random() < 0.5
     bnn_amd.set_precision(prec)
     torch.manual_seed(it)
