@@ -391,11 +391,13 @@ __global__ __launch_bounds__(kVecThreads) void mnf_flow_planar_vec_kernel(const 
     if (on) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float ev = expf(lvv[c]);
-            z0[c] = qmv[c] + sqrtf(ev) * e[c];                                                   // ...MNF.py:183-185
+            // (hardware exp2 with the product's residual put back, v_sqrt_f32, v_rcp_f32: ~1 ulp each, a quarter of the
+            // instructions of expf / sqrtf / a true division on this kernel's one critical chain)
+            const float ev = k1_exp_acc(lvv[c]);
+            z0[c] = qmv[c] + sqrt_hw(ev) * e[c];                                                 // ...MNF.py:183-185
             if (klblk) {
                 const float d = z0[c] - qmv[c];
-                acc[NV - 1] += -0.5f * 1.1447298858494002f - 0.5f * lvv[c] - 0.5f * ((d * d) / ev);   // :213-214
+                acc[NV - 1] += -0.5f * 1.1447298858494002f - 0.5f * lvv[c] - 0.5f * ((d * d) * __builtin_amdgcn_rcpf(ev));   // :213-214
             }
         }
         const float4 z4 = make_float4(z0[0], z0[1], z0[2], z0[3]);
@@ -415,14 +417,19 @@ __global__ __launch_bounds__(kVecThreads) void mnf_flow_planar_vec_kernel(const 
 #pragma unroll
         for (int k = 0; k < NV; ++k) red[k][wv] = acc[k];
     __syncthreads();
-    double tot[NV];
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
+    // the NW partials of every sum combined ONCE (threads 0 .. NV-1, double, fixed order), then read by everyone: the first
+    // version had every thread add all NV x NW values itself (120 LDS reads + 120 double additions on the critical chain)
+    __shared__ double tots[NV];
+    if (tid < NV) {
         double t2 = 0.0;
 #pragma unroll
-        for (int w2 = 0; w2 < NW; ++w2) t2 += (double)red[k][w2];
-        tot[k] = t2;
+        for (int w2 = 0; w2 < NW; ++w2) t2 += (double)red[tid][w2];
+        tots[tid] = t2;
     }
+    __syncthreads();
+    double tot[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) tot[k] = tots[k];
     // scalar chain (flows2.py:87-95), every thread redundantly
     float th[kFastT], ld_q = 0.f, ld_r = 0.f;
     {
@@ -435,7 +442,7 @@ __global__ __launch_bounds__(kVecThreads) void mnf_flow_planar_vec_kernel(const 
             th[t] = 0.f;
             if (t < NT) {
                 th[t] = tanh_fast((float)inner + bias[t]);
-                const float ld = logf(fabsf(1.f + (1.f - th[t] * th[t]) * (float)tot[kFastT + t]));
+                const float ld = 0.6931471805599453f * __builtin_amdgcn_logf(fabsf(1.f + (1.f - th[t] * th[t]) * (float)tot[kFastT + t]));
                 if (t < Tz) ld_q += ld; else ld_r += ld;
             }
         }
