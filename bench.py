@@ -22,12 +22,16 @@ How the number is taken (round 2; the round-1 line did not reproduce under the d
      state: blocks of 25 steps run back to back (no synchronisation between them) until the last
      4 block times agree within 2 % or 0.5 s has passed ("settle" in the JSON) -- a fresh GPU needs
      tens of milliseconds to reach its clocks, far longer than 5 warm-up steps.
-  2. the timed region: barrier + synchronize, EXACTLY K steps, barrier + synchronize; MAX over
-     ranks; ms_per_step = elapsed / K.  One pre-created, pre-recorded HIP event marks each step
-     boundary inside the region (ms_per_step_median/min/max: an outlier step is visible).  A region
-     in which one step took > 10x the median step (a single ~40 ms stall hits a run on this pool
-     now and then, whatever is running) is timed again, at most twice; every attempt is listed in
-     "timed_attempts" and the reported one is the first without such a step.
+  2. the timed region: barrier + synchronize, EXACTLY K steps enqueued back to back with nothing
+     between them, barrier + synchronize; MAX over ranks; ms_per_step = elapsed / K.  Nothing slow
+     sits between the settle phase and the region (events come from a pool made beforehand, the
+     collector is off): an idle GPU drops its clocks within milliseconds.  The per-step distribution
+     (ms_per_step_median/min/max: an outlier step is visible) comes from a SEPARATE pass of the same
+     K steps with one event per step boundary (an event record is a barrier packet: ~3 us per step
+     when it sat inside the region, as it did until late in round 3).  A region whose mean step is
+     > 2x the settled step (a single ~40 ms stall hits a run on this pool now and then, whatever is
+     running) is timed again, at most twice; every attempt is listed in "timed_attempts" and the
+     reported one is the first without a stall.
   3. AFTER the timed region, a separate pass brackets every GEMM launch with HIP events on the
      launch stream ("roofline", sampled_in = "separate pass after the timed region").  A roofline
      that contradicts the timed region (share of step > 1, launch longer than a step) is not
@@ -230,6 +234,17 @@ def _recorded_events(n):
     return evs
 
 
+_EVENT_POOL = []
+
+
+def _event_pool(n):
+    """n recorded timing events from a pool that only grows: no event is created (and no device synchronisation made)
+    between a settle phase and its timed region after the first region of the process."""
+    if len(_EVENT_POOL) < n:
+        _EVENT_POOL.extend(_recorded_events(n - len(_EVENT_POOL)))
+    return _EVENT_POOL[:n]
+
+
 def settle(run_step, world=1):
     """Warm-up to steady state.  Blocks of SETTLE_BLOCK steps are enqueued back to back with one event between blocks;
     the host only ever waits for the block BEFORE the one it has just enqueued, so the GPU queue never drains (a
@@ -271,21 +286,30 @@ STALL_FACTOR = 10.0     # a step this many times longer than the region's median
 MAX_ATTEMPTS = 3
 
 
-def timed_region(run_step, steps, sync, step_events, attempts=None, world=1):
-    """The timed region, repeated (at most MAX_ATTEMPTS times) while a step inside it took more than STALL_FACTOR x the
-    region's median step.  Why: on this pool a single ~40 ms stall hits a run now and then -- round 1's driver line
-    (37 ms inside one GEMM launch's bracket, every other step normal) and a round-2 run of the fp32 leg (48 ms for 20
-    steps that take 7.7) -- unrelated to the step being timed.  Every attempt is listed in the JSON line
-    ("timed_attempts"); the reported value is the first attempt without such a step (the last one if all have one).
+STALL_REGION = 2.0      # a timed region whose mean step is this many times the settled step contains an external stall
+
+
+def timed_region(run_step, steps, sync, step_events, attempts=None, world=1, steady_ms=None):
+    """The timed region: barrier + synchronize, EXACTLY `steps` steps enqueued back to back with NOTHING between them,
+    barrier + synchronize.  (Until late in round 3 one HIP event marked every step boundary inside the region: an event
+    record is a barrier packet on this stack, and the ~3 us bubble behind each of them was 2-3 % of a 0.125 ms step.  The
+    per-step distribution now comes from a SEPARATE instrumented pass after the region: "ms_per_step_median/min/max".)
+    The region is repeated (at most MAX_ATTEMPTS times) while its mean step is more than STALL_REGION x the settled step of
+    the settle phase, or -- in the instrumented pass -- a step took more than STALL_FACTOR x the median.  Why: on this pool a
+    single ~40 ms stall hits a run now and then (round 1's driver line: 37 ms inside one GEMM launch's bracket; a round-2 run
+    of the fp32 leg: 48 ms for 20 steps that take 7.7), unrelated to the step being timed.  Every attempt is listed in the
+    JSON line ("timed_attempts"); the reported value is the first attempt without a stall (the last one if all have one).
     With N > 1 all ranks must agree on repeating: the decision is all-reduced (MAX)."""
     while True:
-        elapsed, per_step = _timed_region_once(run_step, steps, sync, step_events)
-        stalled = False
+        elapsed, _ = _timed_region_once(run_step, steps, sync, False)
         rec = {"ms_per_step": elapsed / steps * 1e3}
-        if per_step:
+        stalled = bool(steady_ms and rec["ms_per_step"] > STALL_REGION * steady_ms)
+        per_step = None
+        if step_events:
+            _, per_step = _timed_region_once(run_step, steps, sync, True)         # the separate, instrumented pass
             srt = sorted(per_step)
             rec["max_step_ms"], rec["median_step_ms"] = srt[-1], srt[len(srt) // 2]
-            stalled = srt[-1] > STALL_FACTOR * srt[len(srt) // 2]
+            rec["step_stats_from"] = "a separate pass of the same %d steps with one event per step boundary" % steps
         if world > 1:
             import torch.distributed as dist
             flag = torch.tensor([1.0 if stalled else 0.0], device="cuda")
@@ -300,7 +324,12 @@ def timed_region(run_step, steps, sync, step_events, attempts=None, world=1):
 
 def _timed_region_once(run_step, steps, sync, step_events):
     """barrier + synchronize, EXACTLY ``steps`` steps, barrier + synchronize.  Returns (elapsed seconds, per-step ms)."""
-    marks = _recorded_events(steps + 1) if step_events else None
+    # Nothing slow may sit between the end of the settle phase and the timed steps: a GPU left idle for milliseconds drops its
+    # clocks and 20 steps (2.5 ms) are over before it has them back (measured: a gc.collect() placed here cost the line 10 %).
+    # The events are made once, ahead of the first timed region of the process; the collector is off inside the region.
+    marks = _event_pool(steps + 1) if step_events else None
+    import gc
+    gc.disable()
     sync()
     t0 = time.perf_counter()
     if marks is not None:
@@ -313,6 +342,7 @@ def _timed_region_once(run_step, steps, sync, step_events):
             run_step()
     sync()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)] if marks is not None else None
     return elapsed, per_step
 
@@ -435,9 +465,12 @@ def forward_leg(args, bnn_amd, ops, net, x, sync, precision, world):
             sync()                         # during a capture) must not cost the run: the leg is launched from Python, and says so
             run = step
             leg["launch_fallback_reason"] = "%s: %s" % (type(exc).__name__, str(exc)[:200])
+        if not args.no_step_events:
+            _event_pool(args.steps + 1)                      # (made before the settle phase, not between it and the timed region)
         leg["settle"] = settle(run, world)
         leg["attempts"] = []
-        elapsed, per_step = timed_region(run, args.steps, sync, not args.no_step_events, leg["attempts"], world)
+        elapsed, per_step = timed_region(run, args.steps, sync, not args.no_step_events, leg["attempts"], world,
+                                         steady_ms=leg["settle"]["last_blocks_ms_per_step"][-1])
         if leg["launch"] == "eager":
             out, kl = step()
         sync()
@@ -487,10 +520,13 @@ def train_leg(args, bnn_amd, net, x, sync, world, rank):
     for _ in range(max(3, min(args.warmup, 10))):
         step()
     sync()
-    st = settle(step, world)
     steps = max(5, min(args.steps, 50))
+    if not args.no_step_events:
+        _event_pool(steps + 1)
+    st = settle(step, world)
     attempts = []
-    elapsed, per_step = timed_region(step, steps, sync, not args.no_step_events, attempts, world)
+    elapsed, per_step = timed_region(step, steps, sync, not args.no_step_events, attempts, world,
+                                     steady_ms=st["last_blocks_ms_per_step"][-1])
     loss = step()
     sync()
     assert torch.isfinite(loss)
