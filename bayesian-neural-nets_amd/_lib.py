@@ -262,6 +262,7 @@ SIGNATURES = {
     "lbbnn_philox_normal": (c_i, [c_p, c_u32, c_i64, c_i64, c_i64, c_p, c_p]),
     "lbbnn_elbo_loss": (c_i, [c_p, c_i, c_p, c_i, c_i, c_p, ctypes.c_float, c_p, c_p]),
     "lbbnn_elbo_loss_backward": (c_i, [c_p, c_p, c_i, c_i, ctypes.c_float, c_p, c_p, c_p]),
+    "lbbnn_elbo_loss_backward_logits": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, ctypes.c_float, c_p, c_p, c_p, c_p]),
     "lbbnn_log_softmax_backward": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_p]),
     "lbbnn_log_softmax_rows": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_p]),
 }

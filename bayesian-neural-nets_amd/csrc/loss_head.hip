@@ -36,6 +36,24 @@ __global__ __launch_bounds__(256) void elbo_loss_backward_kernel(const float* g,
     if (g_kl && blockIdx.x == 0 && threadIdx.x == 0) *g_kl = gv * kl_scale;
 }
 
+// ... and, in the same launch, what lbbnn_log_softmax_backward makes of that gradient when the log-probabilities are the
+// log_softmax of a layer's logits (the fused head of the training forward): g_logits = g_logp - exp(logp) * sum_c g_logp, with
+// the row sum being -g exactly.  Same expression, same order: bitwise the two-launch result.
+__global__ __launch_bounds__(256) void elbo_loss_backward_logits_kernel(const float* g, const int64_t* __restrict__ target,
+                                                                        const float* __restrict__ logp, int ldp, int B, int C,
+                                                                        float kl_scale, float* g_logp, float* g_logits, float* g_kl) {
+    const float gv = *g;
+    const float s = -gv;
+    const int n = B * C;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int b = i / C, c = i - b * C;
+        const float gl = (target[b] == c) ? -gv : 0.f;
+        g_logp[i] = gl;
+        g_logits[i] = gl - expf(logp[(size_t)b * ldp + c]) * s;
+    }
+    if (g_kl && blockIdx.x == 0 && threadIdx.x == 0) *g_kl = gv * kl_scale;
+}
+
 // thread per row (C <= 64)
 __global__ __launch_bounds__(256) void log_softmax_backward_kernel(const float* __restrict__ g, int ldg, const float* __restrict__ logp,
                                                                    int ldp, float* out, int ldo, int B, int C) {
@@ -64,6 +82,16 @@ extern "C" int lbbnn_elbo_loss_backward(const float* g, const int64_t* target, i
     const int blocks = (B * C + 255) / 256 < 512 ? (B * C + 255) / 256 : 512;
     hipLaunchKernelGGL(elbo_loss_backward_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), g, target, B, C,
                        kl_scale, g_logp, g_kl);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lbbnn_elbo_loss_backward_logits(const float* g, const int64_t* target, const float* logp, int ldp, int B, int C,
+                                               float kl_scale, float* g_logp, float* g_logits, float* g_kl, void* stream) {
+    if (!g || !target || !logp || !g_logp || !g_logits) return LBBNN_E_NULL;
+    if (B <= 0 || C <= 0 || ldp < C) return LBBNN_E_SHAPE;
+    const int blocks = (B * C + 255) / 256 < 512 ? (B * C + 255) / 256 : 512;
+    hipLaunchKernelGGL(elbo_loss_backward_logits_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), g, target,
+                       logp, ldp, B, C, kl_scale, g_logp, g_logits, g_kl);
     return (int)hipGetLastError();
 }
 

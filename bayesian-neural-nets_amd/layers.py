@@ -249,7 +249,12 @@ class _BayesLinearFn(torch.autograd.Function):
         # forward's Philox state inside the kernel unless explicit draws were given
         explicit = ctx.saved.get("noise") or {}
         if ctx.saved.get("lsm"):
-            g_out = ops.log_softmax_backward(g_out, out)              # grad wrt log-probabilities -> grad wrt the logits
+            from . import losses
+            ent = losses._LOGITS_GRAD.pop(out.data_ptr(), None)
+            if ent is not None and ent[0] == g_out.data_ptr():
+                g_out = ent[1]                                        # formed by the loss's own backward launch (losses._LOGITS_GRAD)
+            else:
+                g_out = ops.log_softmax_backward(g_out, out)          # grad wrt log-probabilities -> grad wrt the logits
         planar = layer._mnf and layer._check_flows() == "planar"
         dense = layer._mnf and ctx.saved.get("dense_save") is not None
         # With the vector chains deferred (they are the only readers of the column sums Sum_b G_m / G_v, dz_k, dz_2, dr0_c)

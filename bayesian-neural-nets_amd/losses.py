@@ -9,33 +9,53 @@ is the faster one for callers that want it (``bnn_amd.parallel.DataParallelELBO.
 import torch
 import torch.nn.functional as F
 
+import os as _os
+
 from . import _lib
+
+_FUSE_LSM_BWD = _os.environ.get("LBBNN_FUSE_LSM_BWD", "1") != "0"     # A/B knob
+
+
+# Hand-over from the loss's backward to the head layer's backward: when the log-probabilities came out of a layer's fused
+# log_softmax, the loss backward forms the gradient with respect to the LOGITS in its own launch
+# (lbbnn_elbo_loss_backward_logits) and leaves it here under the log-probabilities' address; the layer's backward takes it if
+# the gradient it receives is the very tensor the loss returned, instead of launching lbbnn_log_softmax_backward.
+_LOGITS_GRAD = {}
 
 
 class _ElboLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, log_probs, target, kl, scale):
         B, C = log_probs.shape
+        _LOGITS_GRAD.clear()                       # entries live for one backward pass only
         lp = log_probs if log_probs.stride(1) == 1 else log_probs.contiguous()
         loss = torch.empty((), dtype=torch.float32, device=lp.device)
         stream = torch.cuda.current_stream(lp.device).cuda_stream
         _lib.check(_lib.lib().lbbnn_elbo_loss(lp.data_ptr(), lp.stride(0), target.data_ptr(), B, C,
                                               kl.data_ptr() if kl is not None else None, float(scale), loss.data_ptr(), stream),
                    "lbbnn_elbo_loss")
-        ctx.save_for_backward(target)
+        ctx.save_for_backward(target, lp)
         ctx.meta = (B, C, float(scale), kl is not None)
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        (target,) = ctx.saved_tensors
+        target, lp = ctx.saved_tensors
         B, C, scale, has_kl = ctx.meta
         g = g.contiguous()
         g_logp = torch.empty((B, C), dtype=torch.float32, device=g.device)
         g_kl = torch.empty((), dtype=torch.float32, device=g.device) if has_kl else None
         stream = torch.cuda.current_stream(g.device).cuda_stream
-        _lib.check(_lib.lib().lbbnn_elbo_loss_backward(g.data_ptr(), target.data_ptr(), B, C, scale, g_logp.data_ptr(),
-                                                       g_kl.data_ptr() if has_kl else None, stream), "lbbnn_elbo_loss_backward")
+        if _FUSE_LSM_BWD and C <= 64:
+            g_logits = torch.empty((B, C), dtype=torch.float32, device=g.device)
+            _lib.check(_lib.lib().lbbnn_elbo_loss_backward_logits(g.data_ptr(), target.data_ptr(), lp.data_ptr(), lp.stride(0), B, C,
+                                                                  scale, g_logp.data_ptr(), g_logits.data_ptr(),
+                                                                  g_kl.data_ptr() if has_kl else None, stream),
+                       "lbbnn_elbo_loss_backward_logits")
+            _LOGITS_GRAD[lp.data_ptr()] = (g_logp.data_ptr(), g_logits)
+        else:
+            _lib.check(_lib.lib().lbbnn_elbo_loss_backward(g.data_ptr(), target.data_ptr(), B, C, scale, g_logp.data_ptr(),
+                                                           g_kl.data_ptr() if has_kl else None, stream), "lbbnn_elbo_loss_backward")
         return g_logp, None, g_kl, None
 
 

@@ -846,6 +846,10 @@ int lbbnn_elbo_loss(const float* logp, int ldp, const int64_t* target, int B, in
                     float* loss, void* stream);
 int lbbnn_elbo_loss_backward(const float* g, const int64_t* target, int B, int C, float kl_scale, float* g_logp, float* g_kl,
                              void* stream);
+/* lbbnn_elbo_loss_backward and, in the same launch, the gradient with respect to the LOGITS when `logp` is the log_softmax of a
+ * layer's logits (what lbbnn_log_softmax_backward would make of g_logp: bitwise the same): g_logits (B,C dense). */
+int lbbnn_elbo_loss_backward_logits(const float* g, const int64_t* target, const float* logp, int ldp, int B, int C,
+                                    float kl_scale, float* g_logp, float* g_logits, float* g_kl, void* stream);
 int lbbnn_log_softmax_backward(const float* g, int ldg, const float* logp, int ldp, float* out, int ldo, int B, int C,
                                void* stream);
 

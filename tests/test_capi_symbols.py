@@ -173,3 +173,6 @@ def test_round3_entry_points_argument_checks(lib):
     assert lib.lbbnn_mnf_aux_backward_batch(None, 1, None) == -1
     assert lib.lbbnn_mnf_aux_backward_batch((_lib.AuxBwdArgs * 1)(), 5, None) == -2
     assert lib.lbbnn_mnf_aux_backward_batch((_lib.AuxBwdArgs * 1)(), 1, None) == -1
+    # lbbnn_elbo_loss_backward_logits
+    assert lib.lbbnn_elbo_loss_backward_logits(fake, fake, None, 10, 4, 10, ctypes.c_float(0.1), fake, fake, None, None) == -1
+    assert lib.lbbnn_elbo_loss_backward_logits(fake, fake, fake, 8, 4, 10, ctypes.c_float(0.1), fake, fake, None, None) == -2

@@ -2774,3 +2774,38 @@ def test_batched_v1_from_the_kl_sum_backward_is_bitwise_the_per_layer_one(bnn, d
     for n in grads["batch"]:
         assert torch.equal(grads["batch"][n], grads["per_layer"][n]), n
         assert rel_err(grads["manual_kl"][n], grads["per_layer"][n]) < 1e-6, n
+
+
+def test_loss_backward_hands_the_logits_gradient_to_the_head(bnn, dev, monkeypatch):
+    """lbbnn_elbo_loss_backward_logits: with bnn_amd.elbo_loss on a training forward whose head has its log_softmax fused, the
+    loss's backward launch also forms the gradient with respect to the logits and the head's backward takes it instead of
+    launching lbbnn_log_softmax_backward: every parameter gradient bitwise the same as with the two launches; the reference's
+    own spelling of the loss (F.nll_loss + kl / N) keeps taking the separate launch."""
+    from bnn_amd import losses, ops
+    grads, calls = {}, {True: 0, False: 0, "torch": 0}
+    real = ops.log_softmax_backward
+    for mode in (True, False, "torch"):
+        monkeypatch.setattr(losses, "_FUSE_LSM_BWD", mode is True)
+
+        def counted(*a, _m=mode, **k):
+            calls[_m] += 1
+            return real(*a, **k)
+        monkeypatch.setattr(ops, "log_softmax_backward", counted)
+        bnn.manual_seed(5, 0)
+        torch.manual_seed(5)
+        net = bnn.mnf.BayesianNetwork((784, 48, 32, 10), 2, z_flow_type="Planar", r_flow_type="Planar").to(dev).train()
+        xg = torch.Generator().manual_seed(1)
+        x = torch.rand(256, 784, generator=xg).to(dev)
+        y = torch.randint(0, 10, (256,), generator=xg).to(dev)
+        out = net(x, sample=True)
+        if mode == "torch":
+            loss = torch.nn.functional.nll_loss(out, y, reduction="sum") + net.kl() / 10
+        else:
+            loss = bnn.elbo_loss(out, y, net.kl(), 10)
+        loss.backward()
+        grads[mode] = {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+        del loss, out
+    assert calls == {True: 0, False: 1, "torch": 1}, calls                # the hand-over happened exactly where it should
+    for n in grads[True]:
+        assert torch.equal(grads[True][n], grads[False][n]), n
+        assert rel_err(grads["torch"][n], grads[False][n]) < 1e-5, n
