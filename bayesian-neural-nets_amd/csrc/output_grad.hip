@@ -197,6 +197,9 @@ __global__ __launch_bounds__(HD_COLS) void head_dx_c_kernel(const float* __restr
 // (Measured and dropped: the head's dX formed in the same pass -- both kernels want the batch row's gradients as scalars and
 // x[b][i] once.  34.2 us fused against 14.7 (lbbnn_head_dx) + 14.8 here: 40 accumulator / operand registers per thread and a
 // 256-B store per wave and row inside the loop cost more than the second read of the 19.7 MB activation.)
+// (Measured and dropped too: the same slabs on v_mfma_f32_16x16x4_f32 -- classes as M, four batch rows as K, a lane's float4
+// of x as the B operands of four column tiles, eight waves per workgroup adding their tiles pairwise through LDS: correct to
+// 2e-6, 17.3 us against 14.5 here.)
 constexpr int HW_COLS = 64, HW_LANES = 8;
 
 template <int C>
