@@ -401,20 +401,30 @@ __device__ __forceinline__ void gemm_f16s_body(const G16Args& a) {
             } else {
                 const float4 f0 = __builtin_bit_cast(float4, xu[j][0]), f1 = __builtin_bit_cast(float4, xu[j][1]);
                 const float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
-                uint32_t ph[4], pl[4], qh[4], ql[4];
+                uint32_t ph[4], pl[4], qh[4] = {0, 0, 0, 0}, ql[4] = {0, 0, 0, 0};
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const float v0 = v[2 * t], v1 = v[2 * t + 1];
                     ph[t] = cvt_pk_h(v0, v1);
                     pl[t] = cvt_pk_h(v0 - h_lo(ph[t]), v1 - h_hi(ph[t]));
-                    const float s0 = (v0 * v0) * kS2, s1 = (v1 * v1) * kS2;
-                    qh[t] = cvt_pk_h(s0, s1);
-                    ql[t] = 0;
-                    if (NPV == 3) ql[t] = cvt_pk_h(s0 - h_lo(qh[t]), s1 - h_hi(qh[t]));
+                    if (NPV == 3) {
+                        const float s0 = (v0 * v0) * kS2, s1 = (v1 * v1) * kS2;
+                        qh[t] = cvt_pk_h(s0, s1);
+                        ql[t] = cvt_pk_h(s0 - h_lo(qh[t]), s1 - h_hi(qh[t]));
+                    }
                 }
                 xh[j] = __builtin_bit_cast(f16x8, make_uint4(ph[0], ph[1], ph[2], ph[3]));
                 xl[j] = __builtin_bit_cast(f16x8, make_uint4(pl[0], pl[1], pl[2], pl[3]));
-                sh[j] = __builtin_bit_cast(f16x8, make_uint4(qh[0], qh[1], qh[2], qh[3]));
+                if (NPV == 1) {
+                    // the one variance product takes s from the halves just made, as the plane form does (a a + a b: four packed
+                    // fp16 instructions per 8 k instead of two packed fp32 multiplies and a conversion per 2 k) -- and a layer fed
+                    // fp32 rows now computes bit for bit what the same layer computes from lbbnn_format_x's planes
+                    const f16x8 pa = xh[j] * (_Float16)0.0625f, pb = xl[j] * (_Float16)0.125f;
+                    const f16x8 t2 = pa * pb;
+                    sh[j] = pa * pa + t2;
+                } else {
+                    sh[j] = __builtin_bit_cast(f16x8, make_uint4(qh[0], qh[1], qh[2], qh[3]));
+                }
                 sl[j] = __builtin_bit_cast(f16x8, make_uint4(ql[0], ql[1], ql[2], ql[3]));
             }
         }
