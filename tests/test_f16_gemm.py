@@ -165,6 +165,10 @@ def test_gemm16_plane_output_feeds_the_next_layer_bitwise(bnn, dev, B, I, O, pre
     # fp32 rows ARE representable (hi + lo exact): feed out (already rounded to hi + lo by construction? no -- so compare values)
     o2 = ops.lrt_gemm16(ops.format_x(x), *args[1:], x_planes=True, eps=eps, **kw2)[0]
     assert rel_err(o2, out) < (3e-5 if prec == "fp16x3f" else 2e-6)
+    if prec == "fp16x3f":
+        # 3 + 1 products: the fp32-row form splits x into the same hi | lo halves lbbnn_format_x writes and takes s from them
+        # by the same four packed instructions -- the same bits, whichever way x arrives
+        assert torch.equal(o2, out)
 
 
 def test_range_overflow_is_loud(bnn, dev):
