@@ -52,7 +52,9 @@ class _ElboLossFn(torch.autograd.Function):
                                                                   scale, g_logp.data_ptr(), g_logits.data_ptr(),
                                                                   g_kl.data_ptr() if has_kl else None, stream),
                        "lbbnn_elbo_loss_backward_logits")
-            _LOGITS_GRAD[lp.data_ptr()] = (g_logp.data_ptr(), g_logits)
+            # the entry HOLDS lp and g_logp: while it exists their storage cannot be freed and handed to another tensor, so
+            # "same address" in the head's backward means "same tensor" (an address alone could be a reused block)
+            _LOGITS_GRAD[lp.data_ptr()] = (g_logp.data_ptr(), g_logits, lp, g_logp)
         else:
             _lib.check(_lib.lib().lbbnn_elbo_loss_backward(g.data_ptr(), target.data_ptr(), B, C, scale, g_logp.data_ptr(),
                                                            g_kl.data_ptr() if has_kl else None, stream), "lbbnn_elbo_loss_backward")
