@@ -527,7 +527,10 @@ class _BayesLinearBase(nn.Module):
             return 0
         if (ops.f16s_precision(self) and (cfg is None or cfg[0]) and ops.f16s_eligible(self.in_features, self.out_features)
                 and getattr(self, "_f16s_net_ok", True)):
-            return 3 if ops.get_precision(self) == "fp16x3f" else 2
+            # the single variance product of "fp16x3f" rounds s and var_w to 11 bits each: that averages out over a long row
+            # (1.4-1.8e-5 of max|out| at I = 784 ... 1200, ~1 / sqrt(I)) but not over a short one (6.5e-5 measured at I = 8,
+            # 4.3-4.7e-5 at I = 72 ... 104: tools/gemm16_fuzz.py), so short rows -- whose GEMMs cost nothing -- take all three
+            return 3 if (ops.get_precision(self) == "fp16x3f" and self.in_features >= ops.F16_VAR1_MIN_I) else 2
         return 1
 
     def _single(self):

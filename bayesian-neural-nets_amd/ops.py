@@ -80,6 +80,9 @@ def split_eligible(I: int, O: int) -> bool:
     return O > 16 and I % 8 == 0 and (I % 32 == 0 or operand_ld(I) - I >= 8) and O * operand_ld(I) * 4 < 0x7FFFFFF0
 
 
+F16_VAR1_MIN_I = 256          # "fp16x3f": rows shorter than this keep three variance products (layers._split)
+
+
 def f16s_eligible(I: int, O: int) -> bool:
     """Shapes the row-scaled fp16 format takes: what the split kernels take, and rows of at most 1280 weights (the weight
     pass scales a row by its maximum, which it holds in registers: weight_pass.hip)."""

@@ -359,3 +359,28 @@ def test_head_fold_equals_the_unfolded_forward(bnn, dev, prec, dims, B, monkeypa
     assert elementwise_violation(res[True][0], res[False][0].double(), rtol=1e-4, atol_frac=atol) <= 1.0
     assert torch.equal(res[True][1], res[False][1])
     assert float((res[True][0].exp().sum(dim=1) - 1).abs().max()) < 1e-5            # rows are log-probabilities
+
+
+def test_fp16x3f_keeps_three_variance_products_on_short_rows(bnn, dev):
+    """"fp16x3f" is the 3 + 1 form from ops.F16_VAR1_MIN_I weights per row up: the roundings of the single variance product
+    average out as 1 / sqrt(I) (tools/gemm16_fuzz.py: 8e-5 of max|out| on the raw entry point at I = 8 ... 104, 1.4-1.8e-5 at
+    the headline's 784 / 1200).  A shorter row takes format 2 (all three products) under the same precision setting and
+    meets the 3 + 3 form's bar."""
+    from bnn_amd import ops
+    assert ops.F16_VAR1_MIN_I == 256
+    for I, want in ((96, 2), (248, 2), (256, 3), (784, 3)):
+        torch.manual_seed(I)
+        layer = bnn.mnf.BayesianLinear(I, 80, 2, z_flow_type="Planar", r_flow_type="Planar").to(dev).train()
+        layer.precision = "fp16x3f"
+        g = torch.Generator().manual_seed(I + 1)
+        x = torch.rand(64, I, generator=g)
+        noise = {"eps_z": torch.randn(1, I, generator=g), "eps_out": torch.randn(64, 80, generator=g),
+                 "eps_z2": torch.randn(1, I, generator=g), "eps_act": torch.randn(80, generator=g)}
+        layer.noise = {k: v.to(dev) for k, v in noise.items()}
+        with torch.no_grad():
+            out = layer(x.to(dev), sample=True)
+        assert layer._split_now == want, (I, layer._split_now)
+        p = {k: v.detach().cpu().double() for k, v in layer.state_dict().items()}
+        zf, rf = orc.flow_from_state("z_flow", "Planar", p, 2), orc.flow_from_state("r_flow", "Planar", p, 2)
+        ref, _, _ = orc.mnf_forward(x.double(), p, zf, rf, {k: v.double() for k, v in noise.items()})
+        assert rel_err(out, ref) < (BARS["fp16x3"][0] if want == 2 else BARS["fp16x3f"][0]), (I, rel_err(out, ref))
