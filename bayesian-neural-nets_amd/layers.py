@@ -1072,8 +1072,10 @@ class _NetworkBase(nn.Module):
         for i, l in enumerate(self._layers()):
             l._layer_id = i
         # the batched weight pass of a network is ONE launch: the row-scaled fp16 format needs every row of every layer in
-        # one register batch there (<= 1280 weights per row, weight_pass.hip), so a network with a wider layer keeps bf16x3
-        ok = all(ops.operand_ld(l.in_features) <= 1280 for l in self._layers())
+        # one register batch of the vector row kernel there (<= 1280 weights per row, rows of whole float4s: weight_pass.hip
+        # launch_weight_pass), so a network with a wider layer, or one whose row length is not a multiple of 4, keeps bf16x3
+        # for the layers that qualify for it (found by tools/net_train_fuzz.py: 17-wide head under an fp16 first layer)
+        ok = all(ops.operand_ld(l.in_features) <= 1280 and l.in_features % 4 == 0 for l in self._layers())
         for l in self._layers():
             l._f16s_net_ok = ok
         self._plane_cache = {}

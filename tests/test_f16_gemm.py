@@ -384,3 +384,35 @@ def test_fp16x3f_keeps_three_variance_products_on_short_rows(bnn, dev):
         zf, rf = orc.flow_from_state("z_flow", "Planar", p, 2), orc.flow_from_state("r_flow", "Planar", p, 2)
         ref, _, _ = orc.mnf_forward(x.double(), p, zf, rf, {k: v.double() for k, v in noise.items()})
         assert rel_err(out, ref) < (BARS["fp16x3"][0] if want == 2 else BARS["fp16x3f"][0]), (I, rel_err(out, ref))
+
+
+@pytest.mark.parametrize("dims", [(784, 80, 17, 10), (100, 33, 64, 16), (784, 1400, 64, 10)])
+def test_network_with_a_layer_outside_the_fp16_row_kernel_keeps_bf16x3(bnn, dev, dims):
+    """The network's weight pass is ONE launch; the row-scaled fp16 format exists in its vector row kernel only (rows of
+    whole float4s, at most 1280 weights).  A network with one layer outside that (a 17- or 33-wide row, a 1400-wide one)
+    runs its eligible layers in bf16x3 under an fp16 precision setting, training and inference, instead of failing in
+    lbbnn_layers_operands_snap (found by tools/net_train_fuzz.py)."""
+    torch.manual_seed(3)
+    net = bnn.mnf.BayesianNetwork(dims, 2, z_flow_type="Planar", r_flow_type="Planar").to(dev).train()
+    net.set_precision("fp16x3f")
+    g = torch.Generator().manual_seed(4)
+    B = 64
+    x = torch.rand(B, dims[0], generator=g)
+    y = torch.randint(0, dims[3], (B,), generator=g)
+    lay = [net.l1, net.l2, net.l3]
+    noises = [{"eps_z": torch.randn(1, l.in_features, generator=g), "eps_out": torch.randn(B, l.out_features, generator=g),
+               "eps_z2": torch.randn(1, l.in_features, generator=g), "eps_act": torch.randn(l.out_features, generator=g)} for l in lay]
+    for l, n in zip(lay, noises):
+        l.noise = {k: v.to(dev) for k, v in n.items()}
+    out = net(x.to(dev), sample=True)
+    assert all(l._split_now in (0, 1) for l in lay) and net.l1._split_now == (1 if dims[0] % 8 == 0 else 0)
+    loss = torch.nn.functional.nll_loss(out, y.to(dev), reduction="sum") + net.kl() / 10
+    loss.backward()
+    P = [{k: v.detach().cpu().double() for k, v in l.state_dict().items()} for l in lay]
+    zf = [orc.flow_from_state("z_flow", "Planar", p, 2) for p in P]
+    rf = [orc.flow_from_state("r_flow", "Planar", p, 2) for p in P]
+    ref, ref_kl = orc.mnf_network_forward(x.double(), P, zf, rf, [{k: v.double() for k, v in n.items()} for n in noises])
+    assert rel_err(out, ref) < 2e-6
+    with torch.no_grad():
+        out2 = net(x.to(dev), sample=True)
+    assert rel_err(out2, ref) < 2e-6

@@ -54,6 +54,19 @@ def test_network_structure_and_names():
     assert (ref_net.l1.in_features, ref_net.l2.out_features, ref_net.l3.out_features) == (784, 600, 10)
 
 
+def test_network_level_rule_for_the_row_scaled_fp16_format():
+    """One weight-pass launch per network: the fp16 format is chosen only when EVERY layer fits its vector row kernel (rows
+    of whole float4s, at most 1280 weights) -- layers._number_layers; the headline network does."""
+    import bnn_amd
+    for dims, ok in (((784, 1200, 1200, 10), True), ((784, 80, 17, 10), False), ((100, 33, 64, 16), False),
+                     ((784, 1400, 64, 10), False), ((784, 96, 64, 10), True)):
+        net = bnn_amd.mnf.BayesianNetwork(dims, 2, z_flow_type="Planar", r_flow_type="Planar")
+        assert all(l._f16s_net_ok == ok for l in net._layers()), dims
+        net.set_precision("fp16x3f")
+        want = ((3 if dims[0] >= 256 else 2) if ok else 1) if dims[0] % 8 == 0 else 0
+        assert net.l1._split(None, (True, True, False)) == want, dims
+
+
 def test_eval_helpers_match_reference_objects():
     import bnn_amd
     torch.manual_seed(0)
