@@ -480,6 +480,9 @@ __device__ __forceinline__ void gemm_f16s_body(const G16Args& a) {
     // d = 0, 0.1271 / 0.1279 / 0.1304 / 0.1322 at d = 0.85 / 1.7 / 3.4 / 5.1 us -- two thirds of every microsecond of skew
     // come back as time.  A workgroup looping alone does not use what its neighbour leaves free, so an uneven K split
     // between them would buy less than its combine costs: not built.)
+    // (The first layer's in-register split of fp32 x on v_fma_mixlo/mixhi_f16 (f16(x - float(h)) in one instruction per
+    // element, inline asm: 3 VALU per pair instead of the compiler's 5, bit-identical): forward 0.1240 / 0.1238 / 0.1237 ms
+    // against 0.1240 / 0.1237 / 0.1237 -- the 16 instructions per wave-step are not on the chain either; dropped.)
     dma_step(0, smc);
     __syncthreads();
     for (int c = 0; c < nsteps; ++c) {
