@@ -321,8 +321,17 @@ constexpr int kRowB = 5;                                 // ... of which this ma
 #ifndef LBBNN_K1_ROWS_PER_WG
 #define LBBNN_K1_ROWS_PER_WG 4
 #endif
-constexpr int kRowsWG = LBBNN_K1_ROWS_PER_WG;            // rows (= waves) per workgroup of the row kernel
-constexpr int kRowNT = 64 * kRowsWG;
+// Rows (= waves) per workgroup of the row kernel: the rows of a workgroup share one staging of the layer's per-column vectors
+// (z_fwd, z_kl, r0_c: 14.4 KB at I = 1200).  Measured on the headline forward, round 3, alternating processes on one box
+// (profiles/r03_ab_k1_rows.txt): 4 rows 0.1251 ms, 2 rows 0.1249, 1 row 0.1259, 8 rows 0.1285.  The launch is a single wave of
+// workgroups (2410 rows on 3072 wave slots) and a SIMD holds 2 or 3 of them whatever the grouping; fewer rows per workgroup
+// balance the CUs better (603 four-row workgroups: 3 on 91 CUs, 2 on the rest) but stage the vectors once per row -- 4 x the
+// bytes through each CU's L1, which costs what the balance gains.  (A first run of this experiment staged only the first
+// 2 x 64 x rows float4s of the vectors -- the loop below was written for 4 rows -- and "won" 3 us at 1 row with wrong
+// operands: the loop now covers any workgroup size.)  In-kernel flows (INFLOW) are computed by the four waves together.
+constexpr int kRowsWGFlow = 4;
+constexpr int kRowsWG = LBBNN_K1_ROWS_PER_WG;
+template <bool INFLOW> struct RowsCfg { static constexpr int RW = INFLOW ? kRowsWGFlow : kRowsWG, NT = 64 * RW; };
 
 struct WeightRowsBatch {
     WeightPassArgs l[LBBNN_MAX_LAYERS];
@@ -344,10 +353,11 @@ __device__ __forceinline__ uint32_t dpp_xor1(uint32_t v) { return (uint32_t)dpp_
 // INFLOW: some layer of the launch computes its planar flows inside its workgroups (f.on); the fused forwards since K3v have
 // none, and their instantiation carries neither that code nor its register pressure.
 template <bool F16S, bool INFLOW>
-__global__ __launch_bounds__(kRowNT, 3) void weight_rows_kernel(const WeightRowsBatch bt_) {
+__global__ __launch_bounds__(RowsCfg<INFLOW>::NT, 3) void weight_rows_kernel(const WeightRowsBatch bt_) {
+    constexpr int kRowsWG = RowsCfg<INFLOW>::RW, kRowNT = RowsCfg<INFLOW>::NT;
     const LBBNN_CONST_AS WeightRowsBatch* bt = kernarg_as<WeightRowsBatch>();
     extern __shared__ __attribute__((aligned(16))) float sm[];          // zf[P] | zk[P] | rc[P]
-    __shared__ double red[kInNV][kRowsWG];
+    __shared__ double red[INFLOW ? kInNV : 1][kRowsWG];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (bt->rng_snap && blockIdx.x == 0 && tid == 0) {                   // see weight_pass_kernel
         const uint64_t sd = bt->rng[0], of = bt->rng[1];
@@ -522,7 +532,7 @@ __global__ __launch_bounds__(kRowNT, 3) void weight_rows_kernel(const WeightRows
         }
     } else {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < (64 * kRowG + kRowNT - 1) / kRowNT; ++h) {
             const int j = tid + kRowNT * h;
             if (j < nq) {
                 const bool in = j < iq;
@@ -757,11 +767,14 @@ int launch_weight_pass(const WeightPassArgs* a, int n, hipStream_t s, uint64_t* 
         WeightRowsBatch bt{};
         bt.rng = rng; bt.rng_snap = (rng && rng_snap) ? rng_snap : nullptr; bt.advance = advance;
         int wgs = 0, maxld = 0;
+        bool flow_on = false;
+        for (int i = 0; i < n && flows; ++i) flow_on = flow_on || flows[i].on;
+        const int rw = flow_on ? RowsCfg<true>::RW : RowsCfg<false>::RW;      // rows per workgroup of the instantiation launched
         for (int i = 0; i < n; ++i) {
             bt.l[i] = a[i];
             if (flows) bt.f[i] = flows[i];
             if (bt.f[i].on && advance) return LBBNN_E_FLAGS;     // the in-kernel flows read the live offset in every workgroup
-            wgs += (a[i].O + kRowsWG - 1) / kRowsWG; bt.wg_end[i] = wgs;
+            wgs += (a[i].O + rw - 1) / rw; bt.wg_end[i] = wgs;
             maxld = a[i].ld > maxld ? a[i].ld : maxld;
         }
         for (int i = n; i < LBBNN_MAX_LAYERS; ++i) bt.wg_end[i] = wgs;
@@ -772,10 +785,10 @@ int launch_weight_pass(const WeightPassArgs* a, int n, hipStream_t s, uint64_t* 
         for (int i = 0; i < n; ++i) any_flow = any_flow || bt.f[i].on;
         const dim3 grid(wgs, any_f16 ? 1 : (members > 1 ? members : 1));
         const size_t lds = (size_t)3 * maxld * sizeof(float);
-        if (any_f16 && any_flow)  hipLaunchKernelGGL((weight_rows_kernel<true, true>), grid, dim3(kRowNT), lds, s, bt);
-        else if (any_f16)         hipLaunchKernelGGL((weight_rows_kernel<true, false>), grid, dim3(kRowNT), lds, s, bt);
-        else if (any_flow)        hipLaunchKernelGGL((weight_rows_kernel<false, true>), grid, dim3(kRowNT), lds, s, bt);
-        else                      hipLaunchKernelGGL((weight_rows_kernel<false, false>), grid, dim3(kRowNT), lds, s, bt);
+        if (any_f16 && any_flow)  hipLaunchKernelGGL((weight_rows_kernel<true, true>), grid, dim3(RowsCfg<true>::NT), lds, s, bt);
+        else if (any_f16)         hipLaunchKernelGGL((weight_rows_kernel<true, false>), grid, dim3(RowsCfg<false>::NT), lds, s, bt);
+        else if (any_flow)        hipLaunchKernelGGL((weight_rows_kernel<false, true>), grid, dim3(RowsCfg<true>::NT), lds, s, bt);
+        else                      hipLaunchKernelGGL((weight_rows_kernel<false, false>), grid, dim3(RowsCfg<false>::NT), lds, s, bt);
         return (int)hipGetLastError();
     }
     if (members > 1) return LBBNN_E_ALIGN;                  // the member dimension exists in the row kernel only
