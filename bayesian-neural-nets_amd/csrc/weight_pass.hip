@@ -319,16 +319,18 @@ constexpr int kInNV = 3 * kInT + kInT * (kInT - 1) / 2 + kInT + 1;      // A_k |
 constexpr int kRowG = 8;                                 // float4 groups per lane: ld <= 64 * 4 * 8 = 2048
 constexpr int kRowB = 5;                                 // ... of which this many are loaded together
 #ifndef LBBNN_K1_ROWS_PER_WG
-#define LBBNN_K1_ROWS_PER_WG 4
+#define LBBNN_K1_ROWS_PER_WG 1
 #endif
-// Rows (= waves) per workgroup of the row kernel: the rows of a workgroup share one staging of the layer's per-column vectors
-// (z_fwd, z_kl, r0_c: 14.4 KB at I = 1200).  Measured on the headline forward, round 3, alternating processes on one box
-// (profiles/r03_ab_k1_rows.txt): 4 rows 0.1251 ms, 2 rows 0.1249, 1 row 0.1259, 8 rows 0.1285.  The launch is a single wave of
+// Rows (= waves) per workgroup of the row kernel.  Measured on the headline forward, round 3, alternating processes on one box
+// (profiles/r03_ab_k1_rows.txt).  With the layer's per-column vectors (z_fwd, z_kl, r0_c: 14.4 KB at I = 1200) staged in LDS
+// once per workgroup: 4 rows 0.1251 ms, 2 rows 0.1249, 1 row 0.1259, 8 rows 0.1285 -- the launch is a single wave of
 // workgroups (2410 rows on 3072 wave slots) and a SIMD holds 2 or 3 of them whatever the grouping; fewer rows per workgroup
-// balance the CUs better (603 four-row workgroups: 3 on 91 CUs, 2 on the rest) but stage the vectors once per row -- 4 x the
-// bytes through each CU's L1, which costs what the balance gains.  (A first run of this experiment staged only the first
-// 2 x 64 x rows float4s of the vectors -- the loop below was written for 4 rows -- and "won" 3 us at 1 row with wrong
-// operands: the loop now covers any workgroup size.)  In-kernel flows (INFLOW) are computed by the four waves together.
+// balance the CUs better (603 four-row workgroups: 3 on 91 CUs, 2 on the rest) but stage the vectors once per row, which
+// costs what the balance gains.  ONE row per workgroup with the vectors taken straight into registers, a float4 group at a
+// time beside the row's parameters (no LDS, no barrier; kDirectZ below): 0.1220 against 0.1226 for the 4-row form -- kept.
+// (A first run of this experiment staged only the first 2 x 64 x rows float4s of the vectors -- the loop was written for 4
+// rows -- and "won" 3 us at 1 row with wrong operands: the staging loop now covers any workgroup size.)  In-kernel flows
+// (INFLOW) are computed by four waves together.
 constexpr int kRowsWGFlow = 4;
 constexpr int kRowsWG = LBBNN_K1_ROWS_PER_WG;
 template <bool INFLOW> struct RowsCfg { static constexpr int RW = INFLOW ? kRowsWGFlow : kRowsWG, NT = 64 * RW; };
@@ -389,6 +391,10 @@ __global__ __launch_bounds__(RowsCfg<INFLOW>::NT, 3) void weight_rows_kernel(con
     // the z vectors make their round trip to LDS, instead of after the barrier behind it.  (With the in-kernel flows the same
     // hoist spilled: see above; that path keeps the loads below.)
     float4 mu[kRowB], rho[kRowB], lam[kRowB];
+    // one-row workgroups: no sharing to stage for -- every lane takes its own float4s of the per-column vectors straight
+    // into registers, with the row's parameters (no LDS round trip, no barrier)
+    constexpr bool kDirectZ = !INFLOW && kRowsWG == 1;
+    float4 zfr[1], zkr[1], rcr[1];
     if (!INFLOW && has_row) {
 #pragma unroll
         for (int g = 0; g < kRowB; ++g) {
@@ -396,6 +402,18 @@ __global__ __launch_bounds__(RowsCfg<INFLOW>::NT, 3) void weight_rows_kernel(con
             if (g < G && j < iq) { mu[g] = ld4(a.mu + rowoff, j); rho[g] = ld4(a.rho + rowoff, j); lam[g] = ld4(a.lambdal + rowoff, j); }
         }
     }
+    // (all five groups of the three vectors up front, beside the 15 parameter registers and the operands kept for the row
+    // maximum: 115 spilled VGPRs at the 168 three waves per SIMD leave -- so one group ahead of its use, two register sets)
+    auto load_z = [&](int gg, float4& zf, float4& zk, float4& rc) {
+        const int j = lane + 64 * gg;
+        zf = one4; zk = one4; rc = one4;
+        if (gg < G && j < iq) {
+            if (a.z_fwd) zf = ld4(a.z_fwd + (size_t)mem * P, j);
+            if (a.z_kl) zk = ld4(a.z_kl, j);
+            if (a.r0_c) rc = ld4(a.r0_c, j);
+        }
+    };
+    if constexpr (kDirectZ) { if (has_row) load_z(0, zfr[0], zkr[0], rcr[0]); }
 
     // ---------------------------------------------------------------- per-column vectors of this layer -> LDS
     if (INFLOW && f.on) {
@@ -530,7 +548,7 @@ __global__ __launch_bounds__(RowsCfg<INFLOW>::NT, 3) void weight_rows_kernel(con
             f.scal[4] = ldf;                                                          // logdet of sample_z(B) (:187)
             if (klb) { f.scal[0] = ldq; f.scal[1] = (float)acc[kInNV - 1]; f.scal[2] = ldr; }
         }
-    } else {
+    } else if constexpr (!kDirectZ) {
 #pragma unroll
         for (int h = 0; h < (64 * kRowG + kRowNT - 1) / kRowNT; ++h) {
             const int j = tid + kRowNT * h;
@@ -546,7 +564,7 @@ __global__ __launch_bounds__(RowsCfg<INFLOW>::NT, 3) void weight_rows_kernel(con
             }
         }
     }
-    __syncthreads();
+    if constexpr (!kDirectZ) __syncthreads();
 
     // ---------------------------------------------------------------- one row per wave
     if (!has_row) return;
@@ -577,9 +595,14 @@ __global__ __launch_bounds__(RowsCfg<INFLOW>::NT, 3) void weight_rows_kernel(con
             if (g0 + g >= G) break;
             const int j = lane + 64 * (g0 + g);
             float4 ew = zero4, vw = zero4;
+            if constexpr (kDirectZ) { if (g0 + g > 0) load_z(g0 + g, zfr[0], zkr[0], rcr[0]); }
             if (j < iq) {
-                const float4 zf = reinterpret_cast<const float4*>(zf_s)[j], zk = reinterpret_cast<const float4*>(zk_s)[j];
-                const float4 rc = reinterpret_cast<const float4*>(rc_s)[j];
+                float4 zf, zk, rc;
+                if constexpr (kDirectZ) { zf = zfr[0]; zk = zkr[0]; rc = rcr[0]; }
+                else {
+                    zf = reinterpret_cast<const float4*>(zf_s)[j]; zk = reinterpret_cast<const float4*>(zk_s)[j];
+                    rc = reinterpret_cast<const float4*>(rc_s)[j];
+                }
                 const Elem2 ea = weight_elem_p2(k1_f2{mu[g].x, mu[g].y}, k1_f2{rho[g].x, rho[g].y}, k1_f2{lam[g].x, lam[g].y},
                                                 k1_f2{zf.x, zf.y}, k1_f2{zk.x, zk.y}, k1_f2{rc.x, rc.y}, want_kl, want_act, ec);
                 const Elem2 eb = weight_elem_p2(k1_f2{mu[g].z, mu[g].w}, k1_f2{rho[g].z, rho[g].w}, k1_f2{lam[g].z, lam[g].w},
@@ -784,7 +807,8 @@ int launch_weight_pass(const WeightPassArgs* a, int n, hipStream_t s, uint64_t* 
         bool any_flow = false;
         for (int i = 0; i < n; ++i) any_flow = any_flow || bt.f[i].on;
         const dim3 grid(wgs, any_f16 ? 1 : (members > 1 ? members : 1));
-        const size_t lds = (size_t)3 * maxld * sizeof(float);
+        // (one-row workgroups hold the per-column vectors in registers: no LDS, nothing for the dispatcher to count)
+        const size_t lds = (!flow_on && RowsCfg<false>::RW == 1) ? 0 : (size_t)3 * maxld * sizeof(float);
         if (any_f16 && any_flow)  hipLaunchKernelGGL((weight_rows_kernel<true, true>), grid, dim3(RowsCfg<true>::NT), lds, s, bt);
         else if (any_f16)         hipLaunchKernelGGL((weight_rows_kernel<true, false>), grid, dim3(RowsCfg<false>::NT), lds, s, bt);
         else if (any_flow)        hipLaunchKernelGGL((weight_rows_kernel<false, true>), grid, dim3(RowsCfg<true>::NT), lds, s, bt);
