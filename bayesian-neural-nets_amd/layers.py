@@ -1285,8 +1285,13 @@ class _NetworkBase(nn.Module):
             groups = [dense] if same else [[lc] for lc in dense]
             # (only while a HIP graph is being captured: launched from Python the two event calls and the stream switch cost the
             # host more than the overlap returns -- RNVP forward 0.405 -> 0.454 ms eager, 0.237 -> 0.226 ms replayed)
+            # (not where the second GEMM folds the <= 16-class head into its epilogue -- a three-layer row-scaled fp16 network:
+            # the launch that carries the finalize does not fold, and the unfolded head is another arithmetic (fp32 skinny
+            # kernel), so a captured forward would no longer be the eager one bit for bit; tools/forward_replay_fuzz.py)
+            folds_at_1 = (_HEAD_FOLD and n == 3 and layers[1]._split_now >= 2 and layers[2].out_features <= 16
+                          and layers[2]._split_now == 0 and cfgs[2][0] and cfgs[1][2] and layers[1].out_features % 4 == 0)
             defer = (_DENSE_DEFER and (torch.cuda.is_current_stream_capturing() or _DENSE_DEFER == "always") and n >= 2
-                     and all(c[1] for _, c in dense) and layers[1].out_features > 16
+                     and all(c[1] for _, c in dense) and layers[1].out_features > 16 and not folds_at_1
                      and any(len(l.r_flow.transforms) > 0 for l, _ in dense))
             batches = []
             for grp in groups:
