@@ -38,7 +38,10 @@ def ensemble_forward_batched(net, data: torch.Tensor, samples: int = 10) -> torc
     operands (the variance operand, z-free, once for all), then each layer's GEMM runs all members as gridDim.z slices of
     ONE launch (lbbnn_lrt_gemm_members) -- member m draws at Philox offset (live offset + m), exactly where the m-th of
     ``samples`` consecutive ``net(data, sample=True)`` calls would, so the result is bit-identical to that loop
-    (tests/test_parity_gpu.py::test_ensemble_batched_equals_loop_bitwise)."""
+    (tests/test_parity_gpu.py::test_ensemble_batched_equals_loop_bitwise) under the fp32 and bf16x3 settings.  The member
+    dimension exists in the bf16 hi | lo operand format only: under "fp16x3" / "fp16x3f" the batched form still multiplies in
+    bf16x3 (2.7e-6 of max|out| against fp64, tighter than fp16x3f's 1.4e-5) while the loop's single forwards take the
+    row-scaled fp16 kernels -- same draws, results equal to the formats' error (tools/ensemble_fuzz.py)."""
     import ctypes
     from . import _lib
     net.eval()
