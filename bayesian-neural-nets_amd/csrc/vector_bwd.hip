@@ -556,7 +556,36 @@ __global__ __launch_bounds__(NT) void mnf_flow_planar_backward_batch_kernel(cons
     else flow_planar_backward_body(a, a.in_lds, dyn);
 }
 
+// The bias terms alone (an LRT layer has no other vector-sized parameters): the same arithmetic as the first block of the
+// flow backward kernels above.
+__global__ __launch_bounds__(256) void bias_backward_kernel(const float* bias_mu, const float* bias_rho, const float* g_sum,
+                                                            const float* gv_sum, const float* g_kl, lbbnn_priors_t priors,
+                                                            float* d_bias_mu, float* d_bias_rho, int O) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= O) return;
+    const float er = expf(bias_rho[o]);
+    const float sb = log1pf(er), dsig = er / (1.f + er);
+    float gm = g_sum[o], gs = gv_sum ? gv_sum[o] * 2.f * sb : 0.f;
+    if (g_kl) {
+        const float G = g_kl[0], inv = 1.f / (priors.bias_sigma_prior * priors.bias_sigma_prior);
+        gm += G * (bias_mu[o] - priors.bias_mu_prior) * inv;
+        gs += G * (sb * inv - 1.f / sb);
+    }
+    d_bias_mu[o] = gm;
+    d_bias_rho[o] = gs * dsig;
+}
+
 }  // namespace
+
+extern "C" int lbbnn_bias_backward(const float* bias_mu, const float* bias_rho, const float* g_sum, const float* gv_sum,
+                                   const float* g_kl, const lbbnn_priors_t* priors, float* d_bias_mu, float* d_bias_rho, int O,
+                                   void* stream) {
+    if (!bias_mu || !bias_rho || !g_sum || !priors || !d_bias_mu || !d_bias_rho) return LBBNN_E_NULL;
+    if (O <= 0) return LBBNN_E_SHAPE;
+    hipLaunchKernelGGL(bias_backward_kernel, dim3((O + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), bias_mu,
+                       bias_rho, g_sum, gv_sum, g_kl, *priors, d_bias_mu, d_bias_rho, O);
+    return (int)hipGetLastError();
+}
 
 extern "C" int lbbnn_mnf_aux_backward(const float* act_mu, const float* act_var, const float* eps_act, const float* r0_b1,
                                       const float* r0_b2, const float* zb_last, const float* g_kl, int O, int I,

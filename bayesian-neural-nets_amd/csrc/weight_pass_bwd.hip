@@ -34,7 +34,6 @@ __device__ __forceinline__ void elem_bwd(float mu, float rho, float lam, float g
     czk = 0.f; crc = 0.f;
     if (has_kl) {
         const float d = mu * zk - c.mp;
-        const float one_m = 1.f - alpha;
         const float la = -0.6931471805599453f * __builtin_amdgcn_logf(ope);       // log(alpha) = -log(1 + exp(-lambda))
         const float T = (c.log_sp - k1_log_sigma_of(rho, er, sigma)) - 0.5f + (la - c.log_ap) + (s2 + d * d) * 0.5f * c.inv_sp2;
         Gmu += c.gk * alpha * d * zk * c.inv_sp2;

@@ -53,6 +53,7 @@ _HEAD_FOLD = _os.environ.get("LBBNN_HEAD_FOLD", "1") != "0"
 _ADV_RIDE = _os.environ.get("LBBNN_ADV_RIDE", "1") != "0"          # training forward: the RNG advance rides in the first GEMM's launch
 _V1_BATCH = _os.environ.get("LBBNN_V1_BATCH", "1") != "0"          # all layers' V1 in one launch from the KL sum's backward (A/B knob)
 _DEFER_SUMS = _os.environ.get("LBBNN_DEFER_SUMS", "1") != "0"      # column sums finished with the deferred vector chains (A/B knob)
+_LRT_BIAS_HIP = _os.environ.get("LBBNN_LRT_BIAS_HIP", "1") != "0"   # the LRT layer's bias gradients through lbbnn_bias_backward (A/B knob)
 _HEAD_DW = _os.environ.get("LBBNN_HEAD_DW", "1") != "0"           # the head's weight gradients through lbbnn_head_dw (A/B knob)
 _F16_FIRST_PLANES = _os.environ.get("LBBNN_F16_FIRST", "f32") != "f32"
 _SIDE = {}
@@ -285,6 +286,8 @@ class _BayesLinearFn(torch.autograd.Function):
                     da_mu, da_var, aux = ops.mnf_aux_backward(ctx.saved["act_mu"], ctx.saved["act_var"], noise.get("eps_act"),
                                                               P["r0_b1"], P["r0_b2"], ctx.saved["scal"][3:4], g_kl,
                                                               rng=rng_snap, layer_id=layer._layer_id)
+        elif not layer._mnf and _LRT_BIAS_HIP:
+            z_k = z2 = None                          # an LRT layer: bias vectors only (lbbnn_bias_backward, below)
         else:
             # ---- vector-sized graph (flows, q/r densities, bias terms) under autograd: O(I + O) work
             with torch.enable_grad():
@@ -355,6 +358,11 @@ class _BayesLinearFn(torch.autograd.Function):
         dmu, drho, dlam, dz_k, dz2, dr0c = ops.weight_pass_backward(
             mu, rho, lam, dWm, dWv, z_fwd=z_k, z_kl=z2, r0_c=r0_c, da_mu=da_mu, da_var=da_var, g_kl=g_kl,
             priors=layer.priors, defer_sums=defer_sums)
+        if not layer._mnf and _LRT_BIAS_HIP:
+            # the two bias gradients in one small launch (until round 3: a torch autograd graph over the bias vectors,
+            # ~25 launches per layer inside a captured training step)
+            d_bmu, d_brho = ops.bias_backward(params[3], params[4], g_sum, gv_sum if stochastic else None, g_kl, layer.priors)
+            return (None, gx, None, dmu, drho, dlam, d_bmu, d_brho)
         if planar:
             zp, rp = layer._planar_params_from(params)
             e1 = None if in_kernel else noise["eps_z"].contiguous()

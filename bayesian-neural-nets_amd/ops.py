@@ -618,6 +618,16 @@ def mnf_aux_backward(act_mu, act_var, eps_act, r0_b1, r0_b2, zb_last, g_kl, rng=
     return da_mu, da_var, aux
 
 
+def bias_backward(bias_mu, bias_rho, g_sum, gv_sum, g_kl, priors: Priors):
+    """lbbnn_bias_backward -> (d_bias_mu, d_bias_rho) of a layer without flows (gv_sum / g_kl may be None)."""
+    d_mu, d_rho = torch.empty_like(bias_mu), torch.empty_like(bias_rho)
+    rc = _lib.lib().lbbnn_bias_backward(_ptr(bias_mu, "bias_mu"), _ptr(bias_rho, "bias_rho"), _ptr(g_sum, "g_sum"),
+                                        _ptr(gv_sum), _ptr(g_kl), ctypes.byref(priors), d_mu.data_ptr(), d_rho.data_ptr(),
+                                        bias_mu.shape[0], _stream())
+    _lib.check(rc, "lbbnn_bias_backward")
+    return d_mu, d_rho
+
+
 def mnf_aux_backward_batch(items, g_kl):
     """lbbnn_mnf_aux_backward_batch: V1 of several layers in one launch.  items: dicts with act_mu, act_var, eps_act (or
     None), r0_b1, r0_b2, zb_last, rng (or None), layer_id.  Returns [(da_mu, da_var, aux)] in the same order."""

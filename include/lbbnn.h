@@ -543,6 +543,17 @@ typedef struct {
     uint32_t layer_id;
 } lbbnn_aux_bwd_args_t;
 int lbbnn_mnf_aux_backward_batch(const lbbnn_aux_bwd_args_t* args, int n, void* stream);
+
+/* Gradients of the bias parameters of a layer WITHOUT flows (the LRT layer: BayesianLinear.forward + kl of
+ * LBBNN-GP-MF-LRT.py:171-173, 189-196 differentiated by loss.backward(), :223): activation mean + bias_mu, activation variance
+ * + softplus(bias_rho)^2, KL bias term.  g_sum / gv_sum (O): column sums of the gradients with respect to the activation
+ * mean / variance (lbbnn_output_grad; gv_sum NULL: posterior-mean forward), g_kl: device scalar, the gradient with respect
+ * to the layer's KL (NULL: KL not part of the loss).  d_bias_mu = g_sum + g_kl (mu - mu_p) / s_p^2;
+ * d_bias_rho = (2 sigma gv_sum + g_kl (sigma / s_p^2 - 1 / sigma)) sigmoid(rho).  Replaces the torch autograd graph over the
+ * two bias vectors that the layer's backward built until round 3 (~25 small launches per layer). */
+int lbbnn_bias_backward(const float* bias_mu, const float* bias_rho, const float* g_sum, const float* gv_sum,
+                        const float* g_kl, const lbbnn_priors_t* priors, float* d_bias_mu, float* d_bias_rho, int O,
+                        void* stream);
 int64_t lbbnn_mnf_flow_backward_workspace(int I, int Tz, int Tr);
 int lbbnn_mnf_flow_planar_backward(const lbbnn_flow_bwd_args_t* args, void* stream);
 /* The same for n <= LBBNN_MAX_LAYERS layers in ONE launch (one workgroup per layer): the chains are latency-bound and

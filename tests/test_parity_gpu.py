@@ -2813,3 +2813,44 @@ def test_loss_backward_hands_the_logits_gradient_to_the_head(bnn, dev, monkeypat
     for n in grads[True]:
         assert torch.equal(grads[True][n], grads[False][n]), n
         assert rel_err(grads["torch"][n], grads[False][n]) < 1e-5, n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stochastic_kl", [(True, True), (True, False), (False, False)])
+def test_lrt_bias_gradients_from_the_hip_kernel(bnn, dev, stochastic_kl, monkeypatch):
+    """lbbnn_bias_backward: the LRT layer's bias_mu / bias_rho gradients (activation mean + bias_mu, activation variance +
+    softplus(bias_rho)^2, KL bias term: LBBNN-GP-MF-LRT.py:171-173, 189-196) in one launch instead of a torch autograd graph over
+    the two vectors -- against fp64 autograd of the oracle, and against the torch-graph route kept behind LBBNN_LRT_BIAS_HIP=0;
+    training-mode forward with / without the KL in the loss, and the posterior-mean forward of eval mode (no variance term, no KL:
+    bias_rho gets no gradient)."""
+    from bnn_amd import layers
+    sample, use_kl = stochastic_kl
+    I, O, B = 72, 130, 33
+    torch.manual_seed(21)
+    layer = bnn.lrt.BayesianLinear(I, O)
+    with torch.no_grad():
+        layer.bias_rho.add_(6.0); layer.bias_mu.add_(0.3)          # sigma_b ~ 0.05 instead of e^-9: both KL terms matter
+    p = {k: v.detach().clone() for k, v in layer.state_dict().items()}
+    layer = layer.to(dev).train(sample)
+    g = torch.Generator().manual_seed(22)
+    x, eps, w = torch.rand(B, I, generator=g), torch.randn(B, O, generator=g), torch.randn(B, O, generator=g)
+    grads = {}
+    for hip in (True, False):
+        monkeypatch.setattr(layers, "_LRT_BIAS_HIP", hip)
+        layer.zero_grad()
+        layer.noise = {"eps_out": eps.to(dev)}
+        out = layer(x.to(dev), sample=sample)
+        ((out * w.to(dev)).sum() + (layer.kl / 7 if use_kl else 0)).backward()
+        grads[hip] = {n: (q.grad.clone() if q.grad is not None else torch.zeros_like(q)) for n, q in layer.named_parameters()}
+    p64 = {k: v.double().requires_grad_(True) for k, v in p.items()}
+    o, kl, _ = orc.lrt_forward(x.double(), p64, eps.double() if sample else None, stochastic=sample, compute_kl=sample)
+    ((o * w.double()).sum() + (kl / 7 if use_kl else 0)).backward()
+    for n in ("bias_mu", "bias_rho"):
+        ref = p64[n].grad
+        if ref is None or float(ref.abs().max()) == 0:
+            assert float(grads[True][n].abs().max()) == 0, n
+            continue
+        assert rel_err(grads[True][n], ref) < 2e-6, (n, rel_err(grads[True][n], ref))
+        assert rel_err(grads[True][n], grads[False][n].cpu().double()) < 2e-6, n
+    for n in ("weight_mu", "weight_rho", "lambdal"):
+        assert torch.equal(grads[True][n], grads[False][n]), n
