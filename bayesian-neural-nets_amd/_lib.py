@@ -232,6 +232,7 @@ SIGNATURES = {
     "lbbnn_mnf_aux_backward": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_u32, c_p]),
     "lbbnn_mnf_aux_backward_batch": (c_i, [c_p, c_i, c_p]),
     "lbbnn_bias_backward": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p]),
+    "lbbnn_bias_backward_partials": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "lbbnn_mnf_flow_backward_workspace": (c_i64, [c_i, c_i, c_i]),
     "lbbnn_mnf_flow_planar_backward": (c_i, [ctypes.POINTER(FlowBwdArgs), c_p]),
     "lbbnn_mnf_flow_planar_backward_batch": (c_i, [ctypes.POINTER(FlowBwdArgs), c_i, c_p]),

@@ -101,6 +101,45 @@ __global__ __launch_bounds__(1024) void output_grad_sum_kernel(const float* __re
     reduce_partials_body(work, O, (long long)nbt * O, nbt, O, gv_sum ? 2 : 1, out, blockIdx.x, part);
 }
 
+// The second level of lbbnn_output_grad's column sums AND what an LRT layer does with them (lbbnn_bias_backward) in one
+// launch: same partial order as reduce_partials_body (wave w adds every 16th block, then 16 partials in a fixed order), so the
+// sums -- and the bias gradients -- are bitwise those of the two stand-alone launches.  Wave 0 ends with Sum_b G_m of its 64
+// columns (-> d_bias_mu), wave 1 with Sum_b G_v (-> d_bias_rho; zero for a posterior-mean forward).
+__global__ __launch_bounds__(1024) void bias_backward_partials_kernel(const float* __restrict__ work, int nbt, int O, int has_gv,
+                                                                      const float* bias_mu, const float* bias_rho,
+                                                                      const float* g_kl, lbbnn_priors_t priors,
+                                                                      float* d_bias_mu, float* d_bias_rho) {
+    __shared__ float part[2][16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f;
+    if (i < O)
+        for (int b = w; b < nbt; b += 16) {
+            const float* p = work + (size_t)b * O + i;
+            s0 += p[0];
+            if (has_gv) s1 += p[(size_t)nbt * O];
+        }
+    part[0][w][lane] = s0; part[1][w][lane] = s1;
+    __syncthreads();
+    if (w < 2 && i < O) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += part[w][k][lane];
+        const float G = g_kl ? g_kl[0] : 0.f, inv = 1.f / (priors.bias_sigma_prior * priors.bias_sigma_prior);
+        if (w == 0) {
+            float gm = s;
+            if (g_kl) gm += G * (bias_mu[i] - priors.bias_mu_prior) * inv;
+            d_bias_mu[i] = gm;
+        } else {
+            const float er = expf(bias_rho[i]);
+            const float sb = log1pf(er), dsig = er / (1.f + er);
+            float gs = has_gv ? s * 2.f * sb : 0.f;
+            if (g_kl) gs += G * (sb * inv - 1.f / sb);
+            d_bias_rho[i] = gs * dsig;
+        }
+    }
+}
+
 struct ReduceBatch { lbbnn_reduce_job_t j[LBBNN_MAX_REDUCE_JOBS]; };
 __global__ __launch_bounds__(1024) void reduce_partials_batch_kernel(const ReduceBatch bt) {
     __shared__ float part[3][16][64];
@@ -297,6 +336,17 @@ extern "C" int lbbnn_output_grad(const lbbnn_outgrad_args_t* p, void* stream) {
     if (a.g_sum)                                            // (else the partials wait in `work` for lbbnn_reduce_partials_batch)
         hipLaunchKernelGGL(output_grad_sum_kernel, dim3((a.O + 63) / 64), dim3(1024), 0, s, a.work, nbt, a.O, a.g_sum,
                            a.std ? a.gv_sum : nullptr);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lbbnn_bias_backward_partials(const float* work, int B, int O, int has_gv, const float* bias_mu,
+                                            const float* bias_rho, const float* g_kl, const lbbnn_priors_t* priors,
+                                            float* d_bias_mu, float* d_bias_rho, void* stream) {
+    if (!work || !bias_mu || !bias_rho || !priors || !d_bias_mu || !d_bias_rho) return LBBNN_E_NULL;
+    if (B <= 0 || O <= 0) return LBBNN_E_SHAPE;
+    const int nbt = (B + TS - 1) / TS;
+    hipLaunchKernelGGL(bias_backward_partials_kernel, dim3((O + 63) / 64), dim3(1024), 0, static_cast<hipStream_t>(stream), work,
+                       nbt, O, has_gv ? 1 : 0, bias_mu, bias_rho, g_kl, *priors, d_bias_mu, d_bias_rho);
     return (int)hipGetLastError();
 }
 

@@ -262,10 +262,12 @@ class _BayesLinearFn(torch.autograd.Function):
         # the second level of those sums is deferred with them: one lbbnn_reduce_partials_batch launch for all layers
         # instead of two ~5 us launches per layer
         defer_sums = _OVERLAP["sums"] if (can_defer and (planar or dense) and _DEFER_SUMS) else None
+        # an LRT layer: the sums' only reader is the bias backward, which takes the partials as they lie (one launch for both)
+        lrt_job = [] if (not layer._mnf and _LRT_BIAS_HIP and B > 0) else None
         g, g_v, gT, g_vT, g_sum, gv_sum = ops.output_grad(
             g_out, out=out if relu else None, std=std if stochastic else None, eps=explicit.get("eps_out"),
             rng=ctx.saved.get("rng"), rng_stream=ops.STREAM_EPS_OUT * 64 + layer._layer_id, row_offset=layer.row_offset,
-            relu=relu, want_g=bool(ctx.needs_input_grad[1]), defer_sums=defer_sums)
+            relu=relu, want_g=bool(ctx.needs_input_grad[1]), defer_sums=lrt_job if lrt_job is not None else defer_sums)
         # planar / dense MNF layers re-create their small draws inside V1 / V2; the torch-graph paths need them as tensors
         rng_snap = ctx.saved.get("rng")
         in_kernel = (planar or dense) and not explicit and rng_snap is not None
@@ -361,7 +363,10 @@ class _BayesLinearFn(torch.autograd.Function):
         if not layer._mnf and _LRT_BIAS_HIP:
             # the two bias gradients in one small launch (until round 3: a torch autograd graph over the bias vectors,
             # ~25 launches per layer inside a captured training step)
-            d_bmu, d_brho = ops.bias_backward(params[3], params[4], g_sum, gv_sum if stochastic else None, g_kl, layer.priors)
+            if lrt_job:
+                d_bmu, d_brho = ops.bias_backward_partials(lrt_job[0], B, params[3], params[4], g_kl, layer.priors)
+            else:
+                d_bmu, d_brho = ops.bias_backward(params[3], params[4], g_sum, gv_sum if stochastic else None, g_kl, layer.priors)
             return (None, gx, None, dmu, drho, dlam, d_bmu, d_brho)
         if planar:
             zp, rp = layer._planar_params_from(params)

@@ -628,6 +628,16 @@ def bias_backward(bias_mu, bias_rho, g_sum, gv_sum, g_kl, priors: Priors):
     return d_mu, d_rho
 
 
+def bias_backward_partials(job, B, bias_mu, bias_rho, g_kl, priors: Priors):
+    """lbbnn_bias_backward_partials: `job` is what output_grad(defer_sums=[...]) filed (its partials wait in job["work"])."""
+    d_mu, d_rho = torch.empty_like(bias_mu), torch.empty_like(bias_rho)
+    rc = _lib.lib().lbbnn_bias_backward_partials(job["work"].data_ptr(), B, bias_mu.shape[0], 1 if job["nq"] == 2 else 0,
+                                                 _ptr(bias_mu, "bias_mu"), _ptr(bias_rho, "bias_rho"), _ptr(g_kl),
+                                                 ctypes.byref(priors), d_mu.data_ptr(), d_rho.data_ptr(), _stream())
+    _lib.check(rc, "lbbnn_bias_backward_partials")
+    return d_mu, d_rho
+
+
 def mnf_aux_backward_batch(items, g_kl):
     """lbbnn_mnf_aux_backward_batch: V1 of several layers in one launch.  items: dicts with act_mu, act_var, eps_act (or
     None), r0_b1, r0_b2, zb_last, rng (or None), layer_id.  Returns [(da_mu, da_var, aux)] in the same order."""

@@ -554,6 +554,12 @@ int lbbnn_mnf_aux_backward_batch(const lbbnn_aux_bwd_args_t* args, int n, void* 
 int lbbnn_bias_backward(const float* bias_mu, const float* bias_rho, const float* g_sum, const float* gv_sum,
                         const float* g_kl, const lbbnn_priors_t* priors, float* d_bias_mu, float* d_bias_rho, int O,
                         void* stream);
+/* The same from the column-sum PARTIALS that lbbnn_output_grad leaves in its workspace when called with g_sum == NULL (B, O as
+ * given there; has_gv: the call had std != NULL): the second level of the sums and the bias gradients in one launch, bitwise
+ * what lbbnn_output_grad's own second level followed by lbbnn_bias_backward gives. */
+int lbbnn_bias_backward_partials(const float* work, int B, int O, int has_gv, const float* bias_mu, const float* bias_rho,
+                                 const float* g_kl, const lbbnn_priors_t* priors, float* d_bias_mu, float* d_bias_rho,
+                                 void* stream);
 int64_t lbbnn_mnf_flow_backward_workspace(int I, int Tz, int Tr);
 int lbbnn_mnf_flow_planar_backward(const lbbnn_flow_bwd_args_t* args, void* stream);
 /* The same for n <= LBBNN_MAX_LAYERS layers in ONE launch (one workgroup per layer): the chains are latency-bound and

@@ -2854,3 +2854,15 @@ def test_lrt_bias_gradients_from_the_hip_kernel(bnn, dev, stochastic_kl, monkeyp
         assert rel_err(grads[True][n], grads[False][n].cpu().double()) < 2e-6, n
     for n in ("weight_mu", "weight_rho", "lambdal"):
         assert torch.equal(grads[True][n], grads[False][n]), n
+    # the one-launch form (second level of the column sums + bias gradients: lbbnn_bias_backward_partials) is bitwise the
+    # stand-alone sums followed by lbbnn_bias_backward
+    from bnn_amd import ops
+    gm = torch.randn(B, O, device=dev)
+    std = torch.rand(B, O, device=dev) + 0.1
+    job = []
+    ops.output_grad(gm, std=std if sample else None, eps=eps.to(dev) if sample else None, defer_sums=job)
+    *_, g_sum, gv_sum = ops.output_grad(gm, std=std if sample else None, eps=eps.to(dev) if sample else None)
+    gk = torch.full((), 0.37, device=dev) if use_kl else None
+    a = ops.bias_backward_partials(job[0], B, layer.bias_mu, layer.bias_rho, gk, layer.priors)
+    b = ops.bias_backward(layer.bias_mu, layer.bias_rho, g_sum, gv_sum, gk, layer.priors)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
