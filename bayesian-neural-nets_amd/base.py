@@ -19,6 +19,11 @@ from .distributions import Bernoulli, Gaussian, TEMPER_PRIOR  # noqa: F401  (TEM
 
 _ids = itertools.count(32)
 SAMPLES = 1              # LBBNN-GP-MF.py:38
+# torch.distributions' argument checks of the Gamma / Beta / RelaxedBernoulli draws below: each is a compare + reduce + a
+# host read-back of one bool -- ~35 device-to-host syncs and ~60 launches per sample_elbo step on a GPU (the reference runs on the
+# CPU, where they cost nothing).  The parameters checked are softplus / sigmoid outputs and the positive prior constants: a
+# check can only fire on NaN parameters.  True restores torch's default behaviour (a ValueError at the draw).
+VALIDATE_ARGS = False
 NUM_BATCHES = 600        # len(train_loader) with BATCH_SIZE = 100 on MNIST (LBBNN-GP-MF.py:34,67)
 
 
@@ -33,7 +38,7 @@ class GaussGamma(object):
         self.exact = False
 
     def rsample_tau(self):
-        return torch.distributions.Gamma(self.a, self.b).rsample()
+        return torch.distributions.Gamma(self.a, self.b, validate_args=VALIDATE_ARGS).rsample()
 
     def log_prob(self, input, gamma, tau=None):
         """:140-151.  ``tau``: the Gamma(a, b) draw (default: a fresh ``rsample``, as the reference draws one per call)."""
@@ -62,8 +67,8 @@ class BetaBinomial(object):
                 - torch.lgamma(one * (1 + pa_ + pb_)) - torch.lgamma(one * pa_) - torch.lgamma(one * pb_)).sum()
 
     def rsample(self):
-        p = torch.distributions.Beta(self.pa, self.pb).rsample()
-        return torch.distributions.RelaxedBernoulli(probs=p, temperature=0.001).rsample()
+        p = torch.distributions.Beta(self.pa, self.pb, validate_args=VALIDATE_ARGS).rsample()
+        return torch.distributions.RelaxedBernoulli(probs=p, temperature=0.001, validate_args=VALIDATE_ARGS).rsample()
 
 
 class _BaseFn(torch.autograd.Function):

@@ -55,9 +55,11 @@ class Bernoulli(object):
         self._provider = None
 
     def rsample(self):
+        from . import base                                 # (base.VALIDATE_ARGS: torch's argument checks cost a host sync per draw)
         if self.exact:
-            return torch.distributions.Bernoulli(self.alpha).sample()
-        return torch.distributions.RelaxedBernoulli(probs=self.alpha, temperature=TEMPER_PRIOR).rsample()
+            return torch.distributions.Bernoulli(self.alpha, validate_args=base.VALIDATE_ARGS).sample()
+        return torch.distributions.RelaxedBernoulli(probs=self.alpha, temperature=TEMPER_PRIOR,
+                                                    validate_args=base.VALIDATE_ARGS).rsample()
 
     def log_prob(self, input):
         g = torch.round(input.detach()) if self.exact else input
