@@ -2,7 +2,9 @@
 """Random shapes through the two "next" rows of SURVEY.md section 8: the baseline LBBNN layer (LBBNN-GP-MF.py: relaxed gate x
 Gaussian weight sample, one GEMM, log-prior / log-posterior sums) in its full sample_elbo graph, and the variational-dropout
 layer (variational_dropout.py).  Output, log-probabilities and every gradient from the HIP path against fp64 autograd of the
-oracle on the same draws; all four arithmetics (shapes a 16-bit format does not take run the fp32 kernels).
+oracle on the same draws; all four arithmetics (shapes a 16-bit format does not take run the fp32 kernels).  A gradient's bar is
+5e-4 of its largest entry, or 30 x what torch's own fp32 evaluation of the same graph moves by (the scalar prior parameters'
+gradients are near-cancelling sums).
 Usage: base_vd_fuzz.py [seed] [cases]"""
 import os, random, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -31,7 +33,7 @@ for it in range(N):
     g = torch.Generator().manual_seed(300 + it)
     x = torch.randn(B, I, generator=g)
     wgt = torch.randn(B, O, generator=g)
-    errs = {}
+    errs, e32 = {}, {}
     bnn_amd.set_precision(prec)
     try:
         if which == "vd":
@@ -67,12 +69,22 @@ for it in range(N):
             layer.noise = {"eps_w": eps_w.to(dev), "eps_b": eps_b.to(dev), "tau_w": tau_w, "tau_b": tau_b}
             out = layer(xd, cg, sample=True)
             ((out * wgt.to(dev)).sum() + (layer.log_variational_posterior - layer.log_prior) / 60).backward()
-            P64 = {k: v.double().clone().requires_grad_(True) for k, v in p.items()}
-            x64 = x.double().requires_grad_(True)
-            a64, cg64, tw64, tb64 = build(P64, lambda t: t.double())
-            o, lp, lq = orc.base_forward(x64, P64, cg64, {"eps_w": eps_w.double(), "eps_b": eps_b.double(), "tau_w": tw64, "tau_b": tb64},
-                                         mode="sample", gamma_alpha=a64)
-            ((o * wgt.double()).sum() + (lq - lp) / 60).backward()
+            def oracle(dt):
+                Pd = {k: v.to(dt).clone().requires_grad_(True) for k, v in p.items()}
+                xd_ = x.to(dt).requires_grad_(True)
+                a_, cg_, tw_, tb_ = build(Pd, lambda t: t.to(dt))
+                o_, lp_, lq_ = orc.base_forward(xd_, Pd, cg_, {"eps_w": eps_w.to(dt), "eps_b": eps_b.to(dt), "tau_w": tw_, "tau_b": tb_},
+                                                mode="sample", gamma_alpha=a_)
+                ((o_ * wgt.to(dt)).sum() + (lq_ - lp_) / 60).backward()
+                return Pd, xd_, o_, lp_, lq_
+
+            P64, x64, o, lp, lq = oracle(torch.float64)
+            # conditioning yardstick: the same graph evaluated by torch in fp32 (the scalar gradients of pa / pb / a / b are sums of
+            # O x I digamma-sized terms that can cancel to ~0: any fp32 evaluation moves there)
+            P32 = oracle(torch.float32)[0]
+            for name in P64:
+                if P64[name].grad is not None and P32[name].grad is not None and float(P64[name].grad.abs().max()) > 0:
+                    e32["d" + name] = float((P32[name].grad.double() - P64[name].grad).abs().max() / P64[name].grad.abs().max())
             errs = {"out": rel(out, o), "log_prior": rel(layer.log_prior, lp), "log_q": rel(layer.log_variational_posterior, lq),
                     "dx": rel(xd.grad, x64.grad)}
             for name, prm in layer.named_parameters():
@@ -80,10 +92,11 @@ for it in range(N):
                     errs["d" + name] = rel(prm.grad, P64[name].grad)
     finally:
         bnn_amd.set_precision("fp32")
-    bad = {k: v for k, v in errs.items() if not v < (2e-5 if k in ("out", "log_prior", "log_q") else 5e-4)}
+    bad = {k: (v, e32.get(k)) for k, v in errs.items()
+           if not v < (2e-5 if k in ("out", "log_prior", "log_q") else max(5e-4, 30 * e32.get(k, 0.0)))}
     k = max(errs, key=errs.get)
-    if errs[k] > worst:
-        worst, worst_at = errs[k], (k, case)
+    if errs[k] > worst and not bad:
+        worst, worst_at = errs[k], (k, "fp32 torch: %.1e" % e32[k] if k in e32 else "", case)
     if bad:
         print("FAIL", case, bad); sys.exit(1)
 print("%d random baseline / variational-dropout layers ok; worst relative error %.2e at %s" % (N, worst, worst_at))
