@@ -176,3 +176,18 @@ def test_round3_entry_points_argument_checks(lib):
     # lbbnn_elbo_loss_backward_logits
     assert lib.lbbnn_elbo_loss_backward_logits(fake, fake, None, 10, 4, 10, ctypes.c_float(0.1), fake, fake, None, None) == -1
     assert lib.lbbnn_elbo_loss_backward_logits(fake, fake, fake, 8, 4, 10, ctypes.c_float(0.1), fake, fake, None, None) == -2
+
+
+def test_bias_backward_entry_points_argument_checks(lib):
+    """lbbnn_bias_backward / lbbnn_bias_backward_partials (the LRT layer's vector-sized backward): early checks, nothing launched."""
+    from bnn_amd import _lib
+    fake = ctypes.c_void_p(4096)
+    pr = _lib.Priors()
+    assert lib.lbbnn_bias_backward(None, fake, fake, fake, fake, ctypes.byref(pr), fake, fake, 10, None) == -1
+    assert lib.lbbnn_bias_backward(fake, fake, None, fake, fake, ctypes.byref(pr), fake, fake, 10, None) == -1    # g_sum is not optional
+    assert lib.lbbnn_bias_backward(fake, fake, fake, None, None, None, fake, fake, 10, None) == -1               # priors
+    assert lib.lbbnn_bias_backward(fake, fake, fake, None, None, ctypes.byref(pr), fake, fake, 0, None) == -2
+    assert lib.lbbnn_bias_backward_partials(None, 64, 10, 1, fake, fake, None, ctypes.byref(pr), fake, fake, None) == -1
+    assert lib.lbbnn_bias_backward_partials(fake, 64, 10, 1, fake, fake, None, ctypes.byref(pr), None, fake, None) == -1
+    assert lib.lbbnn_bias_backward_partials(fake, 0, 10, 1, fake, fake, None, ctypes.byref(pr), fake, fake, None) == -2
+    assert lib.lbbnn_bias_backward_partials(fake, 64, 0, 0, fake, fake, None, ctypes.byref(pr), fake, fake, None) == -2
